@@ -1,0 +1,195 @@
+"""CPU oracle for the MSCKF measurement-update path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a plain NumPy/SciPy restatement of the reference algorithm
+(`/root/reference/src/msckf/MSCKF.py:497-661`, `src/msckf/Camera.py:38-67`,
+`src/utils/geometry.py:222-235`).  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import it; the product path
+(`monocular-visual-inertial-msckf_amd/`) never does and fails loudly when the
+HIP library is missing.
+
+Parity status: PINNED.  The reference holds no tests or golden vectors of its
+own, so this oracle is pinned against outputs of the reference
+itself: `tests/golden/gen_golden.py` imports `/root/reference` (with stub
+modules for cv2/rerun/IPython/XFeat), drives `MSCKF.update` on seeded synthetic
+problems and stores inputs and outputs as `tests/golden/*.npz`;
+`tests/test_oracle_golden.py` checks this file against every one of them.
+
+Every function takes the flat arrays of `UpdateProblem` (see
+`monocular-visual-inertial-msckf_amd/synth.py`), all float64.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import null_space
+from scipy.stats import chi2
+
+
+def skew(w):
+    """reference `src/utils/geometry.py:222-235`."""
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def view_terms(R_WC, t_WC, R0_WC, t0_WC, rho, base, m, uv, K, g):
+    """One view of one feature: residual (2,), OC-projected clone block A (2,6),
+    feature block H_f (2,3).  reference `MSCKF.py:505-544` + `Camera.py:54-67`."""
+    R_CW = R_WC.T                                           # MSCKF.py:507
+    R_CW0 = R0_WC.T                                         # :509
+    Ci_f = R_CW @ (rho * (base - t_WC) + m)                 # :516 (rho-scaled point)
+    W_f = R_WC @ Ci_f + t_WC                                # :517, Camera.py:38-44
+    z = np.linalg.inv(K) @ np.append(uv, 1.0)               # :519
+    z = z[:2] / z[2]                                        # :520
+    z_hat = np.array([Ci_f[0] / Ci_f[2], Ci_f[1] / Ci_f[2]])  # :522
+    r = z - z_hat                                           # :524
+    x, y, zz = Ci_f
+    J = np.array([[1.0 / zz, 0.0, -x / zz ** 2], [0.0, 1.0 / zz, -y / zz ** 2]])  # Camera.py:57-58
+    H_x = np.zeros((2, 6))
+    H_x[:, :3] = J @ skew(Ci_f)                             # Camera.py:65
+    H_x[:, 3:] = -J @ R_CW                                  # Camera.py:66
+    u = np.zeros(6)
+    u[:3] = R_CW0 @ g                                       # MSCKF.py:529
+    u[3:] = skew(W_f - t0_WC) @ g                           # :530
+    A = H_x.copy()
+    den = u @ u
+    if den > 1e-6:                                          # :534
+        A = A - (A @ u)[:, None] * u / den
+    H_f = -H_x[:, 3:]                                       # :536 (from the un-projected H_x)
+    return r, A, H_f
+
+
+def feature_blocks(prob, j):
+    """Stacked r (2M,), dense H_x (2M, d), H_f (2M, 3) of feature j.
+    reference `MSCKF.py:497-548`."""
+    a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+    d = prob.P.shape[0]
+    M = b - a
+    r = np.zeros(2 * M)
+    H_x = np.zeros((2 * M, d))
+    H_f = np.zeros((2 * M, 3))
+    for i in range(M):
+        s = int(prob.obs_slot[a + i])
+        ri, A, Hfi = view_terms(prob.cam_R[s], prob.cam_t[s], prob.cam_R0[s], prob.cam_t0[s],
+                                prob.idp_rho[j], prob.idp_base[j], prob.idp_m[j], prob.obs_uv[a + i],
+                                prob.K, prob.gravity)
+        r[2 * i:2 * i + 2] = ri
+        H_x[2 * i:2 * i + 2, 15 + 6 * s:21 + 6 * s] = A    # MSCKF.py:538-540
+        H_f[2 * i:2 * i + 2] = Hfi
+    return r, H_x, H_f
+
+
+def project_on_nullspace(H_f, r, H_x):
+    """reference `MSCKF.py:554-559` (scipy.linalg.null_space of H_f^T)."""
+    A = null_space(H_f.T)
+    return A.T @ r, A.T @ H_x
+
+
+def gate(r_o, H_o, P, sigma):
+    """reference `MSCKF.py:561-568`; returns (passed, gamma, critical value)."""
+    S_inv = np.linalg.inv(H_o @ P @ H_o.T + sigma ** 2 * np.eye(H_o.shape[0]))
+    gamma = float(r_o @ S_inv @ r_o)
+    crit = float(chi2.ppf(0.95, r_o.shape[0]))
+    return gamma <= crit, gamma, crit
+
+
+def update(prob, dense_noise: bool = False):
+    """The whole `MSCKF.update` + covariance half of `MSCKF.correct`
+    (reference `MSCKF.py:570-614`).
+
+    dense_noise=True allocates R_o = sigma^2 * eye(m) and forms Q^T R_o Q exactly
+    as the reference does (`:589, :598`); False uses R_n = sigma^2 I analytically
+    (identical to 4e-17) so large m stay runnable.
+
+    Returns dict(status, dx, P_new, accepted, gamma, crit, T_H, r_n, n_rejected).
+    status 0 = updated, 1 = no-op (nothing accepted; reference early returns
+    `:584-585, :591-592`)."""
+    P = prob.P
+    d = P.shape[0]
+    F = prob.F
+    sigma = prob.sigma
+    accepted = np.zeros(F, dtype=np.uint8)
+    gammas = np.zeros(F)
+    crits = np.zeros(F)
+    H_list, r_list = [], []
+    for j in range(F):                                       # MSCKF.py:573
+        r, H_x, H_f = feature_blocks(prob, j)
+        r_o, H_o = project_on_nullspace(H_f, r, H_x)
+        ok, gammas[j], crits[j] = gate(r_o, H_o, P, sigma)
+        if not ok:
+            continue                                         # :577-579
+        accepted[j] = 1
+        H_list.append(H_o)
+        r_list.append(r_o)
+    out = dict(status=1, dx=np.zeros(d), P_new=P.copy(), accepted=accepted, gamma=gammas, crit=crits,
+               T_H=None, r_n=None, n_rejected=int(F - accepted.sum()))
+    if not H_list:                                           # :584-585
+        return out
+    H_X = np.vstack(H_list)
+    r_o = np.concatenate(r_list)
+    m = H_X.shape[0]
+    if m == 0:                                               # :591-592
+        return out
+    if m > d:                                                # :594-598
+        Q, R = np.linalg.qr(H_X, mode="reduced")
+        T_H = R
+        r_n = Q.T @ r_o
+        if dense_noise:
+            R_n = Q.T @ (sigma ** 2 * np.eye(m)) @ Q
+        else:
+            R_n = sigma ** 2 * np.eye(d)
+    else:                                                    # :599-602
+        T_H, r_n = H_X, r_o
+        R_n = sigma ** 2 * np.eye(m)
+    S = T_H @ P @ T_H.T + R_n                                # :605
+    Kg = P @ T_H.T @ np.linalg.inv(S)                        # :606
+    dx = Kg @ r_n                                            # :607
+    I = np.eye(d)
+    Pn = (I - Kg @ T_H) @ P @ (I - Kg @ T_H).T + Kg @ R_n @ Kg.T  # :613
+    Pn = (Pn + Pn.T) / 2                                     # :614
+    out.update(status=0, dx=dx, P_new=Pn, T_H=T_H, r_n=r_n, H_X=H_X, r_o=r_o)
+    return out
+
+
+def so3_correction(R, dtheta):
+    """R <- R Exp(dtheta)^T followed by the SVD clean-up.
+    reference `MSCKF.py:625-635` (IMU) and `:649-660` (clones)."""
+    n = np.linalg.norm(dtheta)
+    S = skew(dtheta)
+    if np.isclose(n, 0):
+        E = np.eye(3)
+    else:
+        E = np.eye(3) + (np.sin(n) / n) * S + ((1 - np.cos(n)) / n ** 2) * (S @ S)
+    Rn = R @ E.T
+    U, _, Vt = np.linalg.svd(Rn)
+    return U @ Vt
+
+
+def inject(dx, imu_R, imu_t, imu_v, imu_bg, imu_ba, cam_R, cam_t):
+    """State injection half of `MSCKF.correct` (reference `MSCKF.py:616-661`).
+    Returns new copies (imu_R, imu_t, imu_v, imu_bg, imu_ba, cam_R, cam_t)."""
+    imu_R = so3_correction(imu_R, dx[0:3])
+    imu_bg = imu_bg + dx[3:6]
+    imu_v = imu_v + dx[6:9]
+    imu_ba = imu_ba + dx[9:12]
+    imu_t = imu_t + dx[12:15]
+    cam_R = cam_R.copy()
+    cam_t = cam_t.copy()
+    for i in range(cam_R.shape[0]):
+        dc = dx[15 + 6 * i:21 + 6 * i]
+        cam_R[i] = so3_correction(cam_R[i], dc[:3])
+        cam_t[i] = cam_t[i] + dc[3:6]
+    return imu_R, imu_t, imu_v, imu_bg, imu_ba, cam_R, cam_t
+
+
+def invariants(prob, accepted=None):
+    """Basis-invariant per-problem quantities used to check intermediate HIP
+    stages: G = H_X^T H_X (d, d) and b = H_X^T r_o (d,) over the accepted set."""
+    d = prob.P.shape[0]
+    G = np.zeros((d, d))
+    b = np.zeros(d)
+    for j in range(prob.F):
+        if accepted is not None and not accepted[j]:
+            continue
+        r, H_x, H_f = feature_blocks(prob, j)
+        r_o, H_o = project_on_nullspace(H_f, r, H_x)
+        G += H_o.T @ H_o
+        b += H_o.T @ r_o
+    return G, b

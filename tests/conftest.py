@@ -1,0 +1,46 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    """Returns (UpdateProblem, dict of expected outputs) for one fixture."""
+    from msckf_amd import synth
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    prob = synth.UpdateProblem(
+        P=z["P"], cam_R=z["cam_R"], cam_t=z["cam_t"], cam_R0=z["cam_R0"], cam_t0=z["cam_t0"],
+        gravity=z["gravity"], K=z["K"], sigma=float(z["sigma"]), view_ptr=z["view_ptr"],
+        obs_uv=z["obs_uv"], obs_slot=z["obs_slot"], idp_base=z["idp_base"], idp_m=z["idp_m"],
+        idp_rho=z["idp_rho"], meta={"golden": name})
+    return prob, {k: z[k] for k in z.files}
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))
+
+
+@pytest.fixture(scope="session")
+def engine_lib():
+    """The HIP C-ABI library; GPU tests fail loudly if it is missing."""
+    from msckf_amd import _ffi
+    return _ffi.load()

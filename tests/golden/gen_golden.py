@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE.
+
+Runs only in the build container, where `/root/reference` is mounted; it never
+runs on the GPU box and nothing here is imported by tests.  It imports the
+reference's own `MSCKF` class (stub modules stand in for the cv2 / rerun /
+IPython / XFeat imports its module headers pull in but `update`/`correct`
+never touch -- SURVEY.md Appendix A), builds the reference's objects from a
+seeded synthetic `UpdateProblem`, calls the reference's `MSCKF.update(features)`
+and stores the flat inputs and the captured outputs as `<case>.npz`.
+
+Only numeric arrays are written -- no reference source or bytecode.
+
+    python tests/golden/gen_golden.py            # all cases except the 45 s headline
+    python tests/golden/gen_golden.py --headline # also cfg3 (needs ~12 GB RAM, ~1 min)
+"""
+import argparse
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+for name in ["cv2", "rerun", "IPython", "IPython.display", "modules", "modules.xfeat"]:
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["cv2"].Mat = object
+sys.modules["IPython.display"].display = lambda *a, **k: None
+sys.modules["IPython.display"].clear_output = lambda *a, **k: None
+
+
+class _XFeat:
+    def __init__(self, *a, **k):
+        pass
+
+
+sys.modules["modules.xfeat"].XFeat = _XFeat
+sys.path.insert(0, "/root/reference")
+
+from src.msckf.MSCKF import MSCKF, MSCKFParameters  # noqa: E402
+from src.msckf.Camera import Camera  # noqa: E402
+from src.msckf.FeatureExtractor import Feature  # noqa: E402
+from src.msckf.IMU import IMUMeasurement  # noqa: E402
+from src.utils.geometry import Isometry3D, InverseDepthPoint  # noqa: E402
+
+import scipy  # noqa: E402
+from scipy.stats import chi2  # noqa: E402
+
+import msckf_amd  # noqa: E402
+from msckf_amd import synth  # noqa: E402
+
+
+def realistic_state(N, seed):
+    """Recipe B: drive the reference's own process_imu x10 + state_augmentation
+    per clone from a 15x15 diagonal prior.  Returns (P, cam_R, cam_t, keys)."""
+    rng = np.random.default_rng(1000 + seed)
+    f = MSCKF(MSCKFParameters())
+    f.state.imu.is_initialized = True
+    f.first_measurement_arrived = True
+    f.state.imu.v_W_Ii = np.array([1.2, 0.0, 0.0])
+    f.state.imu.v_W_Ii_null = np.array([1.2, 0.0, 0.0])
+    f.state.imu.gyroscope_bias = np.zeros(3)
+    f.state.imu.accelerometer_bias = np.zeros(3)
+    f.state.covariance = np.diag([1e-4] * 3 + [1e-6] * 3 + [1e-3] * 3 + [1e-5] * 3 + [1e-3] * 3).astype(float)
+    t = 0.0
+    g = f.state.imu.W_gravity
+    for c in range(N):
+        for k in range(10):
+            t += 0.01
+            R = f.state.imu.T_W_Ii.R
+            a_w = np.array([0.3, 0.8 * np.cos(2.0 * t), 0.3 * np.sin(1.3 * t)])
+            acc = R.T @ (a_w + g) + 1e-3 * rng.standard_normal(3)
+            gyro = np.array([0.02 * np.sin(t), 0.03 * np.cos(0.7 * t), 0.05 * np.sin(0.5 * t)]) + 1e-4 * rng.standard_normal(3)
+            f.process_imu(IMUMeasurement(t, gyro, acc))
+        f.state_augmentation()
+    keys = list(f.state.cameras.keys())
+    cam_R = np.stack([f.state.cameras[k].T_W_Ci.R for k in keys])
+    cam_t = np.stack([f.state.cameras[k].T_W_Ci.t for k in keys])
+    return f.state.covariance.copy(), cam_R, cam_t, keys
+
+
+def run_reference(prob, keys=None, imu_seed=0):
+    """Build reference objects from the flat problem, call MSCKF.update, capture."""
+    N, F = prob.N, prob.F
+    params = MSCKFParameters()
+    params.K = prob.K
+    params.sigma_image = prob.sigma
+    params.W_gravity = prob.gravity.copy()
+    f = MSCKF(params)
+    rng = np.random.default_rng(7 + imu_seed)
+    imu_R = synth.so3_exp(0.1 * rng.standard_normal(3))
+    f.state.imu.T_W_Ii = Isometry3D(imu_R.copy(), rng.standard_normal(3))
+    f.state.imu.v_W_Ii = rng.standard_normal(3)
+    f.state.imu.gyroscope_bias = 1e-3 * rng.standard_normal(3)
+    f.state.imu.accelerometer_bias = 1e-2 * rng.standard_normal(3)
+    imu0 = dict(imu_R=f.state.imu.T_W_Ii.R.copy(), imu_t=f.state.imu.T_W_Ii.t.copy(),
+                imu_v=f.state.imu.v_W_Ii.copy(), imu_bg=f.state.imu.gyroscope_bias.copy(),
+                imu_ba=f.state.imu.accelerometer_bias.copy())
+    if keys is None:
+        keys = [10 * (i + 1) for i in range(N)]
+    for i, k in enumerate(keys):
+        cam = Camera(prob.K, 640, 480, Isometry3D(prob.cam_R[i].copy(), prob.cam_t[i].copy()))
+        if not (np.array_equal(prob.cam_R0[i], prob.cam_R[i]) and np.array_equal(prob.cam_t0[i], prob.cam_t[i])):
+            cam.T_W_Ci_null = Isometry3D(prob.cam_R0[i].copy(), prob.cam_t0[i].copy())
+        f.state.cameras[k] = cam
+    f.state.covariance = prob.P.copy()
+    feats = {}
+    for j in range(F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        ft = Feature()
+        ft.keypoints = [prob.obs_uv[i].copy() for i in range(a, b)]
+        ft.camera_indices = [keys[int(prob.obs_slot[i])] for i in range(a, b)]
+        idp = InverseDepthPoint()
+        idp.base = prob.idp_base[j].copy()
+        idp.m = prob.idp_m[j].copy()
+        idp.rho = float(prob.idp_rho[j])
+        ft.inverse_depth_point = idp
+        feats[100 + j] = ft
+
+    # per-feature gate statistics through the reference's own jacobian code
+    gamma = np.zeros(F)
+    crit = np.zeros(F)
+    accepted = np.zeros(F, dtype=np.uint8)
+    d = prob.d
+    G = np.zeros((d, d))
+    bvec = np.zeros(d)
+    for j, ft in enumerate(feats.values()):
+        r_o, H_o = f.compute_residual_and_jacobians(ft)
+        S = H_o @ f.state.covariance @ H_o.T + f.sigma_image ** 2 * np.eye(H_o.shape[0])
+        gamma[j] = float((r_o.T @ np.linalg.inv(S) @ r_o).flatten()[0])
+        crit[j] = float(chi2.ppf(0.95, r_o.shape[0]))
+        accepted[j] = 1 if f.gating_test(r_o, H_o) else 0
+        if accepted[j]:
+            G += H_o.T @ H_o
+            bvec += (H_o.T @ r_o).flatten()
+
+    captured = {}
+    orig_correct = f.correct
+
+    def wrapped(Kg, T_H, R_n, delta_x):
+        captured["T_H"] = np.array(T_H)
+        captured["dx"] = np.array(delta_x).flatten()
+        captured["Rn_dev"] = float(np.abs(R_n - f.sigma_image ** 2 * np.eye(R_n.shape[0])).max())
+        return orig_correct(Kg, T_H, R_n, delta_x)
+
+    f.correct = wrapped
+    rej0 = f.number_of_residuals_discarded_for_gasting_test
+    f.update(feats)
+    n_rej = f.number_of_residuals_discarded_for_gasting_test - rej0
+    status = 0 if "dx" in captured else 1
+    out = dict(
+        status=np.int32(status),
+        dx=captured.get("dx", np.zeros(d)),
+        P_new=f.state.covariance.copy(),
+        accepted=accepted, gamma=gamma, crit=crit, n_rejected=np.int32(n_rej),
+        G=G, b=bvec,
+        ThT_Th=(captured["T_H"].T @ captured["T_H"]) if status == 0 else np.zeros((d, d)),
+        Rn_dev=np.float64(captured.get("Rn_dev", 0.0)),
+        post_imu_R=f.state.imu.T_W_Ii.R.copy(), post_imu_t=f.state.imu.T_W_Ii.t.copy(),
+        post_imu_v=f.state.imu.v_W_Ii.copy(), post_imu_bg=f.state.imu.gyroscope_bias.copy(),
+        post_imu_ba=f.state.imu.accelerometer_bias.copy(),
+        post_cam_R=np.stack([f.state.cameras[k].T_W_Ci.R for k in keys]),
+        post_cam_t=np.stack([f.state.cameras[k].T_W_Ci.t for k in keys]),
+        min_gate_margin=np.float64(np.min(np.abs(gamma - crit) / crit)) if F else np.float64(1.0),
+        **imu0)
+    assert int(accepted.sum()) + int(n_rej) == F
+    return out
+
+
+def save(name, prob, out):
+    arrays = dict(
+        P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
+        gravity=prob.gravity, K=prob.K, sigma=np.float64(prob.sigma), view_ptr=prob.view_ptr,
+        obs_uv=prob.obs_uv, obs_slot=prob.obs_slot, idp_base=prob.idp_base, idp_m=prob.idp_m,
+        idp_rho=prob.idp_rho,
+        versions=np.array([np.__version__, scipy.__version__, sys.version.split()[0]]))
+    arrays.update(out)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    acc = int(out["accepted"].sum())
+    print(f"{name:28s} N={prob.N:3d} F={prob.F:5d} accepted={acc:5d} status={int(out['status'])} "
+          f"|dx|={np.linalg.norm(out['dx']):.3e} margin={float(out['min_gate_margin']):.2e} "
+          f"Rn_dev={float(out['Rn_dev']):.1e} size={os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--headline", action="store_true")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+
+    cases = {}
+    # config 1 and 2, recipe A (random SPD P) and B (P and poses from the reference's own propagation)
+    cases["cfg1_A"] = lambda: (synth.make_problem(10, 50, 5, seed=0), None)
+    cases["cfg2_A"] = lambda: (synth.make_problem(20, 500, 8, seed=1), None)
+
+    def recipe_b(N, F, M, seed):
+        P, cam_R, cam_t, keys = realistic_state(N, seed)
+        prob = synth.make_problem(N, F, M, seed=seed, P=P, poses=(cam_R, cam_t))
+        return prob, keys
+    cases["cfg1_B"] = lambda: recipe_b(10, 50, 5, 2)
+    cases["cfg2_B"] = lambda: recipe_b(20, 500, 8, 3)
+    # edge cases
+    cases["edge_variable_tracks"] = lambda: (synth.make_problem(12, 80, 12, seed=4, variable_tracks=True, min_track=2), None)
+    cases["edge_no_qr_branch"] = lambda: (synth.make_problem(10, 6, 5, seed=5), None)            # m = 42 <= d = 75
+    cases["edge_all_rejected"] = lambda: (synth.make_problem(8, 20, 5, seed=6, sigma=0.01, pixel_noise=80.0), None)   # every gate fails -> no-op
+    cases["edge_some_rejected"] = lambda: (synth.make_problem(12, 120, 6, seed=7, outlier_fraction=0.25, outlier_px=500.0), None)
+    cases["edge_null_pose"] = lambda: (synth.make_problem(10, 60, 6, seed=8, distinct_null=True), None)
+    cases["edge_zero_gravity"] = lambda: (synth.make_problem(10, 60, 6, seed=9, gravity=np.zeros(3)), None)
+    cases["edge_int_K"] = lambda: (synth.make_problem(10, 40, 5, seed=10, K=np.array([[180, 0, 320], [0, 180, 240], [0, 0, 1]])), None)
+    cases["edge_sigma_01"] = lambda: (synth.make_problem(15, 150, 7, seed=11, sigma=0.1, outlier_fraction=0.1, outlier_px=300.0), None)
+    cases["edge_single_feature"] = lambda: (synth.make_problem(6, 1, 4, seed=12), None)
+    cases["edge_full_window_tracks"] = lambda: (synth.make_problem(8, 40, 8, seed=13), None)      # every track spans all clones
+    if args.headline:
+        cases["cfg3_A"] = lambda: (synth.make_problem(30, 2000, 10, seed=0), None)
+
+    for name, mk in cases.items():
+        if args.only and name != args.only:
+            continue
+        prob, keys = mk()
+        out = run_reference(prob, keys)
+        save(name, prob, out)
+
+    if not args.only:
+        table = np.array([0.0] + [chi2.ppf(0.95, k) for k in range(1, 513)])
+        np.save(os.path.join(HERE, "chi2_ppf_095.npy"), table)
+        print("chi2 table written:", table[:4], "...")
+
+
+if __name__ == "__main__":
+    main()

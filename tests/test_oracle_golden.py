@@ -1,0 +1,69 @@
+"""The oracle (oracle/msckf_oracle.py) against every golden fixture captured from
+the reference (tests/golden/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden, rel_err
+from oracle import msckf_oracle as oracle
+
+FAST = [c for c in golden_cases() if c != "cfg3_A"]
+
+
+@pytest.mark.parametrize("case", FAST)
+def test_oracle_matches_reference(case):
+    prob, ref = load_golden(case)
+    out = oracle.update(prob, dense_noise=True)
+    assert out["status"] == int(ref["status"])
+    assert np.array_equal(out["accepted"], ref["accepted"])
+    assert out["n_rejected"] == int(ref["n_rejected"])
+    # gate statistic and chi-square critical values
+    np.testing.assert_allclose(out["gamma"], ref["gamma"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(out["crit"], ref["crit"], rtol=1e-14)
+    assert rel_err(out["dx"], ref["dx"]) < 1e-10
+    assert rel_err(out["P_new"], ref["P_new"]) < 1e-12
+    if out["status"] == 0:
+        assert rel_err(out["T_H"].T @ out["T_H"], ref["ThT_Th"]) < 1e-11
+        G, b = oracle.invariants(prob, out["accepted"])
+        assert rel_err(G, ref["G"]) < 1e-11
+        assert rel_err(b, ref["b"]) < 1e-10
+
+
+@pytest.mark.parametrize("case", ["cfg1_A", "cfg2_B", "edge_some_rejected"])
+def test_analytic_noise_equals_dense(case):
+    """R_n = sigma^2 I analytically is the same update."""
+    prob, ref = load_golden(case)
+    out = oracle.update(prob, dense_noise=False)
+    assert rel_err(out["dx"], ref["dx"]) < 1e-10
+    assert rel_err(out["P_new"], ref["P_new"]) < 1e-12
+
+
+@pytest.mark.parametrize("case", ["cfg1_A", "cfg1_B", "edge_null_pose", "edge_some_rejected"])
+def test_state_injection(case):
+    """reference MSCKF.correct :616-661 (exp-map + SVD clean-up, additive rest)."""
+    prob, ref = load_golden(case)
+    post = oracle.inject(ref["dx"], ref["imu_R"], ref["imu_t"], ref["imu_v"], ref["imu_bg"], ref["imu_ba"],
+                         prob.cam_R, prob.cam_t)
+    names = ["post_imu_R", "post_imu_t", "post_imu_v", "post_imu_bg", "post_imu_ba", "post_cam_R", "post_cam_t"]
+    for got, name in zip(post, names):
+        np.testing.assert_allclose(got, ref[name], rtol=0, atol=1e-13, err_msg=name)
+
+
+def test_headline_fixture_if_present():
+    """cfg3 (N=30, F=2000, M=10): oracle with analytic R_n vs the reference run."""
+    if "cfg3_A" not in golden_cases():
+        pytest.skip("headline fixture not generated")
+    prob, ref = load_golden("cfg3_A")
+    out = oracle.update(prob, dense_noise=False)
+    assert np.array_equal(out["accepted"], ref["accepted"])
+    assert rel_err(out["dx"], ref["dx"]) < 1e-9
+    assert rel_err(out["P_new"], ref["P_new"]) < 1e-11
+
+
+def test_chi2_table():
+    from scipy.stats import chi2
+    import os
+    from conftest import GOLDEN_DIR
+    t = np.load(os.path.join(GOLDEN_DIR, "chi2_ppf_095.npy"))
+    assert t.shape == (513,)
+    for k in (1, 2, 7, 17, 27, 61, 256, 512):
+        assert abs(t[k] - chi2.ppf(0.95, k)) <= 1e-12 * t[k]
