@@ -1,0 +1,173 @@
+/*
+ * msckf_mi355x.h -- C-ABI of the MI355X-native MSCKF measurement-update engine.
+ *
+ * This is the drop-in boundary for ONE path of the reference
+ * (ValerioSpagnoli/Monocular-Visual-Inertial-MSCKF):
+ *
+ *     MSCKF.update(self, features: Dict[int, Feature]) -> None     src/msckf/MSCKF.py:570-609
+ *       + the covariance half of MSCKF.correct(...)                 src/msckf/MSCKF.py:611-614
+ *
+ * i.e. per-feature residual/Jacobian stack (MSCKF.py:497-552, Camera.py:54-67),
+ * left-nullspace projection (:554-559), chi-square gate (:561-568), stacking
+ * (:581-588), QR compression (:594-598), Kalman gain (:604-607) and the
+ * Joseph-form covariance update with symmetrisation (:612-614).
+ * The state injection half of `correct` (:616-661, N+1 3x3 exp-maps) stays on
+ * the host (Python, see monocular-visual-inertial-msckf_amd/api.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes, row-major, float64 ("double") unless stated;
+ *   - "host" pointers are caller-owned and not retained past the call;
+ *   - N = number of camera clones; d = 15 + 6 N is the error-state size, ordered
+ *     [dtheta, db_g, dv, db_a, dp | per clone dtheta_c, dp_c]   (MSCKF.py:171, :258-261);
+ *   - a clone's *slot* is its position in the reference's ordered
+ *     `state.cameras` dict at call time (MSCKF.py:539), NOT its key;
+ *   - feature tracks are CSR: view_ptr[F+1] indexes obs_uv / obs_slot;
+ *   - return value: 0 = state updated, 1 = no-op (no feature passed the gate or
+ *     F == 0: dx = 0, P_out = P, mirrors the early returns MSCKF.py:584-585,
+ *     :591-592), < 0 = error (see msckf_strerror).
+ *   - one context per host thread; calls on a context are serialised.
+ */
+#ifndef MSCKF_MI355X_H
+#define MSCKF_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSCKF_ABI_VERSION 1
+
+#define MSCKF_OK 0
+#define MSCKF_NOOP 1
+#define MSCKF_ERR_ARG (-1)          /* bad argument / size over the context's capacity      */
+#define MSCKF_ERR_HIP (-2)          /* HIP runtime failure (msckf_last_error has the text)  */
+#define MSCKF_ERR_NO_DEVICE (-3)    /* no usable gfx950 device                              */
+#define MSCKF_ERR_NOT_SPD (-4)      /* innovation covariance S not positive definite (the
+                                       reference would raise numpy.linalg.LinAlgError,
+                                       MSCKF.py:562/:606)                                   */
+#define MSCKF_ERR_STATE (-5)        /* call order (e.g. run before set_state/set_features)  */
+#define MSCKF_ERR_DUP_SLOT (-6)     /* a track observes the same clone slot twice           */
+
+#define MSCKF_MAX_TRACK 31          /* views per feature (2M+1 rows fit one wavefront)      */
+
+typedef struct msckf_ctx msckf_ctx;
+
+typedef struct msckf_config {
+    int32_t abi_version;            /* MSCKF_ABI_VERSION                                    */
+    int32_t device;                 /* HIP device ordinal                                   */
+    int32_t max_clones;             /* capacity: N                                          */
+    int32_t max_features;           /* capacity: F                                          */
+    int32_t max_track;              /* capacity: M  (<= MSCKF_MAX_TRACK)                    */
+    int32_t leaf_rows;              /* 0 = default; target stacked rows per QR leaf         */
+    int32_t merge_arity;            /* 0 = default; max children per QR tree node           */
+    int32_t flags;                  /* reserved, 0                                          */
+} msckf_config;
+
+/* Filled by msckf_get_stats / msckf_update (nullable there). Times are device
+ * times from HIP events on the context's stream, in microseconds. */
+typedef struct msckf_stats {
+    int32_t n_features;
+    int32_t n_accepted;
+    int32_t n_rejected;             /* reference counter number_of_residuals_discarded_for_gasting_test, MSCKF.py:578 */
+    int32_t stacked_rows;           /* m = sum of q_j over accepted features                */
+    int32_t n_leaves;
+    int32_t n_levels;               /* QR tree depth (launches of the fold kernel)          */
+    int32_t not_spd;                /* per-feature gate matrices that were not SPD          */
+    int32_t reserved;
+    float us_total;                 /* whole device pipeline                                */
+    float us_feature;               /* K1-K3 kernel                                         */
+    float us_qr;                    /* K5 tree                                              */
+    float us_gain;                  /* K6-K7 kernels                                        */
+    float us_host_prep;             /* host-side sort + tree plan of the last set_features  */
+    float us_h2d;                   /* last host->device upload                             */
+    float us_d2h;                   /* last device->host download                           */
+    float reserved2;
+} msckf_stats;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int msckf_create(msckf_ctx** out, const msckf_config* cfg);
+void msckf_destroy(msckf_ctx* ctx);
+const char* msckf_strerror(int code);
+const char* msckf_last_error(const msckf_ctx* ctx);   /* text of the last HIP failure */
+int msckf_device_count(void);                          /* gfx950 devices visible       */
+
+/* ---- one-shot drop-in: host arrays in, host arrays out ----------------- *
+ * Replaces the arithmetic of MSCKF.update (MSCKF.py:570-609) and the
+ * covariance update of MSCKF.correct (:612-614).
+ *   P        d*d      state.covariance            (MSCKF.py:76)
+ *   cam_R    N*9      Camera.T_W_Ci.R  per slot   (Camera.py:10, MSCKF.py:507)
+ *   cam_t    N*3      Camera.T_W_Ci.t             (MSCKF.py:508)
+ *   cam_R0/t0         Camera.T_W_Ci_null.R / .t   (MSCKF.py:509-510)
+ *   gravity  3        state.imu.W_gravity         (MSCKF.py:529-530)
+ *   Kinv     9        inverse of self.K           (MSCKF.py:519)
+ *   sigma             self.sigma_image            (MSCKF.py:562, :589)
+ *   view_ptr F+1, obs_uv 2*sumM (pixels, Feature.keypoints), obs_slot sumM
+ *   idp_base F*3, idp_m F*3, idp_rho F  InverseDepthPoint.{base,m,rho} (geometry.py:53-71)
+ *   chi2_crit[n_crit]: chi2.ppf(0.95, dof) for dof = 0..n_crit-1 (MSCKF.py:565-566);
+ *                      n_crit must exceed 2*max(M)
+ * outputs (host): dx[d] = delta_x (MSCKF.py:607), P_out[d*d] = covariance after
+ * :613-614, accepted[F] gate result per feature in input order, stats nullable. */
+int msckf_update(msckf_ctx* ctx, int32_t N, const double* P,
+                 const double* cam_R, const double* cam_t,
+                 const double* cam_R0, const double* cam_t0,
+                 const double* gravity, const double* Kinv, double sigma,
+                 int32_t F, const int32_t* view_ptr, const double* obs_uv,
+                 const int32_t* obs_slot, const double* idp_base,
+                 const double* idp_m, const double* idp_rho,
+                 const double* chi2_crit, int32_t n_crit,
+                 double* dx, double* P_out, uint8_t* accepted, msckf_stats* stats);
+
+/* ---- resident path: the same update split so inputs can stay in HBM ---- */
+/* Upload filter state read by update(): P, clone poses, gravity, K^-1, sigma, chi2 table. */
+int msckf_set_state(msckf_ctx* ctx, int32_t N, const double* P,
+                    const double* cam_R, const double* cam_t,
+                    const double* cam_R0, const double* cam_t0,
+                    const double* gravity, const double* Kinv, double sigma,
+                    const double* chi2_crit, int32_t n_crit);
+/* Upload one feature batch (the `features` dict of MSCKF.update): sorts the
+ * tracks by first slot, plans the QR tree and copies everything to HBM. */
+int msckf_set_features(msckf_ctx* ctx, int32_t F, const int32_t* view_ptr,
+                       const double* obs_uv, const int32_t* obs_slot,
+                       const double* idp_base, const double* idp_m,
+                       const double* idp_rho);
+/* Enqueue the whole device pipeline (K1..K7) on the context's stream; async. */
+int msckf_run(msckf_ctx* ctx);
+/* Enqueue `iters` back-to-back pipelines and time them with HIP events on the
+ * context's stream. ms_total = wall between first launch and last completion.
+ * If stage_us is non-NULL it receives 3 floats {feature, qr, gain}: the average
+ * device time of each stage measured with per-stage events in a second pass. */
+int msckf_run_timed(msckf_ctx* ctx, int32_t iters, float* ms_total, float* stage_us);
+int msckf_sync(msckf_ctx* ctx);
+/* Download results of the last run (any pointer may be NULL). Returns 0 / 1 / <0. */
+int msckf_get_result(msckf_ctx* ctx, double* dx, double* P_out, uint8_t* accepted,
+                     msckf_stats* stats);
+/* Keep the updated covariance as the state for the next update (P <- P_out on device). */
+int msckf_commit_covariance(msckf_ctx* ctx);
+
+/* ---- feature-sharded path (one context per GPU / rank) ------------------ *
+ * Each rank holds a shard of the features and the full state.  It runs K1-K5
+ * locally and exports its compressed block [R | Q^T r]: (6N) x (6N+1) doubles,
+ * upper triangular, row-major.  After the blocks are gathered on the root
+ * (RCCL gather, done by the host), the root merges them (QR of the stacked
+ * triangles) and runs K6-K7.  `device_ptr` != 0 means the buffer is HBM. */
+int msckf_run_compress(msckf_ctx* ctx);                 /* K1-K5 on the local shard, async */
+size_t msckf_block_doubles(const msckf_ctx* ctx);       /* 6N * (6N + 1)                   */
+int msckf_export_block(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted);
+int msckf_run_merge_gain(msckf_ctx* ctx, const void* blocks, int32_t n_blocks, int device_ptr,
+                         int32_t total_accepted /* sum of the shards' n_accepted */);
+
+/* ---- introspection for tests (device intermediates, host copies) -------- */
+/* gamma[F] (gate statistic), qdim[F] (dof = projected rows), in input order. */
+int msckf_debug_gate(msckf_ctx* ctx, double* gamma, int32_t* qdim);
+/* Final compressed system: T (6N x 6N, upper triangular) and r_n (6N). */
+int msckf_debug_compressed(msckf_ctx* ctx, double* T, double* rn);
+/* Raw device pointers (as integers) for zero-copy interop: which = 0 dx, 1 P_out, 2 block. */
+uint64_t msckf_device_pointer(msckf_ctx* ctx, int which);
+void* msckf_stream(msckf_ctx* ctx);                     /* hipStream_t of the context */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSCKF_MI355X_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of the C-ABI in include/msckf_mi355x.h.  No fallback: if the
+HIP library has not been built, `load()` raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsckf_mi355x.so")
+ABI_VERSION = 1
+
+OK, NOOP = 0, 1
+ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_SPD, ERR_STATE, ERR_DUP_SLOT = -1, -2, -3, -4, -5, -6
+MAX_TRACK = 31
+
+# every symbol include/msckf_mi355x.h declares
+SYMBOLS = [
+    "msckf_create", "msckf_destroy", "msckf_strerror", "msckf_last_error", "msckf_device_count",
+    "msckf_update", "msckf_set_state", "msckf_set_features", "msckf_run", "msckf_run_timed", "msckf_sync",
+    "msckf_get_result", "msckf_commit_covariance", "msckf_run_compress", "msckf_block_doubles",
+    "msckf_export_block", "msckf_run_merge_gain", "msckf_debug_gate", "msckf_debug_compressed",
+    "msckf_device_pointer", "msckf_stream",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("max_clones", C.c_int32),
+                ("max_features", C.c_int32), ("max_track", C.c_int32), ("leaf_rows", C.c_int32),
+                ("merge_arity", C.c_int32), ("flags", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("n_accepted", C.c_int32), ("n_rejected", C.c_int32),
+                ("stacked_rows", C.c_int32), ("n_leaves", C.c_int32), ("n_levels", C.c_int32),
+                ("not_spd", C.c_int32), ("reserved", C.c_int32),
+                ("us_total", C.c_float), ("us_feature", C.c_float), ("us_qr", C.c_float), ("us_gain", C.c_float),
+                ("us_host_prep", C.c_float), ("us_h2d", C.c_float), ("us_d2h", C.c_float), ("reserved2", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
+
+
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint8)
+
+
+def load():
+    """Load libmsckf_mi355x.so and set prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C monocular-visual-inertial-msckf_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.msckf_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+    lib.msckf_create.restype = C.c_int
+    lib.msckf_destroy.argtypes = [vp]
+    lib.msckf_destroy.restype = None
+    lib.msckf_strerror.argtypes = [C.c_int]
+    lib.msckf_strerror.restype = C.c_char_p
+    lib.msckf_last_error.argtypes = [vp]
+    lib.msckf_last_error.restype = C.c_char_p
+    lib.msckf_device_count.argtypes = []
+    lib.msckf_device_count.restype = C.c_int
+    lib.msckf_update.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int32, _ip, _dp,
+                                 _ip, _dp, _dp, _dp, _dp, C.c_int32, _dp, _dp, _up, C.POINTER(Stats)]
+    lib.msckf_update.restype = C.c_int
+    lib.msckf_set_state.argtypes = [vp, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp, C.c_int32]
+    lib.msckf_set_state.restype = C.c_int
+    lib.msckf_set_features.argtypes = [vp, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp]
+    lib.msckf_set_features.restype = C.c_int
+    for name in ("msckf_run", "msckf_sync", "msckf_run_compress", "msckf_commit_covariance"):
+        getattr(lib, name).argtypes = [vp]
+        getattr(lib, name).restype = C.c_int
+    lib.msckf_run_timed.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.msckf_run_timed.restype = C.c_int
+    lib.msckf_get_result.argtypes = [vp, _dp, _dp, _up, C.POINTER(Stats)]
+    lib.msckf_get_result.restype = C.c_int
+    lib.msckf_block_doubles.argtypes = [vp]
+    lib.msckf_block_doubles.restype = C.c_size_t
+    lib.msckf_export_block.argtypes = [vp, vp, C.c_int, _ip]
+    lib.msckf_export_block.restype = C.c_int
+    lib.msckf_run_merge_gain.argtypes = [vp, vp, C.c_int32, C.c_int, C.c_int32]
+    lib.msckf_run_merge_gain.restype = C.c_int
+    lib.msckf_debug_gate.argtypes = [vp, _dp, _ip]
+    lib.msckf_debug_gate.restype = C.c_int
+    lib.msckf_debug_compressed.argtypes = [vp, _dp, _dp]
+    lib.msckf_debug_compressed.restype = C.c_int
+    lib.msckf_device_pointer.argtypes = [vp, C.c_int]
+    lib.msckf_device_pointer.restype = C.c_uint64
+    lib.msckf_stream.argtypes = [vp]
+    lib.msckf_stream.restype = vp
+    _lib = lib
+    return lib
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def uptr(a):
+    return a.ctypes.data_as(_up)
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"msckf engine error {code}: {text}")
+        self.code = code

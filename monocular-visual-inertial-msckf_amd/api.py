@@ -1,0 +1,234 @@
+"""Host-side mirror of the reference's update interface.
+
+`UpdateEngine.update_problem` is the flat call; `UpdateEngine.update` accepts
+reference-shaped objects (an ordered `cameras` mapping, `Feature`-like records
+with `keypoints`, `camera_indices`, `inverse_depth_point.{base,m,rho}`) exactly
+like `MSCKF.update(features)` (reference `src/msckf/MSCKF.py:570`) reads them, and
+then applies the state injection half of `MSCKF.correct` (`:616-661`) on the
+host.  All arithmetic of the update itself runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from .synth import UpdateProblem
+
+_CHI2 = None
+
+
+def chi2_table() -> np.ndarray:
+    """chi2.ppf(0.95, dof) for dof = 0..512 (index 0 unused), generated once with
+    scipy by tests/golden/gen_golden.py (reference `MSCKF.py:565-566`)."""
+    global _CHI2
+    if _CHI2 is None:
+        _CHI2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "chi2_ppf_095.npy"))
+    return _CHI2
+
+
+@dataclass
+class UpdateResult:
+    status: int              # 0 updated, 1 no-op (nothing accepted)
+    dx: np.ndarray           # (d,)
+    P_new: np.ndarray        # (d, d)
+    accepted: np.ndarray     # (F,) uint8, input order
+    stats: dict
+
+    @property
+    def n_rejected(self) -> int:
+        return int(self.accepted.size - int(self.accepted.sum()))
+
+
+class UpdateEngine:
+    """One context on one MI355X.  Not thread-safe (one engine per host thread)."""
+
+    def __init__(self, max_clones: int = 30, max_features: int = 4096, max_track: int = 30,
+                 device: int = 0, leaf_rows: int = 0, merge_arity: int = 0):
+        self._lib = _ffi.load()
+        if max_track > _ffi.MAX_TRACK:
+            raise ValueError(f"max_track {max_track} > {_ffi.MAX_TRACK}")
+        cfg = _ffi.Config(_ffi.ABI_VERSION, device, max_clones, max_features, max_track, leaf_rows, merge_arity, 0)
+        h = C.c_void_p()
+        rc = self._lib.msckf_create(C.byref(h), C.byref(cfg))
+        if rc != 0:
+            raise _ffi.EngineError(rc, self._lib.msckf_strerror(rc).decode())
+        self._h = h
+        self.max_clones, self.max_features, self.max_track = max_clones, max_features, max_track
+        self._N = 0
+        self._F = 0
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.msckf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, allow_noop=True):
+        if rc == 0 or (allow_noop and rc == 1):
+            return rc
+        text = self._lib.msckf_strerror(rc).decode()
+        if rc == _ffi.ERR_HIP:
+            text += ": " + self._lib.msckf_last_error(self._h).decode()
+        raise _ffi.EngineError(rc, text)
+
+    # -- one-shot drop-in ---------------------------------------------------
+    def update_problem(self, prob: UpdateProblem) -> UpdateResult:
+        """Host arrays in, host arrays out: the arithmetic of `MSCKF.update` +
+        the covariance update of `MSCKF.correct` (reference `MSCKF.py:570-614`)."""
+        N, F, d = prob.N, prob.F, prob.d
+        a = self._pack(prob)
+        chi = _ffi.f64(chi2_table())
+        dx = np.zeros(d)
+        P_out = np.zeros((d, d))
+        acc = np.zeros(max(F, 1), dtype=np.uint8)
+        st = _ffi.Stats()
+        rc = self._lib.msckf_update(
+            self._h, N, _ffi.dptr(a["P"]), _ffi.dptr(a["cam_R"]), _ffi.dptr(a["cam_t"]), _ffi.dptr(a["cam_R0"]),
+            _ffi.dptr(a["cam_t0"]), _ffi.dptr(a["g"]), _ffi.dptr(a["Kinv"]), float(prob.sigma), F,
+            _ffi.iptr(a["view_ptr"]), _ffi.dptr(a["obs_uv"]), _ffi.iptr(a["obs_slot"]), _ffi.dptr(a["idp_base"]),
+            _ffi.dptr(a["idp_m"]), _ffi.dptr(a["idp_rho"]), _ffi.dptr(chi), int(chi.size),
+            _ffi.dptr(dx), _ffi.dptr(P_out), _ffi.uptr(acc), C.byref(st))
+        self._check(rc)
+        self._N, self._F = N, F
+        return UpdateResult(rc, dx, P_out, acc[:F].copy(), st.as_dict())
+
+    @staticmethod
+    def _pack(prob: UpdateProblem) -> dict:
+        K = np.asarray(prob.K, dtype=np.float64)
+        return dict(
+            P=_ffi.f64(prob.P), cam_R=_ffi.f64(prob.cam_R).reshape(-1), cam_t=_ffi.f64(prob.cam_t).reshape(-1),
+            cam_R0=_ffi.f64(prob.cam_R0).reshape(-1), cam_t0=_ffi.f64(prob.cam_t0).reshape(-1),
+            g=_ffi.f64(prob.gravity), Kinv=_ffi.f64(np.linalg.inv(K)),      # reference MSCKF.py:519
+            view_ptr=_ffi.i32(prob.view_ptr), obs_uv=_ffi.f64(prob.obs_uv).reshape(-1),
+            obs_slot=_ffi.i32(prob.obs_slot), idp_base=_ffi.f64(prob.idp_base).reshape(-1),
+            idp_m=_ffi.f64(prob.idp_m).reshape(-1), idp_rho=_ffi.f64(prob.idp_rho))
+
+    # -- resident path ------------------------------------------------------
+    def set_state(self, prob: UpdateProblem):
+        a = self._pack(prob)
+        chi = _ffi.f64(chi2_table())
+        self._check(self._lib.msckf_set_state(
+            self._h, prob.N, _ffi.dptr(a["P"]), _ffi.dptr(a["cam_R"]), _ffi.dptr(a["cam_t"]), _ffi.dptr(a["cam_R0"]),
+            _ffi.dptr(a["cam_t0"]), _ffi.dptr(a["g"]), _ffi.dptr(a["Kinv"]), float(prob.sigma), _ffi.dptr(chi),
+            int(chi.size)), allow_noop=False)
+        self._N = prob.N
+
+    def set_features(self, prob: UpdateProblem):
+        a = self._pack(prob)
+        self._check(self._lib.msckf_set_features(
+            self._h, prob.F, _ffi.iptr(a["view_ptr"]), _ffi.dptr(a["obs_uv"]), _ffi.iptr(a["obs_slot"]),
+            _ffi.dptr(a["idp_base"]), _ffi.dptr(a["idp_m"]), _ffi.dptr(a["idp_rho"])), allow_noop=False)
+        self._F = prob.F
+
+    def load(self, prob: UpdateProblem):
+        self.set_state(prob)
+        self.set_features(prob)
+
+    def run(self):
+        self._check(self._lib.msckf_run(self._h), allow_noop=False)
+
+    def run_compress(self):
+        self._check(self._lib.msckf_run_compress(self._h), allow_noop=False)
+
+    def sync(self):
+        self._check(self._lib.msckf_sync(self._h), allow_noop=False)
+
+    def run_timed(self, iters: int, stages: bool = False):
+        """`iters` back-to-back device pipelines timed with HIP events on the
+        engine's stream.  Returns (ms_total, [us_feature, us_qr, us_gain] or None)."""
+        ms = C.c_float(0)
+        st = (C.c_float * 3)()
+        self._check(self._lib.msckf_run_timed(self._h, iters, C.byref(ms), st if stages else None), allow_noop=False)
+        return float(ms.value), ([float(x) for x in st] if stages else None)
+
+    def result(self) -> UpdateResult:
+        d = 15 + 6 * self._N
+        dx = np.zeros(d)
+        P_out = np.zeros((d, d))
+        acc = np.zeros(max(self._F, 1), dtype=np.uint8)
+        st = _ffi.Stats()
+        rc = self._check(self._lib.msckf_get_result(self._h, _ffi.dptr(dx), _ffi.dptr(P_out), _ffi.uptr(acc), C.byref(st)))
+        return UpdateResult(rc, dx, P_out, acc[:self._F].copy(), st.as_dict())
+
+    def commit_covariance(self) -> int:
+        return self._check(self._lib.msckf_commit_covariance(self._h))
+
+    # -- sharded path -------------------------------------------------------
+    def block_doubles(self) -> int:
+        return int(self._lib.msckf_block_doubles(self._h))
+
+    def export_block(self, dst_ptr: Optional[int] = None):
+        """Copy the local compressed block [R | Q^T r].  With `dst_ptr` (a device
+        address) the copy stays in HBM; otherwise a host array is returned."""
+        n_acc = C.c_int32(0)
+        if dst_ptr is not None:
+            self._check(self._lib.msckf_export_block(self._h, C.c_void_p(dst_ptr), 1, C.byref(n_acc)), allow_noop=False)
+            return None, int(n_acc.value)
+        dc = 6 * self._N
+        blk = np.zeros((dc, dc + 1))
+        self._check(self._lib.msckf_export_block(self._h, blk.ctypes.data_as(C.c_void_p), 0, C.byref(n_acc)),
+                    allow_noop=False)
+        return blk, int(n_acc.value)
+
+    def merge_gain(self, blocks, total_accepted: int, n_blocks: Optional[int] = None):
+        """Root side: QR-merge the gathered blocks and run K6-K7.  `blocks` is a
+        host array (G, 6N, 6N+1) or an int device address (then pass n_blocks)."""
+        if isinstance(blocks, (int, np.integer)):
+            self._check(self._lib.msckf_run_merge_gain(self._h, C.c_void_p(int(blocks)), int(n_blocks), 1,
+                                                       int(total_accepted)), allow_noop=False)
+        else:
+            b = _ffi.f64(blocks)
+            self._check(self._lib.msckf_run_merge_gain(self._h, b.ctypes.data_as(C.c_void_p), int(b.shape[0]), 0,
+                                                       int(total_accepted)), allow_noop=False)
+
+    # -- introspection ------------------------------------------------------
+    def debug_gate(self):
+        g = np.zeros(max(self._F, 1))
+        q = np.zeros(max(self._F, 1), dtype=np.int32)
+        self._check(self._lib.msckf_debug_gate(self._h, _ffi.dptr(g), _ffi.iptr(q)), allow_noop=False)
+        return g[:self._F], q[:self._F]
+
+    def debug_compressed(self):
+        dc = 6 * self._N
+        T = np.zeros((dc, dc))
+        rn = np.zeros(dc)
+        self._check(self._lib.msckf_debug_compressed(self._h, _ffi.dptr(T), _ffi.dptr(rn)), allow_noop=False)
+        return T, rn
+
+    # -- reference-shaped drop-in ---------------------------------------------
+    def update(self, filt, features) -> int:
+        """Drop-in for `MSCKF.update(features)` (reference `MSCKF.py:570-609`)
+        including `correct` (`:611-661`).  `filt` is any object with the
+        attributes the reference method reads: `state.cameras` (ordered mapping
+        key -> camera with `T_W_Ci`, `T_W_Ci_null`, each with `.R`, `.t`),
+        `state.covariance`, `state.imu` (`W_gravity`, `T_W_Ii`, `v_W_Ii`,
+        `gyroscope_bias`, `accelerometer_bias`), `K`, `sigma_image`,
+        `number_of_residuals_discarded_for_gasting_test`.
+        Returns the status (0 updated / 1 no-op); mutates `filt` like the reference."""
+        from .pack import problem_from_reference
+        from .inject import inject_state
+        prob = problem_from_reference(filt, features)
+        res = self.update_problem(prob)
+        filt.number_of_residuals_discarded_for_gasting_test += res.n_rejected        # MSCKF.py:578
+        if res.status != 0:
+            return res.status                                                         # MSCKF.py:584-585
+        filt.state.covariance = res.P_new                                             # MSCKF.py:614 (rebinds)
+        inject_state(filt.state, res.dx)                                              # MSCKF.py:616-661
+        return 0

@@ -1,0 +1,315 @@
+// K1-K3 (+K4 write): one wavefront per tracked feature.
+//
+//   K1  per-view residual and Jacobians           reference MSCKF.py:505-544, Camera.py:54-67
+//   K2  left-nullspace projection of the H_f block reference MSCKF.py:554-559
+//   K3  chi-square gate against the prior P        reference MSCKF.py:561-568
+//   K4  the accepted block [H_o | r_o] is written to the stack in compact form
+//       (only the 6M clone columns the track touches)  reference MSCKF.py:581-588
+//
+// Lane L < 2M owns measurement row L (view L>>1, image axis L&1).  The feature
+// Jacobian H_f (2M x 3) is reduced by three column-pivoted Householder
+// reflectors held in registers (one V row per lane, wavefront reductions over
+// DPP); with Q^T = I - V T^T V^T the projected clone Jacobian is
+//     H_o = D - V Z,   Z = T^T (V^T D)   (3 x 6M)
+// where D is the block-diagonal 2M x 6M matrix of the per-view 2x6 blocks, so
+// V^T D needs only a 2-lane exchange per view.  The gate matrix
+// S = H_o P_sub H_o^T + sigma^2 I is built from E = H_o P_sub with lanes over
+// the 6M columns (each P_sub column is read once), then eliminated in LDS with
+// the residual appended as an extra row, which leaves -gamma in the corner.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wave_ops.h"
+
+namespace msckf {
+
+struct FeatureArgs {
+    int F;                       // features in this launch
+    int ldp;                     // leading dimension of P
+    const int* view_ptr;         // [F+1] CSR, in SORTED feature order
+    const double* obs_uv;        // [sumM*2]
+    const int* obs_slot;         // [sumM]
+    const double* idp_base;      // [F*3]
+    const double* idp_m;         // [F*3]
+    const double* idp_rho;       // [F]
+    const double* cam_R;         // [N*9] R_W_Ci
+    const double* cam_t;         // [N*3]
+    const double* cam_R0;        // [N*9] null-state
+    const double* cam_t0;        // [N*3]
+    const double* P;             // [d*ldp]
+    const double* chi2;          // [n_chi2]
+    int n_chi2;
+    double g[3];
+    double Kinv[9];
+    double sigma2;
+    const long long* blk_off;    // [F] offset (doubles) of the feature's stack block
+    double* stack;               // blocks: column-major (6M+1) columns x 2M rows
+    int* rank;                   // [F] rank of H_f (rows < rank are not part of the projection)
+    unsigned char* accepted;     // [F] (sorted order)
+    double* gamma;               // [F]
+    int* counters;               // [0] accepted, [1] stacked rows, [2] not-SPD gate matrices
+};
+
+// LDS doubles needed for a track of M views.
+__host__ __device__ inline int feature_lds_doubles(int M) {
+    const int R2 = 2 * M, C6 = 6 * M;
+    const int ldE = C6 + 1, ldS = R2 + 2;
+    return R2 * 6 + R2 * 3 + 3 * C6 + 3 * C6 + R2 * ldE + (R2 + 1) * ldS + M /*slots as doubles*/ + 8;
+}
+
+__global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int v0 = p.view_ptr[f];
+    const int M = p.view_ptr[f + 1] - v0;
+    const int R2 = 2 * M, C6 = 6 * M;
+    const int ldE = C6 + 1, ldS = R2 + 2;
+    double* sA = smem;                     // [R2][6]   OC-projected clone block rows (D)
+    double* sV = sA + R2 * 6;              // [R2][3]   Householder vectors
+    double* sZ = sV + R2 * 3;              // [3][C6]
+    double* sZP = sZ + 3 * C6;             // [3][C6]   Z * P_sub
+    double* sE = sZP + 3 * C6;             // [R2][ldE] H_o * P_sub
+    double* sS = sE + R2 * ldE;            // [R2+1][ldS]
+    int* sSlot = reinterpret_cast<int*>(sS + (R2 + 1) * ldS);   // [M]
+
+    // ---------------- K1: one measurement row per lane -----------------------
+    double res = 0.0, a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, h0 = 0, h1 = 0, h2 = 0;
+    const int view = lane >> 1;
+    if (lane < R2) {
+        const int o = v0 + view;
+        const int s = p.obs_slot[o];
+        if ((lane & 1) == 0) sSlot[view] = s;
+        const double* R = p.cam_R + 9 * s;
+        const double* t = p.cam_t + 3 * s;
+        const double* R0 = p.cam_R0 + 9 * s;
+        const double* t0 = p.cam_t0 + 3 * s;
+        const double rho = p.idp_rho[f];
+        const double wx = rho * (p.idp_base[3 * f + 0] - t[0]) + p.idp_m[3 * f + 0];
+        const double wy = rho * (p.idp_base[3 * f + 1] - t[1]) + p.idp_m[3 * f + 1];
+        const double wz = rho * (p.idp_base[3 * f + 2] - t[2]) + p.idp_m[3 * f + 2];
+        // Ci_f = R^T w   (MSCKF.py:516)
+        const double px = R[0] * wx + R[3] * wy + R[6] * wz;
+        const double py = R[1] * wx + R[4] * wy + R[7] * wz;
+        const double pz = R[2] * wx + R[5] * wy + R[8] * wz;
+        // W_f = R Ci_f + t (MSCKF.py:517)
+        const double Wx = R[0] * px + R[1] * py + R[2] * pz + t[0];
+        const double Wy = R[3] * px + R[4] * py + R[5] * pz + t[1];
+        const double Wz = R[6] * px + R[7] * py + R[8] * pz + t[2];
+        const double u = p.obs_uv[2 * o], v = p.obs_uv[2 * o + 1];
+        const double zx = p.Kinv[0] * u + p.Kinv[1] * v + p.Kinv[2];
+        const double zy = p.Kinv[3] * u + p.Kinv[4] * v + p.Kinv[5];
+        const double zw = p.Kinv[6] * u + p.Kinv[7] * v + p.Kinv[8];
+        const double ia = 1.0 / pz;
+        const double jb = -px / (pz * pz);
+        const double jc = -py / (pz * pz);
+        // u = [R0^T g ; (W_f - t0) x g]   (MSCKF.py:528-530)
+        const double gx = p.g[0], gy = p.g[1], gz = p.g[2];
+        const double u0 = R0[0] * gx + R0[3] * gy + R0[6] * gz;
+        const double u1 = R0[1] * gx + R0[4] * gy + R0[7] * gz;
+        const double u2 = R0[2] * gx + R0[5] * gy + R0[8] * gz;
+        const double ex = Wx - t0[0], ey = Wy - t0[1], ez = Wz - t0[2];
+        const double u3 = ey * gz - ez * gy;
+        const double u4 = ez * gx - ex * gz;
+        const double u5 = ex * gy - ey * gx;
+        const double den = u0 * u0 + u1 * u1 + u2 * u2 + u3 * u3 + u4 * u4 + u5 * u5;
+        double J0, J1, J2;   // this lane's row of J (Camera.py:57-58)
+        if ((lane & 1) == 0) {
+            res = zx / zw - px / pz;
+            J0 = ia; J1 = 0.0; J2 = jb;
+            a0 = -jb * py; a1 = -ia * pz + jb * px; a2 = ia * py;          // J skew(Ci_f), row 0
+        } else {
+            res = zy / zw - py / pz;
+            J0 = 0.0; J1 = ia; J2 = jc;
+            a0 = ia * pz - jc * py; a1 = jc * px; a2 = -ia * px;           // row 1
+        }
+        // H_f = J R^T (this row);  H_x[:,3:] = -H_f   (Camera.py:62,66; MSCKF.py:536)
+        h0 = J0 * R[0] + J1 * R[1] + J2 * R[2];
+        h1 = J0 * R[3] + J1 * R[4] + J2 * R[5];
+        h2 = J0 * R[6] + J1 * R[7] + J2 * R[8];
+        a3 = -h0; a4 = -h1; a5 = -h2;
+        if (den > 1e-6) {      // observability-constrained projection (MSCKF.py:532-534)
+            const double au = a0 * u0 + a1 * u1 + a2 * u2 + a3 * u3 + a4 * u4 + a5 * u5;
+            a0 -= au * u0 / den; a1 -= au * u1 / den; a2 -= au * u2 / den;
+            a3 -= au * u3 / den; a4 -= au * u4 / den; a5 -= au * u5 / den;
+        }
+    }
+
+    // ---------------- K2: column-pivoted Householder QR of H_f ---------------
+    // After step k the lane k holds R_kk; rows >= rank span the left null space.
+    double vv0 = 0, vv1 = 0, vv2 = 0;       // this lane's row of V
+    double beta0 = 0, beta1 = 0, beta2 = 0;
+    int rank = 0;
+    double r00 = 0.0;
+    const double tol_scale = 2.220446049250313e-16 * (double)(R2 > 3 ? R2 : 3);
+    {
+        double c0 = h0, c1 = h1, c2 = h2;   // working columns (rows >= k)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k >= R2) break;
+            const bool act = (lane >= k) && (lane < R2);
+            // column norms of the remaining columns over rows >= k
+            double n0 = wave_sum(act ? c0 * c0 : 0.0);
+            double n1 = (k < 2) ? wave_sum(act ? c1 * c1 : 0.0) : -1.0;
+            double n2 = (k < 1) ? wave_sum(act ? c2 * c2 : 0.0) : -1.0;
+            // pivot: bring the largest remaining column to the front (c0)
+            if (n1 > n0 && n1 >= n2) { double t_ = c0; c0 = c1; c1 = t_; n0 = n1; }
+            else if (n2 > n0 && n2 > n1) { double t_ = c0; c0 = c2; c2 = t_; n0 = n2; }
+            const double nrm = sqrt(n0);
+            if (k == 0) r00 = nrm;
+            if (!(nrm > tol_scale * r00) || nrm == 0.0) break;   // numerically rank deficient
+            const double xk = lane_bcast(c0, k);
+            const double alpha = (xk > 0.0) ? -nrm : nrm;
+            const double vk = act ? ((lane == k) ? (xk - alpha) : c0) : 0.0;
+            const double beta = 1.0 / (nrm * (nrm + fabs(xk)));
+            // apply to the remaining columns
+            if (k < 2) {
+                const double d1 = wave_sum(vk * (act ? c1 : 0.0));
+                if (act) c1 -= beta * d1 * vk;
+            }
+            if (k < 1) {
+                const double d2 = wave_sum(vk * (act ? c2 : 0.0));
+                if (act) c2 -= beta * d2 * vk;
+            }
+            if (k == 0) { vv0 = vk; beta0 = beta; }
+            else if (k == 1) { vv1 = vk; beta1 = beta; }
+            else { vv2 = vk; beta2 = beta; }
+            rank = k + 1;
+            // shift: next step works on (c1, c2)
+            c0 = c1; c1 = c2; c2 = 0.0;
+        }
+    }
+    // T of the compact WY form Q = I - V T V^T (forward, columnwise)
+    const double v01 = wave_sum(vv0 * vv1);
+    const double v02 = wave_sum(vv0 * vv2);
+    const double v12 = wave_sum(vv1 * vv2);
+    const double T00 = beta0, T11 = beta1, T22 = beta2;
+    const double T01 = -beta1 * T00 * v01;
+    const double T02 = -beta2 * (T00 * v02 + T01 * v12);
+    const double T12 = -beta2 * T11 * v12;
+
+    // residual: r_o = r - V T^T V^T r
+    const double wr0 = wave_sum(vv0 * res), wr1 = wave_sum(vv1 * res), wr2 = wave_sum(vv2 * res);
+    const double zr0 = T00 * wr0;
+    const double zr1 = T01 * wr0 + T11 * wr1;
+    const double zr2 = T02 * wr0 + T12 * wr1 + T22 * wr2;
+    const double ro = res - (vv0 * zr0 + vv1 * zr1 + vv2 * zr2);
+
+    // W = V^T D (2-lane exchange per view), Z = T^T W
+    {
+        const double av[6] = {a0, a1, a2, a3, a4, a5};
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double w0 = vv0 * av[a], w1 = vv1 * av[a], w2 = vv2 * av[a];
+            w0 += dpp_move<0xB1>(w0);
+            w1 += dpp_move<0xB1>(w1);
+            w2 += dpp_move<0xB1>(w2);
+            if (lane < R2 && (lane & 1) == 0) {
+                const int c = 6 * view + a;
+                sZ[c] = T00 * w0;
+                sZ[C6 + c] = T01 * w0 + T11 * w1;
+                sZ[2 * C6 + c] = T02 * w0 + T12 * w1 + T22 * w2;
+            }
+        }
+        if (lane < R2) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) sA[lane * 6 + a] = av[a];
+            sV[lane * 3 + 0] = vv0; sV[lane * 3 + 1] = vv1; sV[lane * 3 + 2] = vv2;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- K4: write the compact block [H_o | r_o] ----------------
+    const int q = R2 - rank;
+    {
+        double* blk = p.stack + p.blk_off[f];
+        const bool live = (lane >= rank);
+        if (lane < R2) {
+            const double av[6] = {a0, a1, a2, a3, a4, a5};
+            for (int vw = 0; vw < M; ++vw) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int c = 6 * vw + a;
+                    double x = -(vv0 * sZ[c] + vv1 * sZ[C6 + c] + vv2 * sZ[2 * C6 + c]);
+                    if (vw == view) x += av[a];
+                    blk[c * R2 + lane] = live ? x : 0.0;
+                }
+            }
+            blk[C6 * R2 + lane] = live ? ro : 0.0;
+        }
+    }
+
+    // ---------------- K3: gate ------------------------------------------------
+    // pass 1, lanes over columns c of P_sub: E = D P_sub (block rows) and ZP = Z P_sub
+    for (int c = lane; c < C6; c += 64) {
+        const int colg = 15 + 6 * sSlot[c / 6] + (c % 6);
+        double zp0 = 0, zp1 = 0, zp2 = 0;
+        for (int vw = 0; vw < M; ++vw) {
+            const double* prow = p.P + (size_t)(15 + 6 * sSlot[vw]) * p.ldp + colg;
+            double pv[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) pv[a] = prow[(size_t)a * p.ldp];
+            double e0 = 0, e1 = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const int cc = 6 * vw + a;
+                zp0 += sZ[cc] * pv[a];
+                zp1 += sZ[C6 + cc] * pv[a];
+                zp2 += sZ[2 * C6 + cc] * pv[a];
+                e0 += sA[(2 * vw) * 6 + a] * pv[a];
+                e1 += sA[(2 * vw + 1) * 6 + a] * pv[a];
+            }
+            sE[(2 * vw) * ldE + c] = e0;
+            sE[(2 * vw + 1) * ldE + c] = e1;
+        }
+        sZP[c] = zp0; sZP[C6 + c] = zp1; sZP[2 * C6 + c] = zp2;
+        // E -= V ZP  (same column, all rows)
+        for (int L = 0; L < R2; ++L) {
+            sE[L * ldE + c] -= sV[L * 3 + 0] * zp0 + sV[L * 3 + 1] * zp1 + sV[L * 3 + 2] * zp2;
+        }
+    }
+    __syncthreads();
+    // pass 2, lanes over rows: S[L][L'] = E[L,:] . H_o[L',:]
+    if (lane < R2) {
+        double ez0 = 0, ez1 = 0, ez2 = 0;
+        for (int c = 0; c < C6; ++c) {
+            const double e = sE[lane * ldE + c];
+            ez0 += e * sZ[c]; ez1 += e * sZ[C6 + c]; ez2 += e * sZ[2 * C6 + c];
+        }
+        for (int L2 = 0; L2 < R2; ++L2) {
+            const int vw = L2 >> 1;
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) s += sE[lane * ldE + 6 * vw + a] * sA[L2 * 6 + a];
+            s -= ez0 * sV[L2 * 3 + 0] + ez1 * sV[L2 * 3 + 1] + ez2 * sV[L2 * 3 + 2];
+            if (L2 == lane) s += p.sigma2;
+            sS[lane * ldS + L2] = s;
+        }
+        sS[lane * ldS + R2] = ro;          // rhs column
+        sS[R2 * ldS + lane] = ro;          // extra row r_o^T
+    }
+    if (lane == 0) sS[R2 * ldS + R2] = 0.0;
+    __syncthreads();
+    // elimination over rows/cols rank..R2-1; the extra row R2 ends with -gamma in the corner
+    int bad = 0;
+    for (int k = rank; k < R2; ++k) {
+        const double piv = sS[k * ldS + k];
+        if (!(piv > 0.0)) { bad = 1; break; }
+        if (lane > k && lane <= R2) {
+            const double l = sS[lane * ldS + k] / piv;
+            for (int j = k + 1; j <= R2; ++j) sS[lane * ldS + j] -= l * sS[k * ldS + j];
+        }
+        __syncthreads();
+    }
+    const double gam = -sS[R2 * ldS + R2];
+    bool ok = (q >= 1) && (bad == 0) && (q < p.n_chi2);
+    if (ok) ok = (gam <= p.chi2[q]);
+    if (lane == 0) {
+        p.rank[f] = rank;
+        p.gamma[f] = gam;
+        p.accepted[f] = ok ? 1 : 0;
+        if (ok) { atomicAdd(&p.counters[0], 1); atomicAdd(&p.counters[1], q); }
+        if (bad) atomicAdd(&p.counters[2], 1);
+    }
+}
+
+}  // namespace msckf

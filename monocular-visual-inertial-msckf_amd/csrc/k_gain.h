@@ -1,0 +1,201 @@
+// K6-K7: Kalman gain and Joseph-form covariance update.
+//   reference MSCKF.py:604-607 : S = T P T^T + R_n ; K = P T^T S^-1 ; dx = K r_n
+//   reference MSCKF.py:612-614 : P+ = (I-KT) P (I-KT)^T + K R_n K^T ; P+ <- (P+ + P+^T)/2
+// with R_n = sigma^2 I (Q^T (sigma^2 I) Q, MSCKF.py:598) and T = [0 | R] acting
+// on the 6N clone columns only (T_H[:, :15] == 0).
+//
+// Dense d x d products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64),
+// one wavefront per 16x16 output tile.  S is factored by a single workgroup in
+// LDS (S = L L^T, SPD thanks to + sigma^2 I) instead of the reference's explicit
+// inverse; K = Y S^-1 is two triangular sweeps per row, one wavefront per row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wave_ops.h"
+
+namespace msckf {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+    const double* A; int lda;     // A[M][K]
+    const double* B; int ldb;     // transB ? B[N][K] : B[K][N]
+    const double* C0; int ldc0;   // optional addend
+    double* C; int ldc;
+    int M, N, K;
+    double alpha, beta, diag_add; // C = alpha*A*op(B) + beta*C0 + diag_add*I
+    int transB;
+    int tri;                      // 1: B[N][K] is upper triangular (k >= n), transB only
+                                  // 2: A[M][K] is upper triangular (k >= m)
+};
+
+// One wavefront per 16x16 tile of C.  The four 16-lane groups of the MFMA each
+// take a contiguous quarter of the K range (the sum over k is order free), so a
+// lane streams contiguous doubles of its A row (and of its B row when transB).
+__global__ __launch_bounds__(64) void k_gemm_f64(GemmArgs g) {
+    const int lane = threadIdx.x;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int r = lane & 15, grp = lane >> 4;
+    int kbeg = 0;
+    if (g.tri == 1) kbeg = n0;
+    else if (g.tri == 2) kbeg = m0;
+    const int klen = g.K - kbeg;
+    const int kq = (klen + 3) / 4;                 // per-group chunk
+    const int k_lo = kbeg + grp * kq;
+    const int k_hi = min(g.K, k_lo + kq);
+    const int arow = m0 + r, bcol = n0 + r;
+    const bool aok = arow < g.M, bok = bcol < g.N;
+    const double* ap = g.A + (size_t)arow * g.lda;
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    if (g.transB) {
+        const double* bp = g.B + (size_t)bcol * g.ldb;
+        for (int s = 0; s < kq; ++s) {
+            const int k = k_lo + s;
+            const bool kok = k < k_hi;
+            const double a = (aok && kok) ? ap[k] : 0.0;
+            const double b = (bok && kok) ? bp[k] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+    } else {
+        for (int s = 0; s < kq; ++s) {
+            const int k = k_lo + s;
+            const bool kok = k < k_hi;
+            const double a = (aok && kok) ? ap[k] : 0.0;
+            const double b = (bok && kok) ? g.B[(size_t)k * g.ldb + bcol] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const int col = n0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + (lane >> 4) + 4 * i;
+        if (row < g.M && col < g.N) {
+            double x = g.alpha * acc[i];
+            if (g.C0) x += g.beta * g.C0[(size_t)row * g.ldc0 + col];
+            if (row == col) x += g.diag_add;
+            g.C[(size_t)row * g.ldc + col] = x;
+        }
+    }
+}
+
+// Cholesky S = L L^T of an n x n SPD matrix by one workgroup.  Works on the
+// packed lower triangle in LDS when it fits (use_lds), else in place in HBM/L2.
+// Writes L (row-major, ld = n), U = L^T (row-major) and invd[j] = 1 / L[j][j].
+struct CholArgs {
+    const double* S; int lds_;    // input, row-major, leading dimension lds_
+    double* L; double* U; double* invd; int n;
+    int use_lds;
+    double* work;                 // n*(n+1)/2 doubles when !use_lds
+    int* status;                  // [0] set to 1 when a pivot is not positive
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void k_chol(CholArgs c) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int t = threadIdx.x, n = c.n;
+    double* A = c.use_lds ? smem : c.work;      // packed lower by rows: (i,j) at i(i+1)/2 + j
+    __shared__ int s_bad;
+    if (t == 0) s_bad = 0;
+    for (int i = t / 32; i < n; i += T / 32)
+        for (int j = t % 32; j <= i; j += 32) A[i * (i + 1) / 2 + j] = c.S[(size_t)i * c.lds_ + j];
+    __syncthreads();
+    const int tx = t % 32, ty = t / 32;          // 32 x (T/32) thread tile over the trailing block
+    for (int k = 0; k < n; ++k) {
+        const double piv = A[k * (k + 1) / 2 + k];
+        if (!(piv > 0.0)) { if (t == 0) { s_bad = 1; c.status[0] = 1; } break; }
+        const double dinv = 1.0 / sqrt(piv);
+        __syncthreads();
+        for (int i = k + t; i < n; i += T) A[i * (i + 1) / 2 + k] *= dinv;   // column k, incl. diagonal -> sqrt(piv)
+        __syncthreads();
+        for (int i = k + 1 + ty; i < n; i += T / 32) {
+            const double lik = A[i * (i + 1) / 2 + k];
+            double* row = A + i * (i + 1) / 2;
+            for (int j = k + 1 + tx; j <= i; j += 32) row[j] -= lik * A[j * (j + 1) / 2 + k];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = t / 32; i < n; i += T / 32)
+        for (int j = t % 32; j < n; j += 32) {
+            const double x = (j <= i) ? A[i * (i + 1) / 2 + j] : 0.0;
+            c.L[(size_t)i * n + j] = x;
+            c.U[(size_t)j * n + i] = x;
+        }
+    for (int j = t; j < n; j += T) c.invd[j] = 1.0 / A[j * (j + 1) / 2 + j];
+}
+
+// K row i = Y row i * S^-1 : forward sweep with U = L^T rows (L x = y), backward
+// sweep with L rows (L^T k = x).  One wavefront per row; the vector lives in
+// registers (lane l holds elements l, l+64, ...), the pivot element travels by
+// v_readlane.  Also dx[i] = K[i,:] . z.
+struct SolveArgs {
+    const double* Y; int ldy;     // [d][n]
+    const double* L; const double* U; const double* invd; int n;
+    const double* z; int zstride; // r_n (column of the compressed block)
+    double* Kg; int ldk;          // [d][n]
+    double* dx; int d;
+};
+
+template <int NREG>
+__global__ __launch_bounds__(64) void k_solve(SolveArgs s) {
+    const int row = blockIdx.x, lane = threadIdx.x, n = s.n;
+    double x[NREG];
+#pragma unroll
+    for (int m = 0; m < NREG; ++m) {
+        const int i = lane + 64 * m;
+        x[m] = (i < n) ? s.Y[(size_t)row * s.ldy + i] : 0.0;
+    }
+    // forward: for j: xj = x[j] / L[j][j]; x[i] -= L[i][j] xj (i > j); L[i][j] = U[j][i]
+#pragma unroll
+    for (int mj = 0; mj < NREG; ++mj) {
+        for (int jj = 0; jj < 64; ++jj) {
+            const int j = mj * 64 + jj;
+            if (j >= n) break;
+            const double xj = readlane_d(x[mj], jj) * s.invd[j];
+            if (lane == jj) x[mj] = xj;
+            const double* urow = s.U + (size_t)j * n;
+#pragma unroll
+            for (int m = 0; m < NREG; ++m) {
+                if (m < mj) continue;
+                const int i = lane + 64 * m;
+                if (i > j && i < n) x[m] -= urow[i] * xj;
+            }
+        }
+    }
+    // backward: for j = n-1..0: kj = x[j] / L[j][j]; x[i] -= L[j][i] kj (i < j)
+#pragma unroll
+    for (int mj = NREG - 1; mj >= 0; --mj) {
+        for (int jj = 63; jj >= 0; --jj) {
+            const int j = mj * 64 + jj;
+            if (j >= n) continue;
+            const double kj = readlane_d(x[mj], jj) * s.invd[j];
+            if (lane == jj) x[mj] = kj;
+            const double* lrow = s.L + (size_t)j * n;
+#pragma unroll
+            for (int m = 0; m < NREG; ++m) {
+                if (m > mj) continue;
+                const int i = lane + 64 * m;
+                if (i < j) x[m] -= lrow[i] * kj;
+            }
+        }
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int m = 0; m < NREG; ++m) {
+        const int i = lane + 64 * m;
+        if (i < n) {
+            s.Kg[(size_t)row * s.ldk + i] = x[m];
+            dot += x[m] * s.z[(size_t)i * s.zstride];
+        }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) s.dx[row] = dot;
+}
+
+// P_out = (Pn + Pn^T) / 2   (reference MSCKF.py:614)
+__global__ void k_symmetrize(const double* Pn, double* Pout, int d, int ld) {
+    const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
+    if (i < d && j < d) Pout[(size_t)i * ld + j] = 0.5 * (Pn[(size_t)i * ld + j] + Pn[(size_t)j * ld + i]);
+}
+
+}  // namespace msckf

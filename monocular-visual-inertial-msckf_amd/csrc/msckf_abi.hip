@@ -1,0 +1,776 @@
+// Host side of the C-ABI (include/msckf_mi355x.h): context, HBM buffers, the
+// feature sort + QR-tree plan, and the launch sequence K1..K7 on one HIP stream.
+// gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msckf_mi355x.h"
+#include "k_feature.h"
+#include "k_fold.h"
+#include "k_gain.h"
+
+using namespace msckf;
+
+namespace {
+
+constexpr int FOLD_T = 256;
+constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgroup
+constexpr int FOLD_LDS_BYTES = 152 * 1024;
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+double now_us() {
+    using namespace std::chrono;
+    return duration_cast<duration<double, std::micro>>(steady_clock::now().time_since_epoch()).count();
+}
+
+int fold_bcap(int w, int T, int lds_doubles) { return fold_layout(w, T, lds_doubles).bcap; }
+
+}  // namespace
+
+struct msckf_ctx {
+    msckf_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8]{};
+    std::string last_error;
+    // capacities
+    int maxN = 0, maxF = 0, maxM = 0;
+    // current problem
+    int N = 0, d = 0, dc = 0, F = 0, sumM = 0, Mmax = 0;
+    bool have_state = false, have_features = false, ran = false, ran_gain = false;
+    double sigma = 0.0;
+    double g[3]{}, Kinv[9]{};
+    int n_chi2 = 0;
+    // device buffers
+    Buf dP, dPout, dCamR, dCamT, dCamR0, dCamT0, dChi2;
+    Buf dViewPtr, dObsUV, dObsSlot, dBase, dMvec, dRho, dFmin, dBlkOff, dStack, dRank, dAcc, dGamma, dCounters;
+    Buf dNodes, dRbuf;
+    Buf dY, dS, dL, dU, dInvd, dK, dB2, dD, dPn, dDx, dCholWork, dStatus;
+    // host-side plan
+    std::vector<int> perm;                // sorted position -> input index
+    std::vector<FoldNode> nodes;
+    std::vector<std::pair<int, int>> levels;   // (node_base, count) per fold launch
+    int root = -1;
+    size_t rbuf_doubles = 0;              // used by the plan
+    size_t gather_off = 0;                // region for gathered shard blocks
+    int gather_cap = 0;
+    int n_leaves = 0;
+    int acc_override = -1;                // total accepted over all shards (merge_gain path)
+    float us_host_prep = 0, us_h2d = 0, us_d2h = 0;
+    float us_stage[3] = {0, 0, 0};
+    float us_total = 0;
+    std::vector<int> h_view_sorted;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);              \
+            return MSCKF_ERR_HIP;                                                               \
+        }                                                                                       \
+    } while (0)
+
+int ensure(msckf_ctx* c, Buf& b, size_t bytes, bool zero = false) {
+    if (b.bytes >= bytes && b.p) return MSCKF_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.bytes = want;
+    if (zero) HIPCHK(c, hipMemset(b.p, 0, want));
+    return MSCKF_OK;
+}
+
+template <typename Tp>
+Tp* ptr(const Buf& b) { return reinterpret_cast<Tp*>(b.p); }
+
+// ---- QR tree plan ---------------------------------------------------------
+// Leaves: consecutive sorted features whose stacked-row bound stays under
+// leaf_rows.  Merge levels: consecutive nodes, up to `arity` children as long
+// as the rows to fold fit one LDS batch of the parent window, else two.
+void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
+                const std::vector<int>& view_sorted) {
+    const int F = c->F, N = c->N;
+    const int lds_doubles = FOLD_LDS_BYTES / 8;
+    const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 160;
+    const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 4;
+    c->nodes.clear();
+    c->levels.clear();
+    size_t off = 0;
+    auto push = [&](int kind, int b, int e, int lo, int hi) {
+        FoldNode n{};
+        n.kind = kind; n.src_begin = b; n.src_end = e; n.win_lo = lo; n.w = 6 * (hi - lo + 1); n.pad = 0;
+        n.out_off = (long long)off;
+        off += (size_t)n.w * (n.w + 1);
+        c->nodes.push_back(n);
+    };
+    // leaves
+    int f = 0;
+    while (f < F) {
+        int lo = fmin[f], hi = fmax[f];
+        int rows = 0, e = f;
+        while (e < F && (e - f) < FOLD_MAX_SRC) {
+            const int r = 2 * (view_sorted[e + 1] - view_sorted[e]);
+            if (e > f && rows + r > leaf_rows) break;
+            rows += r;
+            lo = std::min(lo, fmin[e]);
+            hi = std::max(hi, fmax[e]);
+            ++e;
+        }
+        push(0, f, e, lo, hi);
+        f = e;
+    }
+    c->n_leaves = (int)c->nodes.size();
+    if (c->n_leaves > 0) c->levels.push_back({0, c->n_leaves});
+    // merge levels
+    int lvl_base = 0, lvl_cnt = c->n_leaves;
+    while (lvl_cnt > 1 || (lvl_cnt == 1 && (c->nodes[lvl_base].win_lo != 0 || c->nodes[lvl_base].w != 6 * N))) {
+        const int nb = (int)c->nodes.size();
+        const int end = lvl_base + lvl_cnt;
+        struct Grp { int b, e, lo, hi; };
+        std::vector<Grp> grps;
+        int i = lvl_base;
+        while (i < end) {
+            int lo = c->nodes[i].win_lo, hi = lo + c->nodes[i].w / 6 - 1;
+            int e = i + 1;
+            int fold_rows = 0;
+            while (e < end && (e - i) < arity) {
+                const int lo2 = std::min(lo, c->nodes[e].win_lo);
+                const int hi2 = std::max(hi, c->nodes[e].win_lo + c->nodes[e].w / 6 - 1);
+                const int cap = fold_bcap(6 * (hi2 - lo2 + 1), FOLD_T, lds_doubles);
+                if ((e - i) >= 2 && fold_rows + c->nodes[e].w > cap) break;   // keep one LDS batch per node
+                fold_rows += c->nodes[e].w;
+                lo = lo2; hi = hi2;
+                ++e;
+            }
+            grps.push_back({i, e, lo, hi});
+            i = e;
+        }
+        if (grps.size() == 1) { grps[0].lo = 0; grps[0].hi = N - 1; }   // the root spans every clone
+        for (const Grp& g : grps) push(1, g.b, g.e, g.lo, g.hi);
+        lvl_base = nb;
+        lvl_cnt = (int)c->nodes.size() - nb;
+        c->levels.push_back({lvl_base, lvl_cnt});
+    }
+    c->root = c->nodes.empty() ? -1 : (int)c->nodes.size() - 1;
+    c->rbuf_doubles = off;
+}
+
+int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& levels) {
+    FoldArgs a{};
+    a.nodes = ptr<FoldNode>(c->dNodes);
+    a.lds_doubles = FOLD_LDS_BYTES / 8;
+    a.view_ptr = ptr<int>(c->dViewPtr);
+    a.obs_slot = ptr<int>(c->dObsSlot);
+    a.fmin = ptr<int>(c->dFmin);
+    a.blk_off = ptr<long long>(c->dBlkOff);
+    a.stack = ptr<double>(c->dStack);
+    a.rank = ptr<int>(c->dRank);
+    a.accepted = ptr<unsigned char>(c->dAcc);
+    a.rbuf = ptr<double>(c->dRbuf);
+    for (auto& lv : levels) {
+        a.node_base = lv.first;
+        hipLaunchKernelGGL(k_fold<FOLD_T>, dim3(lv.second), dim3(FOLD_T), FOLD_LDS_BYTES, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+int launch_feature(msckf_ctx* c) {
+    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, 64, c->stream));
+    if (c->F == 0) return MSCKF_OK;
+    FeatureArgs a{};
+    a.F = c->F; a.ldp = c->d;
+    a.view_ptr = ptr<int>(c->dViewPtr); a.obs_uv = ptr<double>(c->dObsUV); a.obs_slot = ptr<int>(c->dObsSlot);
+    a.idp_base = ptr<double>(c->dBase); a.idp_m = ptr<double>(c->dMvec); a.idp_rho = ptr<double>(c->dRho);
+    a.cam_R = ptr<double>(c->dCamR); a.cam_t = ptr<double>(c->dCamT);
+    a.cam_R0 = ptr<double>(c->dCamR0); a.cam_t0 = ptr<double>(c->dCamT0);
+    a.P = ptr<double>(c->dP); a.chi2 = ptr<double>(c->dChi2); a.n_chi2 = c->n_chi2;
+    for (int i = 0; i < 3; ++i) a.g[i] = c->g[i];
+    for (int i = 0; i < 9; ++i) a.Kinv[i] = c->Kinv[i];
+    a.sigma2 = c->sigma * c->sigma;
+    a.blk_off = ptr<long long>(c->dBlkOff); a.stack = ptr<double>(c->dStack);
+    a.rank = ptr<int>(c->dRank); a.accepted = ptr<unsigned char>(c->dAcc); a.gamma = ptr<double>(c->dGamma);
+    a.counters = ptr<int>(c->dCounters);
+    const size_t lds = (size_t)feature_lds_doubles(c->Mmax) * 8;
+    hipLaunchKernelGGL(k_feature, dim3(c->F), dim3(64), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+void gemm(msckf_ctx* c, const double* A, int lda, const double* B, int ldb, const double* C0, int ldc0,
+          double* C, int ldc, int M, int N, int K, double alpha, double beta, double diag, int transB, int tri) {
+    GemmArgs g{A, lda, B, ldb, C0, ldc0, C, ldc, M, N, K, alpha, beta, diag, transB, tri};
+    hipLaunchKernelGGL(k_gemm_f64, dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, c->stream, g);
+}
+
+// K6-K7 from the root block [T | r_n] (dc x (dc+1), row-major) and the prior P.
+int launch_gain(msckf_ctx* c, const double* Tblk) {
+    const int d = c->d, dc = c->dc, ldt = dc + 1;
+    const double s2 = c->sigma * c->sigma;
+    const double* P = ptr<double>(c->dP);
+    double* Y = ptr<double>(c->dY);     // [d][dc]   Y = P[:,15:] T^T
+    double* S = ptr<double>(c->dS);     // [dc][dc]
+    double* Kg = ptr<double>(c->dK);    // [d][dc]
+    double* B2 = ptr<double>(c->dB2);   // [d][d]    (I - K T) P
+    double* D = ptr<double>(c->dD);     // [d][dc]   sigma^2 K - B2[:,15:] T^T
+    double* Pn = ptr<double>(c->dPn);   // [d][d]
+    HIPCHK(c, hipMemsetAsync(c->dStatus.p, 0, 16, c->stream));
+    // Y = P[:, 15:] T^T                      (P T_H^T, MSCKF.py:606)
+    gemm(c, P + 15, d, Tblk, ldt, nullptr, 0, Y, dc, d, dc, dc, 1.0, 0.0, 0.0, 1, 1);
+    // S = T Y[15:, :] + sigma^2 I            (MSCKF.py:605)
+    gemm(c, Tblk, ldt, Y + (size_t)15 * dc, dc, nullptr, 0, S, dc, dc, dc, dc, 1.0, 0.0, s2, 0, 2);
+    // S = L L^T
+    {
+        CholArgs a{};
+        a.S = S; a.lds_ = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = ptr<double>(c->dInvd);
+        a.n = dc; a.work = ptr<double>(c->dCholWork); a.status = ptr<int>(c->dStatus);
+        const size_t need = (size_t)dc * (dc + 1) / 2 * 8;
+        a.use_lds = need <= (size_t)(LDS_MAX_BYTES - 1024) ? 1 : 0;
+        hipLaunchKernelGGL(k_chol<512>, dim3(1), dim3(512), a.use_lds ? need : 0, c->stream, a);
+    }
+    // K = Y S^-1, dx = K r_n                 (MSCKF.py:606-607)
+    {
+        SolveArgs a{};
+        a.Y = Y; a.ldy = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = ptr<double>(c->dInvd);
+        a.n = dc; a.z = Tblk + dc; a.zstride = ldt; a.Kg = Kg; a.ldk = dc; a.dx = ptr<double>(c->dDx); a.d = d;
+        const int nreg = (dc + 63) / 64;
+        if (nreg <= 1) hipLaunchKernelGGL(k_solve<1>, dim3(d), dim3(64), 0, c->stream, a);
+        else if (nreg <= 2) hipLaunchKernelGGL(k_solve<2>, dim3(d), dim3(64), 0, c->stream, a);
+        else if (nreg <= 3) hipLaunchKernelGGL(k_solve<3>, dim3(d), dim3(64), 0, c->stream, a);
+        else if (nreg <= 4) hipLaunchKernelGGL(k_solve<4>, dim3(d), dim3(64), 0, c->stream, a);
+        else hipLaunchKernelGGL(k_solve<5>, dim3(d), dim3(64), 0, c->stream, a);
+    }
+    // Joseph form (MSCKF.py:613) with A = I - K T_H, T_H = [0 | T]:
+    //   B2 = A P = P - K (T_H P) = P - K Y^T           (P symmetric)
+    gemm(c, Kg, dc, Y, dc, P, d, B2, d, d, d, dc, -1.0, 1.0, 0.0, 1, 0);
+    //   D = sigma^2 K - B2[:, 15:] T^T
+    gemm(c, B2 + 15, d, Tblk, ldt, Kg, dc, D, dc, d, dc, dc, -1.0, s2, 0.0, 1, 1);
+    //   Pn = B2 A^T + sigma^2 K K^T = B2 + D K^T
+    gemm(c, D, dc, Kg, dc, B2, d, Pn, d, d, d, dc, 1.0, 1.0, 0.0, 1, 0);
+    //   P_out = (Pn + Pn^T) / 2                         (MSCKF.py:614)
+    hipLaunchKernelGGL(k_symmetrize, dim3((d + 15) / 16, (d + 15) / 16), dim3(16, 16), 0, c->stream, Pn,
+                       ptr<double>(c->dPout), d, d);
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+const double* root_block(msckf_ctx* c) { return ptr<double>(c->dRbuf) + c->nodes[c->root].out_off; }
+
+int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
+    if (!c->have_state || !c->have_features) return MSCKF_ERR_STATE;
+    int rc;
+    if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[0], c->stream));
+    if ((rc = launch_feature(c)) != MSCKF_OK) return rc;
+    if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
+    if (c->F > 0 && (rc = launch_fold_levels(c, c->levels)) != MSCKF_OK) return rc;
+    if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
+    if (with_gain && c->F > 0) {
+        if ((rc = launch_gain(c, root_block(c))) != MSCKF_OK) return rc;
+    }
+    if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[3], c->stream));
+    c->ran = true;
+    c->ran_gain = with_gain;
+    c->acc_override = -1;
+    return MSCKF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* msckf_strerror(int code) {
+    switch (code) {
+        case MSCKF_OK: return "ok";
+        case MSCKF_NOOP: return "no-op: no feature passed the gate";
+        case MSCKF_ERR_ARG: return "bad argument or size over the context capacity";
+        case MSCKF_ERR_HIP: return "HIP runtime error";
+        case MSCKF_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case MSCKF_ERR_NOT_SPD: return "innovation covariance not positive definite";
+        case MSCKF_ERR_STATE: return "call order: set_state and set_features must precede run";
+        case MSCKF_ERR_DUP_SLOT: return "a track observes the same clone slot twice";
+        default: return "unknown";
+    }
+}
+
+const char* msckf_last_error(const msckf_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int msckf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
+    if (!out || !cfg || cfg->abi_version != MSCKF_ABI_VERSION) return MSCKF_ERR_ARG;
+    if (cfg->max_track < 1 || cfg->max_track > MSCKF_MAX_TRACK || cfg->max_clones < 1 || cfg->max_features < 0)
+        return MSCKF_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || cfg->device < 0 || cfg->device >= n) return MSCKF_ERR_NO_DEVICE;
+    msckf_ctx* c = new msckf_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->maxN = cfg->max_clones; c->maxF = cfg->max_features; c->maxM = cfg->max_track;
+    if (hipSetDevice(c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop{};
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
+    for (auto& e : c->ev) hipEventCreate(&e);
+    // kernels that use more than the default 64 KiB of dynamic LDS
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<FOLD_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        FOLD_LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        LDS_MAX_BYTES - 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        LDS_MAX_BYTES - 1024);
+    const int N = c->maxN, d = 15 + 6 * N, dc = 6 * N;
+    int rc = MSCKF_OK;
+    auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
+    E(c->dP, (size_t)d * d * 8); E(c->dPout, (size_t)d * d * 8);
+    E(c->dCamR, (size_t)N * 9 * 8); E(c->dCamT, (size_t)N * 3 * 8);
+    E(c->dCamR0, (size_t)N * 9 * 8); E(c->dCamT0, (size_t)N * 3 * 8);
+    E(c->dChi2, 1024 * 8);
+    E(c->dCounters, 64, true); E(c->dStatus, 64, true);
+    E(c->dY, (size_t)d * dc * 8); E(c->dS, (size_t)dc * dc * 8); E(c->dL, (size_t)dc * dc * 8);
+    E(c->dU, (size_t)dc * dc * 8); E(c->dInvd, (size_t)dc * 8); E(c->dK, (size_t)d * dc * 8);
+    E(c->dB2, (size_t)d * d * 8); E(c->dD, (size_t)d * dc * 8); E(c->dPn, (size_t)d * d * 8);
+    E(c->dDx, (size_t)d * 8, true); E(c->dCholWork, (size_t)dc * (dc + 1) / 2 * 8);
+    if (rc != MSCKF_OK) { msckf_destroy(c); return rc; }
+    *out = c;
+    return MSCKF_OK;
+}
+
+void msckf_destroy(msckf_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
+                  &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
+                  &c->dRank, &c->dAcc, &c->dGamma, &c->dCounters, &c->dNodes, &c->dRbuf, &c->dY, &c->dS, &c->dL,
+                  &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus};
+    for (Buf* b : all) if (b->p) hipFree(b->p);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, const double* cam_t,
+                    const double* cam_R0, const double* cam_t0, const double* gravity, const double* Kinv,
+                    double sigma, const double* chi2_crit, int32_t n_crit) {
+    if (!c || !P || !cam_R || !cam_t || !cam_R0 || !cam_t0 || !gravity || !Kinv || !chi2_crit) return MSCKF_ERR_ARG;
+    if (N < 1 || N > c->maxN || n_crit < 2 || n_crit > 1024) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_us();
+    if (N != c->N) c->have_features = false;
+    c->N = N; c->d = 15 + 6 * N; c->dc = 6 * N;
+    c->sigma = sigma; c->n_chi2 = n_crit;
+    std::memcpy(c->g, gravity, 24);
+    std::memcpy(c->Kinv, Kinv, 72);
+    const size_t d = c->d;
+    HIPCHK(c, hipMemcpyAsync(c->dP.p, P, d * d * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCamR.p, cam_R, (size_t)N * 72, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCamT.p, cam_t, (size_t)N * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCamR0.p, cam_R0, (size_t)N * 72, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCamT0.p, cam_t0, (size_t)N * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dChi2.p, chi2_crit, (size_t)n_crit * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->us_h2d = (float)(now_us() - t0);
+    c->have_state = true;
+    c->ran = false;
+    return MSCKF_OK;
+}
+
+int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const double* obs_uv,
+                       const int32_t* obs_slot, const double* idp_base, const double* idp_m,
+                       const double* idp_rho) {
+    if (!c || F < 0 || F > c->maxF) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    if (F > 0 && (!view_ptr || !obs_uv || !obs_slot || !idp_base || !idp_m || !idp_rho)) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_us();
+    const int N = c->N;
+    c->F = F;
+    c->ran = false;
+    if (F == 0) {
+        c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->root = -1; c->perm.clear();
+        c->have_features = true;
+        c->us_host_prep = (float)(now_us() - t0);
+        return MSCKF_OK;
+    }
+    // validate + first/last slot of each track
+    std::vector<int> fmin_in(F), fmax_in(F);
+    int Mmax = 0;
+    if (view_ptr[0] != 0) return MSCKF_ERR_ARG;
+    for (int f = 0; f < F; ++f) {
+        const int a = view_ptr[f], b = view_ptr[f + 1], M = b - a;
+        if (M < 1 || M > c->maxM) return MSCKF_ERR_ARG;
+        Mmax = std::max(Mmax, M);
+        int lo = N, hi = -1;
+        unsigned long long seen = 0;    // N <= 64 fast path; general check below
+        for (int i = a; i < b; ++i) {
+            const int s = obs_slot[i];
+            if (s < 0 || s >= N) return MSCKF_ERR_ARG;
+            lo = std::min(lo, s); hi = std::max(hi, s);
+            if (N <= 64) {
+                if (seen & (1ull << s)) return MSCKF_ERR_DUP_SLOT;
+                seen |= 1ull << s;
+            } else {
+                for (int k = a; k < i; ++k) if (obs_slot[k] == s) return MSCKF_ERR_DUP_SLOT;
+            }
+        }
+        fmin_in[f] = lo; fmax_in[f] = hi;
+    }
+    if (c->n_chi2 <= 2 * Mmax) return MSCKF_ERR_ARG;
+    const int sumM = view_ptr[F];
+    c->sumM = sumM; c->Mmax = Mmax;
+    // counting sort by (first slot, last slot): stable, O(F + N^2)
+    c->perm.resize(F);
+    {
+        std::vector<int> cnt((size_t)N * N + 1, 0);
+        for (int f = 0; f < F; ++f) cnt[(size_t)fmin_in[f] * N + fmax_in[f] + 1]++;
+        for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+        for (int f = 0; f < F; ++f) c->perm[cnt[(size_t)fmin_in[f] * N + fmax_in[f]]++] = f;
+    }
+    // gather into sorted order
+    std::vector<int> h_view(F + 1), h_slot(sumM), h_fmin(F), h_fmax(F);
+    std::vector<double> h_uv((size_t)sumM * 2), h_base((size_t)F * 3), h_m((size_t)F * 3), h_rho(F);
+    std::vector<long long> h_blk(F);
+    long long blk = 0;
+    int pos = 0;
+    for (int sidx = 0; sidx < F; ++sidx) {
+        const int f = c->perm[sidx];
+        const int a = view_ptr[f], M = view_ptr[f + 1] - a;
+        h_view[sidx] = pos;
+        std::memcpy(&h_slot[pos], &obs_slot[a], (size_t)M * 4);
+        std::memcpy(&h_uv[(size_t)pos * 2], &obs_uv[(size_t)a * 2], (size_t)M * 16);
+        std::memcpy(&h_base[(size_t)sidx * 3], &idp_base[(size_t)f * 3], 24);
+        std::memcpy(&h_m[(size_t)sidx * 3], &idp_m[(size_t)f * 3], 24);
+        h_rho[sidx] = idp_rho[f];
+        h_fmin[sidx] = fmin_in[f]; h_fmax[sidx] = fmax_in[f];
+        h_blk[sidx] = blk;
+        blk += (long long)(6 * M + 1) * (2 * M);
+        pos += M;
+    }
+    h_view[F] = pos;
+    c->h_view_sorted = h_view;
+    build_plan(c, h_fmin, h_fmax, h_view);
+    // room for gathered shard blocks behind the plan's blocks
+    c->gather_off = c->rbuf_doubles;
+    const double t1 = now_us();
+    c->us_host_prep = (float)(t1 - t0);
+
+    int rc = MSCKF_OK;
+    auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
+    E(c->dViewPtr, (size_t)(F + 1) * 4); E(c->dObsUV, (size_t)sumM * 16); E(c->dObsSlot, (size_t)sumM * 4);
+    E(c->dBase, (size_t)F * 24); E(c->dMvec, (size_t)F * 24); E(c->dRho, (size_t)F * 8); E(c->dFmin, (size_t)F * 4);
+    E(c->dBlkOff, (size_t)F * 8); E(c->dStack, (size_t)blk * 8); E(c->dRank, (size_t)F * 4);
+    E(c->dAcc, (size_t)F); E(c->dGamma, (size_t)F * 8);
+    E(c->dNodes, c->nodes.size() * sizeof(FoldNode));
+    if (rc != MSCKF_OK) return rc;
+    {
+        // the R workspace is zero-initialised once: entries below a block's diagonal are never written
+        const size_t need = (c->rbuf_doubles + 16) * 8;
+        if (c->dRbuf.bytes < need) {
+            if (c->dRbuf.p) HIPCHK(c, hipFree(c->dRbuf.p));
+            c->dRbuf.p = nullptr; c->dRbuf.bytes = 0;
+            const size_t want = need + need / 2;
+            HIPCHK(c, hipMalloc(&c->dRbuf.p, want));
+            c->dRbuf.bytes = want;
+        }
+        HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->dViewPtr.p, h_view.data(), (size_t)(F + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dObsUV.p, h_uv.data(), (size_t)sumM * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dObsSlot.p, h_slot.data(), (size_t)sumM * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dBase.p, h_base.data(), (size_t)F * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dMvec.p, h_m.data(), (size_t)F * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dRho.p, h_rho.data(), (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dFmin.p, h_fmin.data(), (size_t)F * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dBlkOff.p, h_blk.data(), (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->us_h2d += (float)(now_us() - t1);
+    c->have_features = true;
+    return MSCKF_OK;
+}
+
+int msckf_run(msckf_ctx* c) {
+    if (!c) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_pipeline(c, true, nullptr);
+}
+
+int msckf_run_compress(msckf_ctx* c) {
+    if (!c) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_pipeline(c, false, nullptr);
+}
+
+int msckf_sync(msckf_ctx* c) {
+    if (!c) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSCKF_OK;
+}
+
+int msckf_run_timed(msckf_ctx* c, int32_t iters, float* ms_total, float* stage_us) {
+    if (!c || iters < 1) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = run_pipeline(c, true, nullptr)) != MSCKF_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[5]));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+    if (ms_total) *ms_total = ms;
+    c->us_total = ms * 1000.0f / iters;
+    if (stage_us) {
+        double acc[3] = {0, 0, 0};
+        const int reps = std::min(iters, 20);
+        for (int i = 0; i < reps; ++i) {
+            if ((rc = run_pipeline(c, true, c->ev)) != MSCKF_OK) return rc;
+            HIPCHK(c, hipEventSynchronize(c->ev[3]));
+            for (int s = 0; s < 3; ++s) {
+                float t = 0;
+                HIPCHK(c, hipEventElapsedTime(&t, c->ev[s], c->ev[s + 1]));
+                acc[s] += t * 1000.0;
+            }
+        }
+        for (int s = 0; s < 3; ++s) { stage_us[s] = (float)(acc[s] / reps); c->us_stage[s] = stage_us[s]; }
+    }
+    return MSCKF_OK;
+}
+
+int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted, msckf_stats* st) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (!c->ran) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_us();
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int counters[16] = {0};
+    int status[4] = {0};
+    HIPCHK(c, hipMemcpy(counters, c->dCounters.p, 64, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(status, c->dStatus.p, 16, hipMemcpyDeviceToHost));
+    const int n_acc = (c->acc_override >= 0) ? c->acc_override : ((c->F > 0) ? counters[0] : 0);
+    const size_t d = c->d;
+    int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
+    if (rc == MSCKF_OK && c->ran_gain && status[0] != 0) rc = MSCKF_ERR_NOT_SPD;
+    if (accepted && c->F > 0) {
+        std::vector<unsigned char> tmp(c->F);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->dAcc.p, c->F, hipMemcpyDeviceToHost));
+        for (int s = 0; s < c->F; ++s) accepted[c->perm[s]] = tmp[s];
+    }
+    if (dx) {
+        if (rc == MSCKF_OK && c->ran_gain) HIPCHK(c, hipMemcpy(dx, c->dDx.p, d * 8, hipMemcpyDeviceToHost));
+        else std::memset(dx, 0, d * 8);
+    }
+    if (P_out) {
+        // no-op leaves the covariance untouched (reference early returns MSCKF.py:584-585)
+        const void* src = (rc == MSCKF_OK && c->ran_gain) ? c->dPout.p : c->dP.p;
+        HIPCHK(c, hipMemcpy(P_out, src, d * d * 8, hipMemcpyDeviceToHost));
+    }
+    c->us_d2h = (float)(now_us() - t0);
+    if (st) {
+        std::memset(st, 0, sizeof(*st));
+        st->n_features = c->F; st->n_accepted = n_acc; st->n_rejected = c->F - n_acc;
+        st->stacked_rows = counters[1]; st->not_spd = counters[2];
+        st->n_leaves = c->n_leaves; st->n_levels = (int)c->levels.size();
+        st->us_total = c->us_total; st->us_feature = c->us_stage[0]; st->us_qr = c->us_stage[1];
+        st->us_gain = c->us_stage[2];
+        st->us_host_prep = c->us_host_prep; st->us_h2d = c->us_h2d; st->us_d2h = c->us_d2h;
+    }
+    return rc;
+}
+
+int msckf_commit_covariance(msckf_ctx* c) {
+    if (!c || !c->ran || !c->ran_gain) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    int counters[16] = {0};
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(counters, c->dCounters.p, 64, hipMemcpyDeviceToHost));
+    if (c->F == 0 || counters[0] == 0) return MSCKF_NOOP;
+    HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSCKF_OK;
+}
+
+int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, const double* cam_t,
+                 const double* cam_R0, const double* cam_t0, const double* gravity, const double* Kinv,
+                 double sigma, int32_t F, const int32_t* view_ptr, const double* obs_uv, const int32_t* obs_slot,
+                 const double* idp_base, const double* idp_m, const double* idp_rho, const double* chi2_crit,
+                 int32_t n_crit, double* dx, double* P_out, uint8_t* accepted, msckf_stats* stats) {
+    if (!c) return MSCKF_ERR_ARG;
+    int rc = msckf_set_state(c, N, P, cam_R, cam_t, cam_R0, cam_t0, gravity, Kinv, sigma, chi2_crit, n_crit);
+    if (rc != MSCKF_OK) return rc;
+    rc = msckf_set_features(c, F, view_ptr, obs_uv, obs_slot, idp_base, idp_m, idp_rho);
+    if (rc != MSCKF_OK) return rc;
+    if (F == 0) {
+        // empty feature dict: the reference returns at MSCKF.py:584-585
+        const size_t d = c->d;
+        if (dx) std::memset(dx, 0, d * 8);
+        if (P_out) std::memcpy(P_out, P, d * d * 8);
+        if (stats) { std::memset(stats, 0, sizeof(*stats)); }
+        return MSCKF_NOOP;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    rc = run_pipeline(c, true, nullptr);
+    if (rc != MSCKF_OK) return rc;
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[7]));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+    c->us_total = ms * 1000.0f;
+    return msckf_get_result(c, dx, P_out, accepted, stats);
+}
+
+size_t msckf_block_doubles(const msckf_ctx* c) { return c ? (size_t)c->dc * (c->dc + 1) : 0; }
+
+int msckf_export_block(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accepted) {
+    if (!c || !dst) return MSCKF_ERR_ARG;
+    if (!c->ran) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = msckf_block_doubles(c) * 8;
+    if (c->F == 0 || c->root < 0) {
+        if (device_ptr) HIPCHK(c, hipMemsetAsync(dst, 0, bytes, c->stream));
+        else std::memset(dst, 0, bytes);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_accepted) *n_accepted = 0;
+        return MSCKF_OK;
+    }
+    HIPCHK(c, hipMemcpyAsync(dst, root_block(c), bytes, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                             c->stream));
+    int counters[16] = {0};
+    HIPCHK(c, hipMemcpyAsync(counters, c->dCounters.p, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_accepted) *n_accepted = counters[0];
+    return MSCKF_OK;
+}
+
+int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int device_ptr,
+                         int32_t total_accepted) {
+    if (!c || !blocks || n_blocks < 1) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->N, dc = c->dc;
+    const size_t blk = (size_t)dc * (dc + 1);
+    // workspace: gathered blocks + merge outputs, behind the local plan's region
+    std::vector<FoldNode> nodes;
+    std::vector<std::pair<int, int>> levels;
+    size_t off = c->gather_off;
+    for (int i = 0; i < n_blocks; ++i) {
+        FoldNode n{}; n.kind = 1; n.src_begin = 0; n.src_end = 0; n.win_lo = 0; n.w = dc; n.out_off = (long long)off;
+        off += blk;
+        nodes.push_back(n);
+    }
+    int base = 0, cnt = n_blocks;
+    while (cnt > 1) {
+        const int nb = (int)nodes.size();
+        for (int i = base; i < base + cnt; i += 2) {
+            FoldNode n{}; n.kind = 1; n.src_begin = i; n.src_end = std::min(i + 2, base + cnt); n.win_lo = 0; n.w = dc;
+            n.out_off = (long long)off;
+            off += blk;
+            nodes.push_back(n);
+        }
+        base = nb; cnt = (int)nodes.size() - nb;
+        levels.push_back({base, cnt});
+    }
+    const size_t need = (off + 16) * 8;
+    if (c->dRbuf.bytes < need) {
+        // grow, keeping the local plan's blocks
+        void* np = nullptr;
+        HIPCHK(c, hipMalloc(&np, need));
+        HIPCHK(c, hipMemset(np, 0, need));
+        if (c->dRbuf.p) {
+            HIPCHK(c, hipMemcpy(np, c->dRbuf.p, std::min(c->dRbuf.bytes, c->gather_off * 8), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipFree(c->dRbuf.p));
+        }
+        c->dRbuf.p = np; c->dRbuf.bytes = need;
+    }
+    double* rb = ptr<double>(c->dRbuf);
+    HIPCHK(c, hipMemsetAsync(rb + c->gather_off, 0, (off - c->gather_off) * 8, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rb + c->gather_off, blocks, (size_t)n_blocks * blk * 8,
+                             device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    // the merge nodes live behind the local plan's nodes in dNodes
+    const size_t local_nodes = c->nodes.size();
+    std::vector<FoldNode> all(c->nodes);
+    for (auto n : nodes) { if (n.src_end > 0) { n.src_begin += (int)local_nodes; n.src_end += (int)local_nodes; } all.push_back(n); }
+    for (auto& lv : levels) lv.first += (int)local_nodes;
+    if (int rc = ensure(c, c->dNodes, all.size() * sizeof(FoldNode))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dNodes.p, all.data(), all.size() * sizeof(FoldNode), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!levels.empty()) { if (int rc = launch_fold_levels(c, levels)) return rc; }
+    const double* root = rb + all.back().out_off;
+    // counters[0] decides OK / NOOP in get_result: mark "accepted" when any block is non-empty
+    (void)N;
+    int rc = launch_gain(c, root);
+    if (rc != MSCKF_OK) return rc;
+    c->ran = true; c->ran_gain = true;
+    c->acc_override = total_accepted;
+    return MSCKF_OK;
+}
+
+int msckf_debug_gate(msckf_ctx* c, double* gamma, int32_t* qdim) {
+    if (!c || !c->ran) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> g(c->F);
+    std::vector<int> rk(c->F);
+    if (c->F == 0) return MSCKF_OK;
+    HIPCHK(c, hipMemcpy(g.data(), c->dGamma.p, (size_t)c->F * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(rk.data(), c->dRank.p, (size_t)c->F * 4, hipMemcpyDeviceToHost));
+    for (int s = 0; s < c->F; ++s) {
+        const int f = c->perm[s];
+        if (gamma) gamma[f] = g[s];
+        if (qdim) qdim[f] = 2 * (c->h_view_sorted[s + 1] - c->h_view_sorted[s]) - rk[s];
+    }
+    return MSCKF_OK;
+}
+
+int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
+    if (!c || !c->ran || c->root < 0) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int dc = c->dc;
+    std::vector<double> blk((size_t)dc * (dc + 1));
+    HIPCHK(c, hipMemcpy(blk.data(), root_block(c), blk.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < dc; ++i) {
+        if (T) for (int j = 0; j < dc; ++j) T[(size_t)i * dc + j] = (j >= i) ? blk[(size_t)i * (dc + 1) + j] : 0.0;
+        if (rn) rn[i] = blk[(size_t)i * (dc + 1) + dc];
+    }
+    return MSCKF_OK;
+}
+
+uint64_t msckf_device_pointer(msckf_ctx* c, int which) {
+    if (!c) return 0;
+    switch (which) {
+        case 0: return (uint64_t)c->dDx.p;
+        case 1: return (uint64_t)c->dPout.p;
+        case 2: return (c->root >= 0) ? (uint64_t)root_block(c) : 0;
+        default: return 0;
+    }
+}
+
+void* msckf_stream(msckf_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+}  // extern "C"
