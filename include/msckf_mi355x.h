@@ -158,11 +158,21 @@ int msckf_export_block(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_acc
 int msckf_run_merge_gain(msckf_ctx* ctx, const void* blocks, int32_t n_blocks, int device_ptr,
                          int32_t total_accepted /* sum of the shards' n_accepted */);
 
+/* Copy dx[d] and P_out[d*d] of the last run into caller buffers that may live in HBM
+ * (device_ptr != 0), e.g. the send buffer of the broadcast that follows the merge. */
+int msckf_export_result(msckf_ctx* ctx, void* dx_dst, void* P_dst, int device_ptr);
+/* Replace the prior covariance P (d*d) from a host or HBM buffer (non-root ranks after
+ * the broadcast; also the hand-over point for a device-resident propagation step). */
+int msckf_import_covariance(msckf_ctx* ctx, const void* P, int device_ptr);
+
 /* ---- introspection for tests (device intermediates, host copies) -------- */
 /* gamma[F] (gate statistic), qdim[F] (dof = projected rows), in input order. */
 int msckf_debug_gate(msckf_ctx* ctx, double* gamma, int32_t* qdim);
 /* Final compressed system: T (6N x 6N, upper triangular) and r_n (6N). */
 int msckf_debug_compressed(msckf_ctx* ctx, double* T, double* rn);
+/* Diagnostics: out == NULL enables per-node cycle stamps in the fold kernel; otherwise copies
+ * 8 int64 per tree node {setup, staging, steps, total (100 MHz ticks), w, rows, -, -}. */
+int msckf_debug_fold_stamps(msckf_ctx* ctx, long long* out, int32_t max_nodes);
 /* Raw device pointers (as integers) for zero-copy interop: which = 0 dx, 1 P_out, 2 block. */
 uint64_t msckf_device_pointer(msckf_ctx* ctx, int which);
 void* msckf_stream(msckf_ctx* ctx);                     /* hipStream_t of the context */

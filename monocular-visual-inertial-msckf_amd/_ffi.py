@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsckf_mi355x.so")
+LIB_PATH = os.environ.get("MSCKF_LIB") or os.path.join(_HERE, "libmsckf_mi355x.so")   # MSCKF_LIB: A/B builds
 ABI_VERSION = 1
 
 OK, NOOP = 0, 1
@@ -20,7 +20,7 @@ SYMBOLS = [
     "msckf_create", "msckf_destroy", "msckf_strerror", "msckf_last_error", "msckf_device_count",
     "msckf_update", "msckf_set_state", "msckf_set_features", "msckf_run", "msckf_run_timed", "msckf_sync",
     "msckf_get_result", "msckf_commit_covariance", "msckf_run_compress", "msckf_block_doubles",
-    "msckf_export_block", "msckf_run_merge_gain", "msckf_debug_gate", "msckf_debug_compressed",
+    "msckf_export_block", "msckf_run_merge_gain", "msckf_export_result", "msckf_import_covariance", "msckf_debug_gate", "msckf_debug_compressed", "msckf_debug_fold_stamps",
     "msckf_device_pointer", "msckf_stream",
 ]
 
@@ -90,10 +90,16 @@ def load():
     lib.msckf_export_block.restype = C.c_int
     lib.msckf_run_merge_gain.argtypes = [vp, vp, C.c_int32, C.c_int, C.c_int32]
     lib.msckf_run_merge_gain.restype = C.c_int
+    lib.msckf_export_result.argtypes = [vp, vp, vp, C.c_int]
+    lib.msckf_export_result.restype = C.c_int
+    lib.msckf_import_covariance.argtypes = [vp, vp, C.c_int]
+    lib.msckf_import_covariance.restype = C.c_int
     lib.msckf_debug_gate.argtypes = [vp, _dp, _ip]
     lib.msckf_debug_gate.restype = C.c_int
     lib.msckf_debug_compressed.argtypes = [vp, _dp, _dp]
     lib.msckf_debug_compressed.restype = C.c_int
+    lib.msckf_debug_fold_stamps.argtypes = [vp, C.POINTER(C.c_longlong), C.c_int32]
+    lib.msckf_debug_fold_stamps.restype = C.c_int
     lib.msckf_device_pointer.argtypes = [vp, C.c_int]
     lib.msckf_device_pointer.restype = C.c_uint64
     lib.msckf_stream.argtypes = [vp]

@@ -198,6 +198,18 @@ class UpdateEngine:
             self._check(self._lib.msckf_run_merge_gain(self._h, b.ctypes.data_as(C.c_void_p), int(b.shape[0]), 0,
                                                        int(total_accepted)), allow_noop=False)
 
+    def export_result(self, dx_ptr: int, P_ptr: int):
+        """dx and P+ of the last run into HBM buffers owned by the caller."""
+        self._check(self._lib.msckf_export_result(self._h, C.c_void_p(dx_ptr), C.c_void_p(P_ptr), 1), allow_noop=False)
+
+    def import_covariance(self, P):
+        """New prior covariance from a host array or an int device address."""
+        if isinstance(P, (int, np.integer)):
+            self._check(self._lib.msckf_import_covariance(self._h, C.c_void_p(int(P)), 1), allow_noop=False)
+        else:
+            a = _ffi.f64(P)
+            self._check(self._lib.msckf_import_covariance(self._h, a.ctypes.data_as(C.c_void_p), 0), allow_noop=False)
+
     # -- introspection ------------------------------------------------------
     def debug_gate(self):
         g = np.zeros(max(self._F, 1))

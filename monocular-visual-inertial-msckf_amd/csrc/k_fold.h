@@ -9,10 +9,17 @@
 //          scattered into the window's local columns;
 //   merge: rows are the children's R factors (the first child is adopted as
 //          the accumulator in place, the others are folded into it).
-// One workgroup per node.  Rows are staged in LDS in batches sorted by their
-// leading column; per column j one Householder reflector built from
-// [R_jj ; batch(:, j)] is applied to R row j (streamed from/to HBM, prefetched
-// one step ahead) and to the live batch rows (rows whose leading column <= j).
+// One workgroup per node.  The rows to fold are taken in batches of up to
+// 16*RPT rows (sorted by leading column) that live in REGISTERS for the whole
+// elimination: lane (rq, cq) of wave v owns rows {rq + 16 r} and columns
+// {(4 v + cq) + NCG k} of the batch (cyclic in both directions, so work stays
+// balanced as columns retire and rows come alive).  Per column j one Householder
+// reflector is built from [R_jj ; batch(:, j)]:
+//   - the 16 lanes that own column j publish it (v) through a double-buffered
+//     LDS vector -> ONE workgroup barrier per column;
+//   - every lane reads the v entries of its rows, forms its partial dots with
+//     its columns and reduces them over the 16 row-lanes with DPP moves;
+//   - R row j is streamed from/to HBM (prefetched one step ahead in registers).
 // Householder only: the stack is exactly rank deficient (rank 6N-4) so no
 // Gram / Cholesky-QR shortcut is admissible.
 #pragma once
@@ -43,58 +50,63 @@ struct FoldArgs {
     const int* rank;
     const unsigned char* accepted;
     double* rbuf;
+    long long* stamps;          // optional diagnostics: per-node cycle stamps (8 per node), may be null
 };
 
 constexpr int FOLD_MAX_SRC = 1024;   // sources per node the LDS bookkeeping can hold
 
 // LDS carve-up of k_fold (offsets in doubles); shared by the kernel and the host planner.
 struct FoldLayout {
-    int ld;        // batch row stride (odd: conflict-free column walks)
-    int rrow;      // [2][w+2] current / next R row
-    int part;      // [T] partial dots
-    int ints;      // int region: nalive[w], rstate[w], srow0[FOLD_MAX_SRC+1], ctl[8]
-    int blead;     // [bcap] ints: leading column of each batch row
-    int batch;     // [bcap][ld]
-    int bcap;      // batch rows that fit
+    int ld;        // staging row stride (odd: conflict-free column walks)
+    int vbuf;      // [2][bmax + 2] published column j (+ pivot)
+    int ints;      // int region: nalive[w], rstate[w], srow0[FOLD_MAX_SRC+1], ctl[8], blead[bmax],
+                   //             bsrc[bmax], slotmap[16][32]
+    int panel;     // [prow][ld] staging panel
+    int prow;      // staging rows that fit
 };
 
-__host__ __device__ inline FoldLayout fold_layout(int w, int T, int lds_doubles) {
+__host__ __device__ inline FoldLayout fold_layout(int w, int bmax, int lds_doubles) {
     FoldLayout L;
     L.ld = (w + 1) | 1;
-    L.rrow = 0;
-    L.part = 2 * (w + 2);
-    L.ints = L.part + T;
-    const int nints = 2 * w + (FOLD_MAX_SRC + 1) + 8;
-    const int dyn = L.ints + (nints + 1) / 2;
-    const int avail = lds_doubles - dyn;
-    L.bcap = (2 * avail) / (2 * L.ld + 1) - 1;
-    L.blead = dyn;
-    L.batch = dyn + (L.bcap + 1) / 2;
+    L.vbuf = 0;
+    L.ints = 2 * (bmax + 2);
+    const int nints = 2 * w + (FOLD_MAX_SRC + 1) + 8 + 2 * bmax + 16 * 32;
+    L.panel = L.ints + (nints + 1) / 2;
+    L.prow = (lds_doubles - L.panel) / L.ld;
     return L;
 }
 
-template <int T>
-__global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
+// Fallback for windows whose packed R does not fit LDS (w > FOLD_RLDS_MAX_W): R rows are
+// streamed from/to HBM every step.  T threads; batch of up to 16*RPT rows; up to CPT*(T/16)
+// columns (incl. the rhs column).
+template <int T, int RPT, int CPT>
+__global__ __launch_bounds__(T) void k_fold_g(FoldArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NCG = T / 16;          // column groups
+    constexpr int BMAX = 16 * RPT;       // rows per register batch
     const FoldNode nd = p.nodes[p.node_base + blockIdx.x];
     const int t = threadIdx.x;
-    const int lane = t & 63;
+    const int rq = t & 15;               // row lane inside the DPP row
+    const int cg = t >> 4;               // column group
     const int w = nd.w;
     const int nsrc = nd.src_end - nd.src_begin;
-    const FoldLayout lay = fold_layout(w, T, p.lds_doubles);
+    const FoldLayout lay = fold_layout(w, BMAX, p.lds_doubles);
     const int ld = lay.ld;
-    const int Bcap = lay.bcap;
-    double* rrow = smem + lay.rrow;
-    double* part = smem + lay.part;
+    const int prow = lay.prow;
+    double* vbuf = smem + lay.vbuf;
     int* nalive = reinterpret_cast<int*>(smem + lay.ints);   // [w]
     int* rstate = nalive + w;                                 // [w] 0 empty, 1 adopted child, 2 out block
     int* srow0 = rstate + w;                                  // [FOLD_MAX_SRC+1] first row of each source
     int* s_ctl = srow0 + (FOLD_MAX_SRC + 1);                  // [8]
-    int* blead = reinterpret_cast<int*>(smem + lay.blead);    // [Bcap]
-    double* batch = smem + lay.batch;                         // [Bcap][ld]
+    int* blead = s_ctl + 8;                                   // [BMAX] leading column of each batch row
+    int* bsrc = blead + BMAX;                                 // [BMAX] merge: (child << 20) | child row
+    int* slotmap = bsrc + BMAX;                               // [T/64][32] leaf: per-wave clone slots of a track
+    double* panel = smem + lay.panel;                         // [prow][ld]
 
     double* out = p.rbuf + nd.out_off;
     const int ldo = w + 1;
+    long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+    if (p.stamps) tk0 = wall_clock64();
 
     // adopted child (merge only)
     int ad_off = 0, ad_w = 0;
@@ -111,63 +123,115 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
     // leaf : source i = feature nd.src_begin + i, rows = accepted ? 2M - rank : 0
     // merge: source i = child node nd.src_begin + 1 + i (child 0 is adopted), rows = child w
     const int nfold = (nd.kind == 0) ? nsrc : nsrc - 1;
+    for (int i = t; i < nfold; i += T) {
+        int rows;
+        if (nd.kind == 0) {
+            const int f = nd.src_begin + i;
+            rows = p.accepted[f] ? 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f] : 0;
+        } else {
+            rows = p.nodes[nd.src_begin + 1 + i].w;
+        }
+        srow0[i + 1] = rows;
+    }
+    __syncthreads();
     if (t == 0) {
         int acc = 0;
-        for (int i = 0; i < nfold; ++i) {
-            srow0[i] = acc;
-            if (nd.kind == 0) {
-                const int f = nd.src_begin + i;
-                if (p.accepted[f]) acc += 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f];
-            } else {
-                acc += p.nodes[nd.src_begin + 1 + i].w;
-            }
-        }
-        srow0[nfold] = acc;
+        srow0[0] = 0;
+        for (int i = 0; i < nfold; ++i) { acc += srow0[i + 1]; srow0[i + 1] = acc; }
         s_ctl[3] = acc;
     }
     __syncthreads();
     const int total_rows = s_ctl[3];
 
-    // Row r of the node (0 <= r < total_rows) in lead-sorted order:
-    //   leaf : sources are already sorted by lead, rows of a source share its lead
-    //   merge: global sort position of (child c, row i) is computed in closed form
-    for (int row_lo = 0; row_lo < total_rows; row_lo += Bcap) {
-        const int nb = min(Bcap, total_rows - row_lo);
-        // ---------- stage the batch: zero, then scatter ----------------------
-        for (int e = t; e < nb * ld; e += T) batch[e] = 0.0;
-        __syncthreads();
+    // R row element (j, c) from wherever row j currently lives
+    auto load_r = [&](int j, int c) -> double {
+        const int st = rstate[j];
+        if (st == 2) return out[(size_t)j * ldo + c];
+        if (st == 1) {
+            const int i = j - ad_off;
+            if (c == w) return ad_blk[(size_t)i * (ad_w + 1) + ad_w];
+            if (c < ad_off + ad_w) return ad_blk[(size_t)i * (ad_w + 1) + (c - ad_off)];
+            return 0.0;
+        }
+        return 0.0;
+    };
+
+    if (p.stamps) tk1 = wall_clock64();
+    for (int row_lo = 0; row_lo < total_rows; row_lo += BMAX) {
+        const int nb = min(BMAX, total_rows - row_lo);
+        long long ts0 = 0;
+        if (p.stamps) ts0 = wall_clock64();
+        double a[RPT][CPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) a[r][k] = 0.0;
+
         if (nd.kind == 0) {
-            // threads over (source, element): each source block is column-major (6M+1) x 2M
-            for (int i = 0; i < nfold; ++i) {
-                const int r0 = srow0[i], r1 = srow0[i + 1];
-                if (r1 <= row_lo || r0 >= row_lo + nb || r1 == r0) continue;
-                const int f = nd.src_begin + i;
-                const int vbeg = p.view_ptr[f];
-                const int M = p.view_ptr[f + 1] - vbeg;
-                const int R2 = 2 * M, rk = p.rank[f];
-                const double* blk = p.stack + p.blk_off[f];
-                const int lead = 6 * (p.fmin[f] - nd.win_lo);
-                const int nel = (6 * M + 1) * R2;
-                for (int e = t; e < nel; e += T) {
-                    const int c = e / R2, L = e - c * R2;
-                    if (L < rk) continue;
-                    const int br = r0 + (L - rk) - row_lo;
-                    if (br < 0 || br >= nb) continue;
-                    const int col = (c == 6 * M) ? w : 6 * (p.obs_slot[vbeg + c / 6] - nd.win_lo) + (c % 6);
-                    batch[br * ld + col] = blk[e];
-                    if (c == 0) blead[br] = lead;
+            // ---------- leaf: stage the compact K4 blocks through the LDS panel ------
+            for (int sub_lo = row_lo; sub_lo < row_lo + nb; sub_lo += prow) {
+                const int np = min(prow, row_lo + nb - sub_lo);
+                __syncthreads();
+                for (int e = t; e < np * ld; e += T) panel[e] = 0.0;
+                __syncthreads();
+                // one wavefront per source block (column-major (6M+1) x 2M)
+                const int wv = t >> 6, ln = t & 63;
+                int* smap = slotmap + wv * 32;
+                for (int i = wv; i < nfold; i += T / 64) {
+                    const int r0 = srow0[i], r1 = srow0[i + 1];
+                    if (r1 <= sub_lo || r0 >= sub_lo + np || r1 == r0) continue;
+                    const int f = nd.src_begin + i;
+                    const int vbeg = p.view_ptr[f];
+                    const int M = p.view_ptr[f + 1] - vbeg;
+                    const int R2 = 2 * M, rk = p.rank[f];
+                    const double* blk = p.stack + p.blk_off[f];
+                    const int lead = 6 * (p.fmin[f] - nd.win_lo);
+                    if (ln < M) smap[ln] = 6 * (p.obs_slot[vbeg + ln] - nd.win_lo);
+                    const int nel = (6 * M + 1) * R2;
+                    for (int e0 = 0; e0 < nel; e0 += 256) {
+                        double x[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = e0 + 64 * u + ln;
+                            x[u] = (e < nel) ? blk[e] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = e0 + 64 * u + ln;
+                            if (e < nel) {
+                                const int c = e / R2, L = e - c * R2;
+                                const int gr = r0 + (L - rk);           // node-global sorted row
+                                if (L >= rk && gr >= sub_lo && gr < sub_lo + np) {
+                                    const int col = (c == 6 * M) ? w : smap[c / 6] + (c % 6);
+                                    panel[(gr - sub_lo) * ld + col] = x[u];
+                                    if (c == 0) blead[gr - row_lo] = lead;
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                // registers pick up their rows / columns of this panel
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const int gr = row_lo + rq + 16 * r;
+                    if (gr >= sub_lo && gr < sub_lo + np) {
+#pragma unroll
+                        for (int k = 0; k < CPT; ++k) {
+                            const int c = cg + NCG * k;
+                            if (c <= w) a[r][k] = panel[(gr - sub_lo) * ld + c];
+                        }
+                    }
                 }
             }
         } else {
+            // ---------- merge: batch rows come straight from the children's R blocks ---
+            // sorted position of (child i, row ri) = ri + rows of the other children that sort first
+            __syncthreads();
             for (int i = 0; i < nfold; ++i) {
                 const FoldNode ch = p.nodes[nd.src_begin + 1 + i];
                 const int off = 6 * (ch.win_lo - nd.win_lo);
-                const double* blk = p.rbuf + ch.out_off;
-                const int cw = ch.w, cld = ch.w + 1;
-                // sorted position of (child i, row ri): rows of other children with smaller lead
-                for (int e = t; e < cw * cld; e += T) {
-                    const int ri = e / cld, cc = e - ri * cld;
-                    if (cc < ri) continue;                       // below the diagonal: never written
+                for (int ri = t; ri < ch.w; ri += T) {
                     const int lead = off + ri;
                     int pos = ri;
                     for (int k = 0; k < nfold; ++k) {
@@ -178,11 +242,32 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                         cnt = max(0, min(cnt, ok.w));
                         pos += cnt;
                     }
-                    const int br = pos - row_lo;
-                    if (br < 0 || br >= nb) continue;
-                    const int col = (cc == cw) ? w : off + cc;
-                    batch[br * ld + col] = blk[ri * cld + cc];
-                    if (cc == ri) blead[br] = lead;
+                    if (pos >= row_lo && pos < row_lo + nb) {
+                        bsrc[pos - row_lo] = (i << 20) | ri;
+                        blead[pos - row_lo] = lead;
+                    }
+                }
+            }
+            __syncthreads();
+            // every lane loads its own elements (independent loads; entries below a child's
+            // diagonal were never written and read back as the workspace's zeros)
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int b = rq + 16 * r;
+                if (b < nb) {
+                    const int code = bsrc[b];
+                    const FoldNode ch = p.nodes[nd.src_begin + 1 + (code >> 20)];
+                    const int ri = code & 0xFFFFF;
+                    const int off = 6 * (ch.win_lo - nd.win_lo);
+                    const double* rowp = p.rbuf + ch.out_off + (size_t)ri * (ch.w + 1);
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) {
+                        const int c = cg + NCG * k;
+                        double x = 0.0;
+                        if (c == w) x = rowp[ch.w];
+                        else if (c >= off + ri && c < off + ch.w) x = rowp[c - off];
+                        a[r][k] = x;
+                    }
                 }
             }
         }
@@ -195,87 +280,93 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
         }
         __syncthreads();
         const int jmin = blead[0];
+        if (p.stamps) { const long long tn = wall_clock64(); tk2 += tn - ts0; ts0 = tn; }
 
-        // ---------- fetch R row jmin synchronously -----------------------------
-        auto load_r = [&](int j, int c) -> double {
-            const int st = rstate[j];
-            if (st == 2) return out[(size_t)j * ldo + c];
-            if (st == 1) {
-                const int i = j - ad_off;
-                if (c == w) return ad_blk[(size_t)i * (ad_w + 1) + ad_w];
-                if (c < ad_off + ad_w) return ad_blk[(size_t)i * (ad_w + 1) + (c - ad_off)];
-                return 0.0;
-            }
-            return 0.0;
-        };
-        for (int c = jmin + t; c <= w; c += T) rrow[(jmin & 1) * (w + 2) + c] = load_r(jmin, c);
-        __syncthreads();
+        // R row jmin for this lane's columns (later rows are prefetched one step ahead)
+        double rcur[CPT], rnxt[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = cg + NCG * k;
+            rcur[k] = (c >= jmin && c <= w) ? load_r(jmin, c) : 0.0;
+            rnxt[k] = 0.0;
+        }
 
         for (int j = jmin; j < w; ++j) {
             const int na = nalive[j];
-            double* cur = rrow + (j & 1) * (w + 2);
-            double* nxtbuf = rrow + ((j + 1) & 1) * (w + 2);
-            // prefetch R row j+1 (registers now, LDS at the end of the step)
-            double nx0 = 0.0, nx1 = 0.0;
-            const int pc0 = j + 1 + t, pc1 = j + 1 + t + T;
+            const int ra = (na + 15) >> 4;                 // live register rows (uniform bound)
+            // prefetch R row j+1
             if (j + 1 < w) {
-                if (pc0 <= w) nx0 = load_r(j + 1, pc0);
-                if (pc1 <= w) nx1 = load_r(j + 1, pc1);
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int c = cg + NCG * k;
+                    rnxt[k] = (c >= j + 1 && c <= w) ? load_r(j + 1, c) : 0.0;
+                }
             }
-            // sigma = sum of squares of column j over the live rows (every wave redundantly)
+            // the 16 lanes that own column j publish it, plus the pivot R_jj
+            double* vb = vbuf + (j & 1) * (BMAX + 2);
+            const int kj = j / NCG;
+            if (cg == j - kj * NCG) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    if (k == kj) {
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r)
+                            if (r < ra) vb[rq + 16 * r] = a[r][k];
+                        if (rq == 0) vb[BMAX] = rcur[k];
+                    }
+                }
+            }
+            __syncthreads();
+            double v[RPT];
             double sg = 0.0;
-            for (int b = lane; b < na; b += 64) { const double x = batch[b * ld + j]; sg += x * x; }
-            sg = wave_sum(sg);
-            const double x0 = cur[j];
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                v[r] = (r < ra) ? vb[rq + 16 * r] : 0.0;
+                sg += v[r] * v[r];
+            }
+            const double x0 = vb[BMAX];
+            sg = row16_sum(sg);
             if (sg > 0.0) {
                 const double nrm = sqrt(x0 * x0 + sg);
                 const double alpha = (x0 > 0.0) ? -nrm : nrm;
                 const double v0 = x0 - alpha;
                 const double beta = 1.0 / (nrm * (nrm + fabs(x0)));
-                const int nc = w - j;                    // columns j+1 .. w
-                int nchunk = (nc >= T) ? 1 : T / nc;
-                if (nchunk > na) nchunk = na;
-                const int rpc = (na + nchunk - 1) / nchunk;
-                if (nchunk == 1) {
-                    for (int c = j + 1 + t; c <= w; c += T) {
-                        double dot = v0 * cur[c];
-                        for (int b = 0; b < na; ++b) dot += batch[b * ld + j] * batch[b * ld + c];
-                        const double tau = beta * dot;
-                        out[(size_t)j * ldo + c] = cur[c] - tau * v0;
-                        for (int b = 0; b < na; ++b) batch[b * ld + c] -= tau * batch[b * ld + j];
-                    }
-                } else {
-                    const int ci = t % nc, ch = t / nc;
-                    const int c = j + 1 + ci;
-                    const bool on = ch < nchunk;
-                    const int b0 = ch * rpc, b1 = min(na, b0 + rpc);
-                    if (on) {
-                        double dot = (ch == 0) ? v0 * cur[c] : 0.0;
-                        for (int b = b0; b < b1; ++b) dot += batch[b * ld + j] * batch[b * ld + c];
-                        part[ch * nc + ci] = dot;
-                    }
-                    __syncthreads();
-                    if (on) {
-                        double dot = 0.0;
-                        for (int k = 0; k < nchunk; ++k) dot += part[k * nc + ci];
-                        const double tau = beta * dot;
-                        if (ch == 0) out[(size_t)j * ldo + c] = cur[c] - tau * v0;
-                        for (int b = b0; b < b1; ++b) batch[b * ld + c] -= tau * batch[b * ld + j];
+                double dot[CPT];
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) s += v[r] * a[r][k];
+                    dot[k] = s;
+                }
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) dot[k] = row16_sum(dot[k]);
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int c = cg + NCG * k;
+                    if (c > j && c <= w) {
+                        const double tau = beta * (dot[k] + v0 * rcur[k]);
+                        if (rq == 0) out[(size_t)j * ldo + c] = rcur[k] - tau * v0;
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) a[r][k] -= tau * v[r];
+                    } else if (c == j) {
+                        if (rq == 0) out[(size_t)j * ldo + j] = alpha;
                     }
                 }
-                if (t == 0) out[(size_t)j * ldo + j] = alpha;
             } else {
                 // nothing to eliminate in this column: R row j passes through
-                for (int c = j + t; c <= w; c += T) out[(size_t)j * ldo + c] = cur[c];
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    const int c = cg + NCG * k;
+                    if (c >= j && c <= w && rq == 0) out[(size_t)j * ldo + c] = rcur[k];
+                }
             }
-            if (j + 1 < w) {
-                if (pc0 <= w) nxtbuf[pc0] = nx0;
-                if (pc1 <= w) nxtbuf[pc1] = nx1;
-            }
-            __syncthreads();
             if (t == 0) rstate[j] = 2;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) rcur[k] = rnxt[k];
         }
         __syncthreads();
+        if (p.stamps) { const long long tn = wall_clock64(); tk3 += tn - ts0; }
     }
 
     // ---- rows never touched by a fold step: copy (adopted) or zero-fill ------
@@ -292,6 +383,331 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
             }
             out[(size_t)j * ldo + c] = x;
         }
+    }
+    if (p.stamps && t == 0) {
+        tk4 = wall_clock64();
+        long long* o = p.stamps + 8 * (p.node_base + blockIdx.x);
+        o[0] = tk1 - tk0; o[1] = tk2; o[2] = tk3; o[3] = tk4 - tk0; o[4] = w; o[5] = total_rows;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
+// Main variant: the node's R accumulator (packed upper triangle incl. the rhs column,
+// (w+1)(w+2)/2 doubles) stays in LDS for the whole node; the step loop touches no global
+// memory.  Row j of R sits at roff(j) = j (w+1) - j (j-1)/2 and holds columns j..w.
+constexpr int FOLD_RLDS_MAX_W = 186;
+
+struct FoldLayoutR {
+    int ld, vbuf, ints, racc, panel, prow;
+};
+__host__ __device__ inline FoldLayoutR fold_layout_r(int w, int bmax, int lds_doubles) {
+    FoldLayoutR L;
+    L.ld = (w + 1) | 1;
+    L.vbuf = 0;
+    L.ints = 2 * (bmax + 2);
+    const int nints = (FOLD_MAX_SRC + 1) + 8 + 2 * bmax + 16 * 32 + w;
+    L.racc = L.ints + (nints + 1) / 2;
+    L.panel = L.racc + (w + 1) * (w + 2) / 2;
+    L.prow = (lds_doubles - L.panel) / L.ld;
+    return L;
+}
+
+// T threads, RL (8 or 16) row lanes, RPT (multiple of 4) register rows, CPT register columns;
+// TRI: rows come alive progressively (merge of triangles) -> skip dead row blocks.
+template <int T, int RL, int RPT, int CPT, bool TRI>
+__global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
+    static_assert(RPT % 4 == 0, "RPT must be a multiple of 4");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NCG = T / RL;          // column groups
+    constexpr int BMAX = RL * RPT;       // rows per register batch
+    const FoldNode nd = p.nodes[p.node_base + blockIdx.x];
+    const int t = threadIdx.x;
+    const int rq = t & (RL - 1);         // row lane inside the half DPP row
+    const int cg = t / RL;               // column group
+    const int w = nd.w;
+    const int nsrc = nd.src_end - nd.src_begin;
+    const FoldLayoutR lay = fold_layout_r(w, BMAX, p.lds_doubles);
+    const int ld = lay.ld;
+    const int prow = lay.prow;
+    double* vbuf = smem + lay.vbuf;
+    int* srow0 = reinterpret_cast<int*>(smem + lay.ints);    // [FOLD_MAX_SRC+1] first row of each source
+    int* s_ctl = srow0 + (FOLD_MAX_SRC + 1);                  // [8]
+    int* blead = s_ctl + 8;                                   // [BMAX] leading column of each batch row
+    int* bsrc = blead + BMAX;                                 // [BMAX] merge: (child << 20) | child row
+    int* slotmap = bsrc + BMAX;                               // [T/64][32] leaf: per-wave clone slots of a track
+    int* nalive = slotmap + 16 * 32;                          // [w] live batch rows per column
+    double* racc = smem + lay.racc;                           // packed R accumulator
+    double* panel = smem + lay.panel;                         // [prow][ld] leaf staging panel
+    const int nracc = (w + 1) * (w + 2) / 2;
+    const int ldo = w + 1;
+    double* out = p.rbuf + nd.out_off;
+    long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+    if (p.stamps) tk0 = wall_clock64();
+
+    // ---- R accumulator: zero, then adopt the first child (merge) --------------
+    for (int e = t; e < nracc; e += T) racc[e] = 0.0;
+    const int nfold = (nd.kind == 0) ? nsrc : nsrc - 1;
+    for (int i = t; i < nfold; i += T) {
+        int rows;
+        if (nd.kind == 0) {
+            const int f = nd.src_begin + i;
+            rows = p.accepted[f] ? 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f] : 0;
+        } else {
+            rows = p.nodes[nd.src_begin + 1 + i].w;
+        }
+        srow0[i + 1] = rows;
+    }
+    __syncthreads();
+    if (nd.kind == 1) {
+        const FoldNode c0 = p.nodes[nd.src_begin];
+        const int off = 6 * (c0.win_lo - nd.win_lo);
+        const int cw = c0.w, cld = c0.w + 1;
+        const double* blk = p.rbuf + c0.out_off;
+        for (int e = t; e < cw * cld; e += T) {
+            const int ri = e / cld, cc = e - ri * cld;
+            if (cc < ri) continue;
+            const int j = off + ri;
+            const int c = (cc == cw) ? w : off + cc;
+            racc[j * (w + 1) - (j * (j - 1)) / 2 + (c - j)] = blk[e];
+        }
+    }
+    if (t == 0) {
+        int acc = 0;
+        srow0[0] = 0;
+        for (int i = 0; i < nfold; ++i) { acc += srow0[i + 1]; srow0[i + 1] = acc; }
+        s_ctl[3] = acc;
+    }
+    __syncthreads();
+    const int total_rows = s_ctl[3];
+    if (p.stamps) tk1 = wall_clock64();
+
+    for (int row_lo = 0; row_lo < total_rows; row_lo += BMAX) {
+        const int nb = min(BMAX, total_rows - row_lo);
+        long long ts0 = 0;
+        if (p.stamps) ts0 = wall_clock64();
+        double a[RPT][CPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r)
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) a[r][k] = 0.0;
+
+        if (nd.kind == 0) {
+            // ---------- leaf: stage the compact K4 blocks through the LDS panel ------
+            for (int sub_lo = row_lo; sub_lo < row_lo + nb; sub_lo += prow) {
+                const int np = min(prow, row_lo + nb - sub_lo);
+                __syncthreads();
+                for (int e = t; e < np * ld; e += T) panel[e] = 0.0;
+                __syncthreads();
+                const int wv = t >> 6, ln = t & 63;
+                int* smap = slotmap + wv * 32;
+                for (int i = wv; i < nfold; i += T / 64) {
+                    const int r0 = srow0[i], r1 = srow0[i + 1];
+                    if (r1 <= sub_lo || r0 >= sub_lo + np || r1 == r0) continue;
+                    const int f = nd.src_begin + i;
+                    const int vbeg = p.view_ptr[f];
+                    const int M = p.view_ptr[f + 1] - vbeg;
+                    const int R2 = 2 * M, rk = p.rank[f];
+                    const double* blk = p.stack + p.blk_off[f];
+                    const int lead = 6 * (p.fmin[f] - nd.win_lo);
+                    if (ln < M) smap[ln] = 6 * (p.obs_slot[vbeg + ln] - nd.win_lo);
+                    const int nel = (6 * M + 1) * R2;
+                    for (int e0 = 0; e0 < nel; e0 += 256) {
+                        double x[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = e0 + 64 * u + ln;
+                            x[u] = (e < nel) ? blk[e] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int e = e0 + 64 * u + ln;
+                            if (e < nel) {
+                                const int c = e / R2, L = e - c * R2;
+                                const int gr = r0 + (L - rk);           // node-global sorted row
+                                if (L >= rk && gr >= sub_lo && gr < sub_lo + np) {
+                                    const int col = (c == 6 * M) ? w : smap[c / 6] + (c % 6);
+                                    panel[(gr - sub_lo) * ld + col] = x[u];
+                                    if (c == 0) blead[gr - row_lo] = lead;
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const int gr = row_lo + rq + RL * r;
+                    if (gr >= sub_lo && gr < sub_lo + np) {
+#pragma unroll
+                        for (int k = 0; k < CPT; ++k) {
+                            const int c = cg + NCG * k;
+                            if (c <= w) a[r][k] = panel[(gr - sub_lo) * ld + c];
+                        }
+                    }
+                }
+            }
+        } else {
+            // ---------- merge: batch rows come straight from the children's R blocks ---
+            __syncthreads();
+            for (int i = 0; i < nfold; ++i) {
+                const FoldNode ch = p.nodes[nd.src_begin + 1 + i];
+                const int off = 6 * (ch.win_lo - nd.win_lo);
+                for (int ri = t; ri < ch.w; ri += T) {
+                    const int lead = off + ri;
+                    int pos = ri;
+                    for (int k = 0; k < nfold; ++k) {
+                        if (k == i) continue;
+                        const FoldNode ok = p.nodes[nd.src_begin + 1 + k];
+                        const int offk = 6 * (ok.win_lo - nd.win_lo);
+                        int cnt = lead - offk + (k < i ? 1 : 0);
+                        cnt = max(0, min(cnt, ok.w));
+                        pos += cnt;
+                    }
+                    if (pos >= row_lo && pos < row_lo + nb) {
+                        bsrc[pos - row_lo] = (i << 20) | ri;
+                        blead[pos - row_lo] = lead;
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                const int b = rq + RL * r;
+                if (b < nb) {
+                    const int code = bsrc[b];
+                    const FoldNode ch = p.nodes[nd.src_begin + 1 + (code >> 20)];
+                    const int ri = code & 0xFFFFF;
+                    const int off = 6 * (ch.win_lo - nd.win_lo);
+                    const double* rowp = p.rbuf + ch.out_off + (size_t)ri * (ch.w + 1);
+#pragma unroll
+                    for (int k = 0; k < CPT; ++k) {
+                        const int c = cg + NCG * k;
+                        double x = 0.0;
+                        if (c == w) x = rowp[ch.w];
+                        else if (c >= off + ri && c < off + ch.w) x = rowp[c - off];
+                        a[r][k] = x;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // live-row count per column: rows are sorted by lead -> binary search
+        for (int j = t; j < w; j += T) {
+            int lo = 0, hi = nb;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (blead[mid] <= j) lo = mid + 1; else hi = mid; }
+            nalive[j] = lo;
+        }
+        __syncthreads();
+        const int jmin = blead[0];
+        if (p.stamps) { const long long tn = wall_clock64(); tk2 += tn - ts0; ts0 = tn; }
+
+        // ---------- elimination: one reflector per column, no global memory ---------
+        int roff = jmin * (w + 1) - (jmin * (jmin - 1)) / 2;          // start of R row j in racc
+        const int cgw = (t >> 6) * (64 / RL);                         // first column group of this wave
+        unsigned long long cA = 0, cB = 0, cC = 0, cD = 0, c0 = 0, c1 = 0;
+        for (int j = jmin; j < w; ++j) {
+            if (p.stamps) c0 = __builtin_amdgcn_s_memtime();
+            double* vb = vbuf + (j & 1) * (BMAX + 2);
+            // live register rows, in blocks of 4 (uniform over the workgroup)
+            const int rb = TRI ? (((nalive[j] + RL - 1) / RL) + 3) >> 2 : RPT / 4;
+            const int kj = j / NCG;
+            if (cg == j - kj * NCG) {
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    if (k == kj) {
+#pragma unroll
+                        for (int g = 0; g < RPT / 4; ++g)
+                            if (g < rb) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) vb[rq + RL * (4 * g + u)] = a[4 * g + u][k];
+                            }
+                    }
+                }
+                if (rq == 0) vb[BMAX] = racc[roff];                  // pivot R_jj
+            }
+            __syncthreads();
+            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cA += c1 - c0; c0 = c1; }
+            double v[RPT];
+            double sg0 = 0.0, sg1 = 0.0, sg2 = 0.0, sg3 = 0.0;
+#pragma unroll
+            for (int g = 0; g < RPT / 4; ++g) {
+                if (g < rb) {
+                    v[4 * g + 0] = vb[rq + RL * (4 * g + 0)];
+                    v[4 * g + 1] = vb[rq + RL * (4 * g + 1)];
+                    v[4 * g + 2] = vb[rq + RL * (4 * g + 2)];
+                    v[4 * g + 3] = vb[rq + RL * (4 * g + 3)];
+                    sg0 = fma(v[4 * g + 0], v[4 * g + 0], sg0);
+                    sg1 = fma(v[4 * g + 1], v[4 * g + 1], sg1);
+                    sg2 = fma(v[4 * g + 2], v[4 * g + 2], sg2);
+                    sg3 = fma(v[4 * g + 3], v[4 * g + 3], sg3);
+                } else {
+                    v[4 * g + 0] = 0.0; v[4 * g + 1] = 0.0; v[4 * g + 2] = 0.0; v[4 * g + 3] = 0.0;
+                }
+            }
+            const double x0 = vb[BMAX];
+            const double sg = rowN_sum<RL>((sg0 + sg1) + (sg2 + sg3));
+            if (p.stamps) { asm volatile("" :: "v"(sg)); c1 = __builtin_amdgcn_s_memtime(); cB += c1 - c0; c0 = c1; }
+            if (sg > 0.0) {
+                const double ss = fma(x0, x0, sg);
+                double nrm, beta;
+                if (ss > 1e-200 && ss < 1e200) {
+                    nrm = ss * fast_rsqrt(ss);
+                    beta = fast_rcp(nrm * (nrm + fabs(x0)));
+                } else {
+                    nrm = sqrt(ss);
+                    beta = 1.0 / (nrm * (nrm + fabs(x0)));
+                }
+                const double alpha = (x0 > 0.0) ? -nrm : nrm;
+                const double v0 = x0 - alpha;
+                if (p.stamps) { asm volatile("" :: "v"(beta), "v"(v0)); c1 = __builtin_amdgcn_s_memtime(); cC += c1 - c0; c0 = c1; }
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    // slot k of this wave's groups holds columns cgw + NCG k .. + 64/RL - 1: all retired?
+                    if (cgw + NCG * k + (64 / RL - 1) > j && cgw + NCG * k <= w) {
+                        const int c = cg + NCG * k;
+                        const bool on = (c > j) && (c <= w);
+                        const double rc = on ? racc[roff + (c - j)] : 0.0;
+                        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                        for (int g = 0; g < RPT / 4; ++g)
+                            if (g < rb) {
+                                s0 = fma(v[4 * g + 0], a[4 * g + 0][k], s0);
+                                s1 = fma(v[4 * g + 1], a[4 * g + 1][k], s1);
+                                s2 = fma(v[4 * g + 2], a[4 * g + 2][k], s2);
+                                s3 = fma(v[4 * g + 3], a[4 * g + 3][k], s3);
+                            }
+                        const double s = rowN_sum<RL>((s0 + s1) + (s2 + s3));
+                        const double tau = on ? beta * fma(v0, rc, s) : 0.0;
+                        if (on && rq == 0) racc[roff + (c - j)] = fma(-tau, v0, rc);
+#pragma unroll
+                        for (int g = 0; g < RPT / 4; ++g)
+                            if (g < rb) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) a[4 * g + u][k] = fma(-tau, v[4 * g + u], a[4 * g + u][k]);
+                            }
+                    }
+                }
+                if (t == 0) racc[roff] = alpha;
+            }
+            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cD += c1 - c0; }
+            roff += (w + 1) - j;
+        }
+        __syncthreads();
+        if (p.stamps) { const long long tn = wall_clock64(); tk3 += tn - ts0; }
+        if (p.stamps && t == 0) { long long* o = p.stamps + 8 * (p.node_base + blockIdx.x); o[6] = (long long)((cA << 32) | (cB & 0xffffffffull)); o[7] = (long long)((cC << 32) | (cD & 0xffffffffull)); }
+    }
+
+    // ---- flush R to the node's block (row-major w x (w+1), entries at and right of the diagonal)
+    __syncthreads();
+    for (int j = t >> 6; j < w; j += T / 64) {
+        const int ro = j * (w + 1) - (j * (j - 1)) / 2;
+        for (int c = j + (t & 63); c <= w; c += 64) out[(size_t)j * ldo + c] = racc[ro + (c - j)];
+    }
+    if (p.stamps && t == 0) {
+        const long long tk4 = wall_clock64();
+        long long* o = p.stamps + 8 * (p.node_base + blockIdx.x);
+        o[0] = tk1 - tk0; o[1] = tk2; o[2] = tk3; o[3] = tk4 - tk0; o[4] = w; o[5] = total_rows;
     }
 }
 

@@ -46,22 +46,33 @@ __global__ __launch_bounds__(64) void k_gemm_f64(GemmArgs g) {
     const bool aok = arow < g.M, bok = bcol < g.N;
     const double* ap = g.A + (size_t)arow * g.lda;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
+    // 4 k-steps per trip, all 8 loads issued before the first MFMA (the loop is latency bound)
     if (g.transB) {
         const double* bp = g.B + (size_t)bcol * g.ldb;
-        for (int s = 0; s < kq; ++s) {
-            const int k = k_lo + s;
-            const bool kok = k < k_hi;
-            const double a = (aok && kok) ? ap[k] : 0.0;
-            const double b = (bok && kok) ? bp[k] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        for (int s0 = 0; s0 < kq; s0 += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k_lo + s0 + u;
+                const bool kok = (s0 + u < kq) && (k < k_hi);
+                av[u] = (aok && kok) ? ap[k] : 0.0;
+                bv[u] = (bok && kok) ? bp[k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
     } else {
-        for (int s = 0; s < kq; ++s) {
-            const int k = k_lo + s;
-            const bool kok = k < k_hi;
-            const double a = (aok && kok) ? ap[k] : 0.0;
-            const double b = (bok && kok) ? g.B[(size_t)k * g.ldb + bcol] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        for (int s0 = 0; s0 < kq; s0 += 4) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k_lo + s0 + u;
+                const bool kok = (s0 + u < kq) && (k < k_hi);
+                av[u] = (aok && kok) ? ap[k] : 0.0;
+                bv[u] = (bok && kok) ? g.B[(size_t)k * g.ldb + bcol] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -94,15 +105,13 @@ __global__ __launch_bounds__(T) void k_chol(CholArgs c) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int t = threadIdx.x, n = c.n;
     double* A = c.use_lds ? smem : c.work;      // packed lower by rows: (i,j) at i(i+1)/2 + j
-    __shared__ int s_bad;
-    if (t == 0) s_bad = 0;
     for (int i = t / 32; i < n; i += T / 32)
         for (int j = t % 32; j <= i; j += 32) A[i * (i + 1) / 2 + j] = c.S[(size_t)i * c.lds_ + j];
     __syncthreads();
     const int tx = t % 32, ty = t / 32;          // 32 x (T/32) thread tile over the trailing block
     for (int k = 0; k < n; ++k) {
         const double piv = A[k * (k + 1) / 2 + k];
-        if (!(piv > 0.0)) { if (t == 0) { s_bad = 1; c.status[0] = 1; } break; }
+        if (!(piv > 0.0)) { if (t == 0) c.status[0] = 1; break; }
         const double dinv = 1.0 / sqrt(piv);
         __syncthreads();
         for (int i = k + t; i < n; i += T) A[i * (i + 1) / 2 + k] *= dinv;   // column k, incl. diagonal -> sqrt(piv)
@@ -177,6 +186,146 @@ __global__ __launch_bounds__(64) void k_solve(SolveArgs s) {
                 const int i = lane + 64 * m;
                 if (i < j) x[m] -= lrow[i] * kj;
             }
+        }
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int m = 0; m < NREG; ++m) {
+        const int i = lane + 64 * m;
+        if (i < n) {
+            s.Kg[(size_t)row * s.ldk + i] = x[m];
+            dot += x[m] * s.z[(size_t)i * s.zstride];
+        }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) s.dx[row] = dot;
+}
+
+// Register-resident Cholesky for n <= 16*RI and n <= (T/16)*QJ: thread (ti, tj) =
+// (t & 15, t >> 4) owns the entries (ti + 16 r, tj + NTJ q) of the lower triangle.
+// Per column k the owners publish the (unscaled) column through a double-buffered
+// LDS vector -> one barrier per column; every thread scales by rsqrt(pivot) itself
+// and applies the rank-1 update to its registers.  The factor is collected in LDS
+// (packed) and written to HBM once at the end: the loop touches no global memory.
+template <int T, int RI, int QJ>
+__global__ __launch_bounds__(T) void k_chol_reg(CholArgs c) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NTJ = T / 16;                  // column residues
+    constexpr int CB = 16 * RI + 16;
+    const int t = threadIdx.x, n = c.n;
+    const int ti = t & 15, tj = t >> 4;
+    double* colbuf = smem;                       // [2][CB]
+    double* lp = smem + 2 * CB;                  // packed lower factor: (i, k) at i(i+1)/2 + k
+    double a[RI][QJ];
+#pragma unroll
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int q = 0; q < QJ; ++q) {
+            const int i = ti + 16 * r, j = tj + NTJ * q;
+            a[r][q] = (i < n && j <= i) ? c.S[(size_t)i * c.lds_ + j] : 0.0;
+        }
+    int bad = 0;
+    for (int k = 0; k < n; ++k) {
+        double* cb = colbuf + (k & 1) * CB;
+        const int qk = k / NTJ;
+        const bool owner = (tj == k - qk * NTJ);
+        if (owner) {
+#pragma unroll
+            for (int q = 0; q < QJ; ++q)
+                if (q == qk) {
+#pragma unroll
+                    for (int r = 0; r < RI; ++r) cb[ti + 16 * r] = a[r][q];
+                }
+        }
+        __syncthreads();
+        const double piv = cb[k];
+        if (!(piv > 0.0)) { bad = 1; break; }
+        const double dinv = rsqrt(piv);
+        double lj[QJ];
+#pragma unroll
+        for (int q = 0; q < QJ; ++q) {
+            const int j = tj + NTJ * q;
+            lj[q] = (j > k && j < n) ? cb[j] * dinv : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int i = ti + 16 * r;
+            const double x = (i >= k && i < n) ? cb[i] * dinv : 0.0;
+            if (owner && i >= k && i < n) lp[i * (i + 1) / 2 + k] = x;     // final column k of L
+            const double li = (i > k) ? x : 0.0;
+#pragma unroll
+            for (int q = 0; q < QJ; ++q) a[r][q] -= li * lj[q];
+        }
+    }
+    __syncthreads();
+    if (bad) { if (t == 0) c.status[0] = 1; return; }
+    for (int i = t >> 6; i < n; i += T / 64)
+        for (int j = (t & 63); j <= i; j += 64) {
+            const double x = lp[i * (i + 1) / 2 + j];
+            c.L[(size_t)i * n + j] = x;
+            c.U[(size_t)j * n + i] = x;
+            if (i == j) c.invd[j] = 1.0 / x;
+        }
+}
+
+// K = Y S^-1 with the packed factor L resident in LDS (n(n+1)/2 doubles): one
+// wavefront per row of Y, WAVES rows per workgroup.
+template <int NREG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int n = s.n, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    double* lp = smem;                          // packed lower: (i, j) at i(i+1)/2 + j
+    double* sinv = smem + (size_t)n * (n + 1) / 2;
+    for (int i = wv; i < n; i += WAVES)
+        for (int j = lane; j <= i; j += 64) lp[i * (i + 1) / 2 + j] = s.L[(size_t)i * n + j];
+    for (int j = t; j < n; j += 64 * WAVES) sinv[j] = s.invd[j];
+    __syncthreads();
+    const int row = blockIdx.x * WAVES + wv;
+    if (row >= s.d) return;
+    double x[NREG];
+#pragma unroll
+    for (int m = 0; m < NREG; ++m) {
+        const int i = lane + 64 * m;
+        x[m] = (i < n) ? s.Y[(size_t)row * s.ldy + i] : 0.0;
+    }
+    // forward sweep  L x = y
+#pragma unroll
+    for (int mj = 0; mj < NREG; ++mj) {
+#pragma unroll 4
+        for (int jj = 0; jj < 64; ++jj) {
+            const int j = mj * 64 + jj;
+            if (j >= n) break;
+            double lv[NREG];
+#pragma unroll
+            for (int m = 0; m < NREG; ++m) {
+                const int i = lane + 64 * m;
+                lv[m] = (m >= mj && i > j && i < n) ? lp[i * (i + 1) / 2 + j] : 0.0;
+            }
+            const double xj = readlane_d(x[mj], jj) * sinv[j];
+            if (lane == jj) x[mj] = xj;
+#pragma unroll
+            for (int m = 0; m < NREG; ++m)
+                if (m >= mj) x[m] -= lv[m] * xj;
+        }
+    }
+    // backward sweep  L^T k = x
+#pragma unroll
+    for (int mj = NREG - 1; mj >= 0; --mj) {
+#pragma unroll 4
+        for (int jj = 63; jj >= 0; --jj) {
+            const int j = mj * 64 + jj;
+            if (j >= n) continue;
+            double lv[NREG];
+#pragma unroll
+            for (int m = 0; m < NREG; ++m) {
+                const int i = lane + 64 * m;
+                lv[m] = (m <= mj && i < j) ? lp[j * (j + 1) / 2 + i] : 0.0;
+            }
+            const double kj = readlane_d(x[mj], jj) * sinv[j];
+            if (lane == jj) x[mj] = kj;
+#pragma unroll
+            for (int m = 0; m < NREG; ++m)
+                if (m <= mj) x[m] -= lv[m] * kj;
         }
     }
     double dot = 0.0;

@@ -21,9 +21,32 @@ using namespace msckf;
 
 namespace {
 
-constexpr int FOLD_T = 256;
+#ifndef MSCKF_FOLD_T
+#define MSCKF_FOLD_T 512
+#endif
+#ifndef MSCKF_FOLD_RL
+#define MSCKF_FOLD_RL 8
+#endif
+constexpr int FOLD_T = MSCKF_FOLD_T;             // main fold kernel threads
+constexpr int FOLD_RL = MSCKF_FOLD_RL;           // row lanes (8 or 16)
+constexpr int FOLD_NCG = FOLD_T / FOLD_RL;       // column groups of the fold kernel
+// register tile variants: window classes W1/W2/W3 (w+1 <= 64 / 128 / 192 columns) x batch rows
+constexpr int FOLD_CPT1 = (64 + FOLD_NCG - 1) / FOLD_NCG;
+constexpr int FOLD_CPT2 = (128 + FOLD_NCG - 1) / FOLD_NCG;
+constexpr int FOLD_CPT3 = (192 + FOLD_NCG - 1) / FOLD_NCG;
+constexpr int FOLD_RPT_LEAF = ((160 / FOLD_RL + 3) / 4) * 4;   // <= 160-row leaves
+constexpr int FOLD_RPT_BIG = 256 / FOLD_RL;                     // 256-row batches (W1, W2)
+constexpr int FOLD_RPT_W3 = 192 / FOLD_RL;                      // 192-row batches (W3)
+constexpr int FOLDG_T = 512;                     // fallback kernel (R streamed through HBM)
 constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgroup
-constexpr int FOLD_LDS_BYTES = 152 * 1024;
+constexpr int FOLD_LDS_BYTES = 160 * 1024 - 512;
+
+inline int fold_class(int w) { return (w + 1 <= 64) ? 1 : (w + 1 <= 128) ? 2 : 3; }
+// rows one register batch of a node with window width w holds
+inline int fold_bmax(int w) {
+    if (w > FOLD_RLDS_MAX_W) return (w + 1 <= 6 * 32) ? 16 * 12 : 16 * 6;     // fallback kernel tiles
+    return FOLD_RL * (fold_class(w) == 3 ? FOLD_RPT_W3 : FOLD_RPT_BIG);
+}
 
 struct Buf {
     void* p = nullptr;
@@ -34,8 +57,6 @@ double now_us() {
     using namespace std::chrono;
     return duration_cast<duration<double, std::micro>>(steady_clock::now().time_since_epoch()).count();
 }
-
-int fold_bcap(int w, int T, int lds_doubles) { return fold_layout(w, T, lds_doubles).bcap; }
 
 }  // namespace
 
@@ -56,7 +77,7 @@ struct msckf_ctx {
     // device buffers
     Buf dP, dPout, dCamR, dCamT, dCamR0, dCamT0, dChi2;
     Buf dViewPtr, dObsUV, dObsSlot, dBase, dMvec, dRho, dFmin, dBlkOff, dStack, dRank, dAcc, dGamma, dCounters;
-    Buf dNodes, dRbuf;
+    Buf dNodes, dRbuf, dStamps;
     Buf dY, dS, dL, dU, dInvd, dK, dB2, dD, dPn, dDx, dCholWork, dStatus;
     // host-side plan
     std::vector<int> perm;                // sorted position -> input index
@@ -107,7 +128,6 @@ Tp* ptr(const Buf& b) { return reinterpret_cast<Tp*>(b.p); }
 void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                 const std::vector<int>& view_sorted) {
     const int F = c->F, N = c->N;
-    const int lds_doubles = FOLD_LDS_BYTES / 8;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 160;
     const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 4;
     c->nodes.clear();
@@ -153,8 +173,8 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
             while (e < end && (e - i) < arity) {
                 const int lo2 = std::min(lo, c->nodes[e].win_lo);
                 const int hi2 = std::max(hi, c->nodes[e].win_lo + c->nodes[e].w / 6 - 1);
-                const int cap = fold_bcap(6 * (hi2 - lo2 + 1), FOLD_T, lds_doubles);
-                if ((e - i) >= 2 && fold_rows + c->nodes[e].w > cap) break;   // keep one LDS batch per node
+                const int cap = fold_bmax(6 * (hi2 - lo2 + 1));
+                if ((e - i) >= 2 && fold_rows + c->nodes[e].w > cap) break;   // keep one register batch per node
                 fold_rows += c->nodes[e].w;
                 lo = lo2; hi = hi2;
                 ++e;
@@ -172,7 +192,8 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
     c->rbuf_doubles = off;
 }
 
-int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& levels) {
+int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& levels,
+                       const std::vector<FoldNode>& all_nodes) {
     FoldArgs a{};
     a.nodes = ptr<FoldNode>(c->dNodes);
     a.lds_doubles = FOLD_LDS_BYTES / 8;
@@ -184,9 +205,46 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
     a.rank = ptr<int>(c->dRank);
     a.accepted = ptr<unsigned char>(c->dAcc);
     a.rbuf = ptr<double>(c->dRbuf);
+    a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) : nullptr;
     for (auto& lv : levels) {
         a.node_base = lv.first;
-        hipLaunchKernelGGL(k_fold<FOLD_T>, dim3(lv.second), dim3(FOLD_T), FOLD_LDS_BYTES, c->stream, a);
+        int maxw = 0, leaf_rows_max = 0;
+        for (int i = lv.first; i < lv.first + lv.second; ++i) {
+            const FoldNode& n = all_nodes[i];
+            maxw = std::max(maxw, n.w);
+            if (n.kind == 0) {
+                const int rows = 2 * (c->h_view_sorted[n.src_end] - c->h_view_sorted[n.src_begin]);
+                leaf_rows_max = std::max(leaf_rows_max, rows);
+            } else {
+                leaf_rows_max = 1 << 30;
+            }
+        }
+        const dim3 grid(lv.second);
+        if (maxw <= FOLD_RLDS_MAX_W) {          // R accumulator resident in LDS
+            const dim3 block(FOLD_T);
+            const bool leaf = all_nodes[lv.first].kind == 0;
+            const bool small = leaf && leaf_rows_max <= FOLD_RL * FOLD_RPT_LEAF;
+            const int cls = fold_class(maxw);
+#define FOLD_LAUNCH(RPT, CPT, TRI) \
+    hipLaunchKernelGGL((k_fold<FOLD_T, FOLD_RL, RPT, CPT, TRI>), grid, block, FOLD_LDS_BYTES, c->stream, a)
+            if (cls == 1) {
+                if (small) FOLD_LAUNCH(FOLD_RPT_LEAF, FOLD_CPT1, false);
+                else if (leaf) FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT1, false);
+                else FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT1, true);
+            } else if (cls == 2) {
+                if (small) FOLD_LAUNCH(FOLD_RPT_LEAF, FOLD_CPT2, false);
+                else if (leaf) FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT2, false);
+                else FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT2, true);
+            } else {
+                if (leaf) FOLD_LAUNCH(FOLD_RPT_W3, FOLD_CPT3, false);
+                else FOLD_LAUNCH(FOLD_RPT_W3, FOLD_CPT3, true);
+            }
+#undef FOLD_LAUNCH
+        } else {                                // wide windows: R streamed through HBM
+            const dim3 block(FOLDG_T);
+            if (maxw + 1 <= 6 * 32) hipLaunchKernelGGL((k_fold_g<FOLDG_T, 12, 6>), grid, block, FOLD_LDS_BYTES, c->stream, a);
+            else hipLaunchKernelGGL((k_fold_g<FOLDG_T, 6, 10>), grid, block, FOLD_LDS_BYTES, c->stream, a);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
@@ -241,9 +299,14 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         CholArgs a{};
         a.S = S; a.lds_ = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = ptr<double>(c->dInvd);
         a.n = dc; a.work = ptr<double>(c->dCholWork); a.status = ptr<int>(c->dStatus);
-        const size_t need = (size_t)dc * (dc + 1) / 2 * 8;
-        a.use_lds = need <= (size_t)(LDS_MAX_BYTES - 1024) ? 1 : 0;
-        hipLaunchKernelGGL(k_chol<512>, dim3(1), dim3(512), a.use_lds ? need : 0, c->stream, a);
+        if (dc <= 192) {
+            const size_t lds_chol = (size_t)(2 * (16 * 12 + 16) + dc * (dc + 1) / 2) * 8;
+            hipLaunchKernelGGL((k_chol_reg<512, 12, 6>), dim3(1), dim3(512), lds_chol, c->stream, a);
+        } else {
+            const size_t need = (size_t)dc * (dc + 1) / 2 * 8;
+            a.use_lds = need <= (size_t)(LDS_MAX_BYTES - 1024) ? 1 : 0;
+            hipLaunchKernelGGL(k_chol<512>, dim3(1), dim3(512), a.use_lds ? need : 0, c->stream, a);
+        }
     }
     // K = Y S^-1, dx = K r_n                 (MSCKF.py:606-607)
     {
@@ -251,10 +314,14 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         a.Y = Y; a.ldy = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = ptr<double>(c->dInvd);
         a.n = dc; a.z = Tblk + dc; a.zstride = ldt; a.Kg = Kg; a.ldk = dc; a.dx = ptr<double>(c->dDx); a.d = d;
         const int nreg = (dc + 63) / 64;
-        if (nreg <= 1) hipLaunchKernelGGL(k_solve<1>, dim3(d), dim3(64), 0, c->stream, a);
-        else if (nreg <= 2) hipLaunchKernelGGL(k_solve<2>, dim3(d), dim3(64), 0, c->stream, a);
-        else if (nreg <= 3) hipLaunchKernelGGL(k_solve<3>, dim3(d), dim3(64), 0, c->stream, a);
-        else if (nreg <= 4) hipLaunchKernelGGL(k_solve<4>, dim3(d), dim3(64), 0, c->stream, a);
+        const size_t lds_need = ((size_t)dc * (dc + 1) / 2 + dc) * 8;
+        if (nreg <= 3 && lds_need <= (size_t)(LDS_MAX_BYTES - 1024)) {
+            constexpr int WV = 4;
+            const dim3 grid((d + WV - 1) / WV), block(64 * WV);
+            if (nreg <= 1) hipLaunchKernelGGL((k_solve_lds<1, WV>), grid, block, lds_need, c->stream, a);
+            else if (nreg <= 2) hipLaunchKernelGGL((k_solve_lds<2, WV>), grid, block, lds_need, c->stream, a);
+            else hipLaunchKernelGGL((k_solve_lds<3, WV>), grid, block, lds_need, c->stream, a);
+        } else if (nreg <= 4) hipLaunchKernelGGL(k_solve<4>, dim3(d), dim3(64), 0, c->stream, a);
         else hipLaunchKernelGGL(k_solve<5>, dim3(d), dim3(64), 0, c->stream, a);
     }
     // Joseph form (MSCKF.py:613) with A = I - K T_H, T_H = [0 | T]:
@@ -279,7 +346,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[0], c->stream));
     if ((rc = launch_feature(c)) != MSCKF_OK) return rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
-    if (c->F > 0 && (rc = launch_fold_levels(c, c->levels)) != MSCKF_OK) return rc;
+    if (c->F > 0 && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     if (with_gain && c->F > 0) {
         if ((rc = launch_gain(c, root_block(c))) != MSCKF_OK) return rc;
@@ -332,13 +399,32 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
-    for (auto& e : c->ev) hipEventCreate(&e);
+    for (auto& e : c->ev) (void)hipEventCreate(&e);
     // kernels that use more than the default 64 KiB of dynamic LDS
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold<FOLD_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        FOLD_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    {
+#define FK(RPT, CPT, TRI) reinterpret_cast<const void*>(&k_fold<FOLD_T, FOLD_RL, RPT, CPT, TRI>)
+        const void* fk[] = {
+            FK(FOLD_RPT_LEAF, FOLD_CPT1, false), FK(FOLD_RPT_BIG, FOLD_CPT1, false), FK(FOLD_RPT_BIG, FOLD_CPT1, true),
+            FK(FOLD_RPT_LEAF, FOLD_CPT2, false), FK(FOLD_RPT_BIG, FOLD_CPT2, false), FK(FOLD_RPT_BIG, FOLD_CPT2, true),
+            FK(FOLD_RPT_W3, FOLD_CPT3, false), FK(FOLD_RPT_W3, FOLD_CPT3, true)};
+#undef FK
+        for (const void* f : fk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
+    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold_g<FOLDG_T, 12, 6>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold_g<FOLDG_T, 6, 10>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<1, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<2, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<3, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_reg<512, 12, 6>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         LDS_MAX_BYTES - 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature), hipFuncAttributeMaxDynamicSharedMemorySize,
                         LDS_MAX_BYTES - 1024);
     const int N = c->maxN, d = 15 + 6 * N, dc = 6 * N;
     int rc = MSCKF_OK;
@@ -359,15 +445,15 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
 
 void msckf_destroy(msckf_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
-                  &c->dRank, &c->dAcc, &c->dGamma, &c->dCounters, &c->dNodes, &c->dRbuf, &c->dY, &c->dS, &c->dL,
+                  &c->dRank, &c->dAcc, &c->dGamma, &c->dCounters, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus};
-    for (Buf* b : all) if (b->p) hipFree(b->p);
-    for (auto& e : c->ev) if (e) hipEventDestroy(e);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (Buf* b : all) if (b->p) (void)hipFree(b->p);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -719,7 +805,7 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     if (int rc = ensure(c, c->dNodes, all.size() * sizeof(FoldNode))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->dNodes.p, all.data(), all.size() * sizeof(FoldNode), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (!levels.empty()) { if (int rc = launch_fold_levels(c, levels)) return rc; }
+    if (!levels.empty()) { if (int rc = launch_fold_levels(c, levels, all)) return rc; }
     const double* root = rb + all.back().out_off;
     // counters[0] decides OK / NOOP in get_result: mark "accepted" when any block is non-empty
     (void)N;
@@ -727,6 +813,29 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     if (rc != MSCKF_OK) return rc;
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
+    return MSCKF_OK;
+}
+
+int msckf_export_result(msckf_ctx* c, void* dx_dst, void* P_dst, int device_ptr) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (!c->ran || !c->ran_gain) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t d = c->d;
+    const hipMemcpyKind kind = device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (dx_dst) HIPCHK(c, hipMemcpyAsync(dx_dst, c->dDx.p, d * 8, kind, c->stream));
+    if (P_dst) HIPCHK(c, hipMemcpyAsync(P_dst, c->dPout.p, d * d * 8, kind, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSCKF_OK;
+}
+
+int msckf_import_covariance(msckf_ctx* c, const void* P, int device_ptr) {
+    if (!c || !P) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t d = c->d;
+    HIPCHK(c, hipMemcpyAsync(c->dP.p, P, d * d * 8, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSCKF_OK;
 }
 
@@ -759,6 +868,18 @@ int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
         if (rn) rn[i] = blk[(size_t)i * (dc + 1) + dc];
     }
     return MSCKF_OK;
+}
+
+int msckf_debug_fold_stamps(msckf_ctx* c, long long* out, int32_t max_nodes) {
+    // out == NULL: enable stamping for the following runs; else copy 8 values per node
+    if (!c) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!out) { return ensure(c, c->dStamps, (size_t)65536 * 8 * 8, true); }
+    if (!c->dStamps.p) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = std::min<size_t>((size_t)max_nodes, c->nodes.size());
+    HIPCHK(c, hipMemcpy(out, c->dStamps.p, n * 64, hipMemcpyDeviceToHost));
+    return (int)n;
 }
 
 uint64_t msckf_device_pointer(msckf_ctx* c, int which) {

@@ -30,10 +30,42 @@ __device__ __forceinline__ double row16_sum(double x) {
     return x;
 }
 
+// Sum over the 8 lanes of each half DPP row; every lane of the group gets the sum.
+__device__ __forceinline__ double row8_sum(double x) {
+    x += dpp_move<0xB1>(x);    // lane ^ 1
+    x += dpp_move<0x4E>(x);    // lane ^ 2
+    x += dpp_move<0x141>(x);   // row_half_mirror: pairs the two quads of each 8
+    return x;
+}
+
 // Sum over all 64 lanes; the result is wave-uniform.
 __device__ __forceinline__ double wave_sum(double x) {
     x = row16_sum(x);
     return (readlane_d(x, 0) + readlane_d(x, 16)) + (readlane_d(x, 32) + readlane_d(x, 48));
+}
+
+// Sum over RL (8 or 16) adjacent lanes.
+template <int RL>
+__device__ __forceinline__ double rowN_sum(double x) {
+    if constexpr (RL == 16) return row16_sum(x);
+    else return row8_sum(x);
+}
+
+// 1/sqrt(s) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-26) plus two
+// Newton steps each: ~1 ulp, a short dependent chain instead of the IEEE sqrt/div expansions.
+// Valid for normal, well-scaled arguments (callers fall back to sqrt / division otherwise).
+__device__ __forceinline__ double fast_rsqrt(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    const double h = 0.5 * s;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
 }
 
 __device__ __forceinline__ double lane_bcast(double x, int lane) { return readlane_d(x, lane); }

@@ -1,0 +1,212 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against
+ (a) the golden fixtures captured from the reference,
+ (b) the oracle on freshly seeded problems,
+ (c) size-independent properties at BASELINE.json's full sizes.
+Tolerance: 1e-8 relative on dx and P+ (BASELINE.json north_star); observed ~1e-14."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from msckf_amd.api import UpdateEngine
+    e = UpdateEngine(max_clones=50, max_features=20000, max_track=31)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_golden(eng, case):
+    prob, ref = load_golden(case)
+    res = eng.update_problem(prob)
+    assert res.status == int(ref["status"])
+    assert np.array_equal(res.accepted, ref["accepted"])
+    assert res.n_rejected == int(ref["n_rejected"])
+    gam, q = eng.debug_gate()
+    np.testing.assert_allclose(gam, ref["gamma"], rtol=1e-9, atol=1e-12)
+    assert rel_err(res.dx, ref["dx"]) < TOL
+    assert rel_err(res.P_new, ref["P_new"]) < TOL
+    assert np.array_equal(res.P_new, res.P_new.T)
+    if res.status == 0:
+        # basis-invariant check of the compressed system: T^T T = H^T H, T^T r_n = H^T r
+        T, rn = eng.debug_compressed()
+        d = prob.d
+        G = np.zeros((d, d)); G[15:, 15:] = T.T @ T
+        b = np.zeros(d); b[15:] = T.T @ rn
+        assert rel_err(G, ref["G"]) < 1e-10
+        assert rel_err(b, ref["b"]) < 1e-10
+        assert np.allclose(np.tril(T, -1), 0.0)
+        assert res.stats["stacked_rows"] == int(sum(q[res.accepted == 1]))
+    else:
+        assert np.array_equal(res.P_new, prob.P) and not res.dx.any()     # untouched state, MSCKF.py:584-585
+
+
+@pytest.mark.parametrize("N,F,M,seed,kw", [
+    (10, 50, 5, 21, {}),
+    (20, 500, 8, 22, {"outlier_fraction": 0.1, "outlier_px": 500.0}),
+    (12, 300, 12, 23, {"variable_tracks": True}),
+    (31, 64, 31, 24, {}),                      # maximum track length, every row of the wavefront in use
+    (50, 400, 15, 25, {}),                     # N = 50 (d = 315): S too large for the LDS Cholesky path
+    (6, 3, 2, 26, {}),                         # two-view tracks: one projected row each
+])
+def test_against_oracle(eng, N, F, M, seed, kw):
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=seed, **kw)
+    ref = oracle.update(prob, dense_noise=False)
+    res = eng.update_problem(prob)
+    assert res.status == ref["status"]
+    assert np.array_equal(res.accepted, ref["accepted"])
+    assert rel_err(res.dx, ref["dx"]) < TOL
+    assert rel_err(res.P_new, ref["P_new"]) < TOL
+
+
+def test_resident_path_equals_one_shot(eng):
+    prob, ref = load_golden("cfg2_A")
+    one = eng.update_problem(prob)
+    eng.load(prob)
+    eng.run()
+    r1 = eng.result()
+    eng.run()                                   # same inputs again: bitwise reproducible
+    r2 = eng.result()
+    assert np.array_equal(r1.dx, one.dx) and np.array_equal(r1.P_new, one.P_new)
+    assert np.array_equal(r1.dx, r2.dx) and np.array_equal(r1.P_new, r2.P_new)
+    ms, stages = eng.run_timed(5, stages=True)
+    assert ms > 0 and len(stages) == 3 and all(s > 0 for s in stages)
+
+
+def test_feature_order_invariance_full_size(eng):
+    """Headline size (N=30, F=2000, M=10): dx and P+ do not depend on the order of
+    the feature dict nor on the QR tree shape."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    prob = synth.make_problem(30, 2000, 10, seed=5)
+    base = eng.update_problem(prob)
+    assert base.status == 0
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(prob.F)
+    M = 10
+    idx = (perm[:, None] * M + np.arange(M)[None, :]).reshape(-1)
+    p2 = synth.UpdateProblem(P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
+                             gravity=prob.gravity, K=prob.K, sigma=prob.sigma, view_ptr=prob.view_ptr,
+                             obs_uv=prob.obs_uv[idx], obs_slot=prob.obs_slot[idx], idp_base=prob.idp_base[perm],
+                             idp_m=prob.idp_m[perm], idp_rho=prob.idp_rho[perm])
+    r2 = eng.update_problem(p2)
+    assert np.array_equal(r2.accepted, base.accepted[perm])
+    assert rel_err(r2.dx, base.dx) < 1e-10 and rel_err(r2.P_new, base.P_new) < 1e-11
+    with UpdateEngine(max_clones=30, max_features=2000, max_track=10, leaf_rows=400, merge_arity=2) as e3:
+        r3 = e3.update_problem(prob)
+    assert rel_err(r3.dx, base.dx) < 1e-10 and rel_err(r3.P_new, base.P_new) < 1e-11
+
+
+def test_covariance_properties_full_size(eng):
+    """cfg3-size update: P+ symmetric, P - P+ positive semidefinite (information
+    only adds), and the update is the oracle's (checked through the fixture)."""
+    prob, ref = load_golden("cfg3_A")
+    res = eng.update_problem(prob)
+    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+    ev = np.linalg.eigvalsh(prob.P - res.P_new)
+    assert ev.min() > -1e-12 * abs(ev).max()
+    assert np.linalg.eigvalsh(res.P_new).min() > 0
+
+
+@pytest.mark.parametrize("shards", [2, 3, 4])
+def test_logical_shards_on_one_gpu(eng, shards):
+    """Shard-merge invariance: S logical shards compressed
+    one after the other on one GPU, merged, equal the single-shard update."""
+    from msckf_amd.shard import partition_features
+    prob, ref = load_golden("cfg2_B")
+    blocks, total, acc = [], 0, np.zeros(prob.F, dtype=np.uint8)
+    for lo, hi in partition_features(prob.view_ptr, shards):
+        eng.load(prob.subset(lo, hi))
+        eng.run_compress()
+        blk, n = eng.export_block()
+        acc[lo:hi] = eng.result().accepted
+        blocks.append(blk); total += n
+    eng.set_state(prob)
+    eng.merge_gain(np.stack(blocks), total)
+    res = eng.result()
+    assert res.status == 0 and np.array_equal(acc, ref["accepted"])
+    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+
+
+def test_sharded_driver_world1(eng):
+    from msckf_amd.shard import HipShardBackend, ShardedUpdate
+    prob, ref = load_golden("edge_some_rejected")
+    status, dx, P_new, acc = ShardedUpdate(HipShardBackend(eng), 0, 1).update(prob)
+    assert status == 0 and np.array_equal(acc, ref["accepted"])
+    assert rel_err(dx, ref["dx"]) < TOL and rel_err(P_new, ref["P_new"]) < TOL
+
+
+def test_two_consecutive_updates_keep_covariance_resident(eng):
+    """P stays in HBM between updates: update, commit, update."""
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    p1 = synth.make_problem(15, 120, 6, seed=31)
+    p2 = synth.make_problem(15, 100, 7, seed=32, poses=(p1.cam_R, p1.cam_t))   # same clones, new tracks
+    o1 = oracle.update(p1)
+    p2.P = o1["P_new"]
+    o2 = oracle.update(p2)
+    eng.load(p1); eng.run()
+    assert eng.commit_covariance() == 0
+    eng.set_features(p2); eng.run()
+    r2 = eng.result()
+    assert rel_err(r2.dx, o2["dx"]) < TOL and rel_err(r2.P_new, o2["P_new"]) < TOL
+
+
+def test_reference_shaped_adapter(eng):
+    """`UpdateEngine.update(filt, features)` mutates reference-shaped objects the
+    way MSCKF.update + correct do (poses, biases, covariance, counter)."""
+    from test_host_logic import make_reference_shaped
+    prob, ref = load_golden("edge_some_rejected")
+    filt, feats = make_reference_shaped(prob, ref)
+    assert eng.update(filt, feats) == 0
+    assert filt.number_of_residuals_discarded_for_gasting_test == int(ref["n_rejected"])
+    assert rel_err(filt.state.covariance, ref["P_new"]) < TOL
+    np.testing.assert_allclose(filt.state.imu.T_W_Ii.R, ref["post_imu_R"], atol=1e-9)
+    np.testing.assert_allclose(filt.state.imu.T_W_Ii.t, ref["post_imu_t"], atol=1e-9)
+    for i, cam in enumerate(filt.state.cameras.values()):
+        np.testing.assert_allclose(cam.T_W_Ci.R, ref["post_cam_R"][i], atol=1e-9)
+        np.testing.assert_allclose(cam.T_W_Ci.t, ref["post_cam_t"][i], atol=1e-9)
+
+
+def test_error_codes(eng):
+    from msckf_amd import _ffi, synth
+    prob = synth.make_problem(8, 10, 4, seed=1)
+    bad = synth.UpdateProblem(**{**prob.__dict__})
+    bad.obs_slot = prob.obs_slot.copy(); bad.obs_slot[1] = bad.obs_slot[0]      # same clone twice in a track
+    with pytest.raises(_ffi.EngineError) as e:
+        eng.update_problem(bad)
+    assert e.value.code == _ffi.ERR_DUP_SLOT
+    bad2 = synth.UpdateProblem(**{**prob.__dict__})
+    bad2.obs_slot = prob.obs_slot.copy(); bad2.obs_slot[0] = 99
+    with pytest.raises(_ffi.EngineError) as e:
+        eng.update_problem(bad2)
+    assert e.value.code == _ffi.ERR_ARG
+    empty = prob.subset(0, 0)
+    res = eng.update_problem(empty)                                              # empty dict: no-op
+    assert res.status == 1 and np.array_equal(res.P_new, prob.P)
+
+
+def test_torch_shares_the_device(eng):
+    """torch (plumbing for the RCCL gather) and the engine in one process: export a
+    block straight into a torch-owned HBM buffer."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    prob, _ = load_golden("cfg1_A")
+    eng.load(prob); eng.run_compress()
+    host_blk, n = eng.export_block()
+    buf = torch.zeros(eng.block_doubles(), dtype=torch.float64, device="cuda:0")
+    eng.export_block(dst_ptr=buf.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy().reshape(host_blk.shape), host_blk)
+    eng.set_state(prob)
+    eng.merge_gain(int(buf.data_ptr()), n, n_blocks=1)
+    assert eng.result().status == 0

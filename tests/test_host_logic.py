@@ -1,0 +1,101 @@
+"""CPU tests of the host-side mirror: packing of reference-shaped objects, state
+injection (reference MSCKF.correct :616-661), chi-square table, sharding."""
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_golden, rel_err
+
+
+def make_reference_shaped(prob, ref):
+    """Mock objects with the attributes MSCKF.update / correct touch."""
+    keys = [7 * (i + 3) for i in range(prob.N)]
+    cams = OrderedDict()
+    for i, k in enumerate(keys):
+        pose = SimpleNamespace(R=prob.cam_R[i].copy(), t=prob.cam_t[i].copy())
+        same = np.array_equal(prob.cam_R0[i], prob.cam_R[i]) and np.array_equal(prob.cam_t0[i], prob.cam_t[i])
+        null = pose if same else SimpleNamespace(R=prob.cam_R0[i].copy(), t=prob.cam_t0[i].copy())
+        cams[k] = SimpleNamespace(T_W_Ci=pose, T_W_Ci_null=null)
+    imu = SimpleNamespace(W_gravity=prob.gravity.copy(),
+                          T_W_Ii=SimpleNamespace(R=ref["imu_R"].copy(), t=ref["imu_t"].copy()),
+                          v_W_Ii=ref["imu_v"].copy(), gyroscope_bias=ref["imu_bg"].copy(),
+                          accelerometer_bias=ref["imu_ba"].copy())
+    state = SimpleNamespace(cameras=cams, covariance=prob.P.copy(), imu=imu)
+    filt = SimpleNamespace(state=state, K=prob.K, sigma_image=prob.sigma,
+                           number_of_residuals_discarded_for_gasting_test=0)
+    feats = OrderedDict()
+    for j in range(prob.F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        idp = SimpleNamespace(base=prob.idp_base[j].copy(), m=prob.idp_m[j].copy(), rho=float(prob.idp_rho[j]))
+        feats[1000 + j] = SimpleNamespace(keypoints=[prob.obs_uv[i].copy() for i in range(a, b)],
+                                          camera_indices=[keys[int(prob.obs_slot[i])] for i in range(a, b)],
+                                          inverse_depth_point=idp)
+    return filt, feats
+
+
+@pytest.mark.parametrize("case", ["cfg1_A", "edge_null_pose", "edge_variable_tracks"])
+def test_pack_roundtrip(case):
+    from msckf_amd.pack import problem_from_reference
+    prob, ref = load_golden(case)
+    filt, feats = make_reference_shaped(prob, ref)
+    p2 = problem_from_reference(filt, feats)
+    for name in ["P", "cam_R", "cam_t", "cam_R0", "cam_t0", "gravity", "view_ptr", "obs_uv", "obs_slot",
+                 "idp_base", "idp_m", "idp_rho"]:
+        assert np.array_equal(getattr(p2, name), getattr(prob, name)), name
+    assert p2.sigma == prob.sigma
+
+
+@pytest.mark.parametrize("case", ["cfg1_A", "cfg1_B", "edge_null_pose", "edge_some_rejected"])
+def test_inject_state_matches_reference(case):
+    from msckf_amd.inject import inject_state
+    prob, ref = load_golden(case)
+    filt, _ = make_reference_shaped(prob, ref)
+    inject_state(filt.state, ref["dx"])
+    np.testing.assert_allclose(filt.state.imu.T_W_Ii.R, ref["post_imu_R"], atol=1e-13)
+    np.testing.assert_allclose(filt.state.imu.T_W_Ii.t, ref["post_imu_t"], atol=1e-13)
+    np.testing.assert_allclose(filt.state.imu.v_W_Ii, ref["post_imu_v"], atol=1e-13)
+    np.testing.assert_allclose(filt.state.imu.gyroscope_bias, ref["post_imu_bg"], atol=1e-13)
+    np.testing.assert_allclose(filt.state.imu.accelerometer_bias, ref["post_imu_ba"], atol=1e-13)
+    for i, cam in enumerate(filt.state.cameras.values()):
+        np.testing.assert_allclose(cam.T_W_Ci.R, ref["post_cam_R"][i], atol=1e-13)
+        np.testing.assert_allclose(cam.T_W_Ci.t, ref["post_cam_t"][i], atol=1e-13)
+
+
+def test_packaged_chi2_table_equals_golden():
+    from msckf_amd.api import chi2_table
+    t = np.load(os.path.join(GOLDEN_DIR, "chi2_ppf_095.npy"))
+    assert np.array_equal(chi2_table(), t)
+
+
+def test_synth_is_seeded():
+    from msckf_amd import synth
+    a = synth.make_problem(10, 30, 5, seed=3)
+    b = synth.make_problem(10, 30, 5, seed=3)
+    c = synth.make_problem(10, 30, 5, seed=4)
+    assert np.array_equal(a.obs_uv, b.obs_uv) and np.array_equal(a.P, b.P)
+    assert not np.array_equal(a.obs_uv, c.obs_uv)
+    assert a.view_ptr[-1] == a.obs_slot.size == 150
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_partition_covers_and_balances(world):
+    from msckf_amd import synth
+    from msckf_amd.shard import partition_features
+    p = synth.make_problem(12, 200, 10, seed=1, variable_tracks=True)
+    parts = partition_features(p.view_ptr, world)
+    assert parts[0][0] == 0 and parts[-1][1] == p.F
+    for (a, b), (c, d) in zip(parts[:-1], parts[1:]):
+        assert b == c and a <= b
+    rows = [2 * int(p.view_ptr[hi] - p.view_ptr[lo]) for lo, hi in parts]
+    assert max(rows) - min(rows) <= 2 * 2 * 10 + 2
+
+
+def test_subset_shares_state():
+    from msckf_amd import synth
+    p = synth.make_problem(8, 40, 5, seed=2)
+    s = p.subset(10, 25)
+    assert s.F == 15 and s.view_ptr[0] == 0 and s.P is p.P
+    assert np.array_equal(s.obs_uv, p.obs_uv[p.view_ptr[10]:p.view_ptr[25]])
