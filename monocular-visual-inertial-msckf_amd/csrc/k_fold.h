@@ -405,7 +405,7 @@ __host__ __device__ inline FoldLayoutR fold_layout_r(int w, int bmax, int lds_do
     FoldLayoutR L;
     L.ld = (w + 1) | 1;
     L.vbuf = 0;
-    L.ints = 2 * (bmax + 2);
+    L.ints = 2 * (bmax + 4);            // double-buffered published column
     const int nints = (FOLD_MAX_SRC + 1) + 8 + 2 * bmax + 16 * 32 + w;
     L.racc = L.ints + (nints + 1) / 2;
     L.panel = L.racc + (w + 1) * (w + 2) / 2;
@@ -603,12 +603,14 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
         if (p.stamps) { const long long tn = wall_clock64(); tk2 += tn - ts0; ts0 = tn; }
 
         // ---------- elimination: one reflector per column, no global memory ---------
+        // (A one-column lookahead and a dedicated "chain" wavefront were both measured and are
+        // slower on gfx950: the per-column cost is the sum of latency-bound pieces -- LDS round
+        // trip ~150 cycles, a 20-row dot + DPP reduction ~650, rsqrt/rcp chain ~175, update ~160
+        // at two wavefronts per SIMD, tools/ubench/step_latency.hip -- not the barrier itself.)
         int roff = jmin * (w + 1) - (jmin * (jmin - 1)) / 2;          // start of R row j in racc
         const int cgw = (t >> 6) * (64 / RL);                         // first column group of this wave
-        unsigned long long cA = 0, cB = 0, cC = 0, cD = 0, c0 = 0, c1 = 0;
         for (int j = jmin; j < w; ++j) {
-            if (p.stamps) c0 = __builtin_amdgcn_s_memtime();
-            double* vb = vbuf + (j & 1) * (BMAX + 2);
+            double* vb = vbuf + (j & 1) * (BMAX + 4);
             // live register rows, in blocks of 4 (uniform over the workgroup)
             const int rb = TRI ? (((nalive[j] + RL - 1) / RL) + 3) >> 2 : RPT / 4;
             const int kj = j / NCG;
@@ -627,7 +629,6 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 if (rq == 0) vb[BMAX] = racc[roff];                  // pivot R_jj
             }
             __syncthreads();
-            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cA += c1 - c0; c0 = c1; }
             double v[RPT];
             double sg0 = 0.0, sg1 = 0.0, sg2 = 0.0, sg3 = 0.0;
 #pragma unroll
@@ -647,7 +648,6 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
             }
             const double x0 = vb[BMAX];
             const double sg = rowN_sum<RL>((sg0 + sg1) + (sg2 + sg3));
-            if (p.stamps) { asm volatile("" :: "v"(sg)); c1 = __builtin_amdgcn_s_memtime(); cB += c1 - c0; c0 = c1; }
             if (sg > 0.0) {
                 const double ss = fma(x0, x0, sg);
                 double nrm, beta;
@@ -660,7 +660,6 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 }
                 const double alpha = (x0 > 0.0) ? -nrm : nrm;
                 const double v0 = x0 - alpha;
-                if (p.stamps) { asm volatile("" :: "v"(beta), "v"(v0)); c1 = __builtin_amdgcn_s_memtime(); cC += c1 - c0; c0 = c1; }
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     // slot k of this wave's groups holds columns cgw + NCG k .. + 64/RL - 1: all retired?
@@ -690,12 +689,10 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 }
                 if (t == 0) racc[roff] = alpha;
             }
-            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cD += c1 - c0; }
             roff += (w + 1) - j;
         }
         __syncthreads();
         if (p.stamps) { const long long tn = wall_clock64(); tk3 += tn - ts0; }
-        if (p.stamps && t == 0) { long long* o = p.stamps + 8 * (p.node_base + blockIdx.x); o[6] = (long long)((cA << 32) | (cB & 0xffffffffull)); o[7] = (long long)((cC << 32) | (cD & 0xffffffffull)); }
     }
 
     // ---- flush R to the node's block (row-major w x (w+1), entries at and right of the diagonal)

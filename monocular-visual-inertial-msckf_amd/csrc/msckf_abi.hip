@@ -25,7 +25,7 @@ namespace {
 #define MSCKF_FOLD_T 512
 #endif
 #ifndef MSCKF_FOLD_RL
-#define MSCKF_FOLD_RL 8
+#define MSCKF_FOLD_RL 16
 #endif
 constexpr int FOLD_T = MSCKF_FOLD_T;             // main fold kernel threads
 constexpr int FOLD_RL = MSCKF_FOLD_RL;           // row lanes (8 or 16)
