@@ -299,9 +299,9 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         CholArgs a{};
         a.S = S; a.lds_ = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = ptr<double>(c->dInvd);
         a.n = dc; a.work = ptr<double>(c->dCholWork); a.status = ptr<int>(c->dStatus);
-        if (dc <= 192) {
-            const size_t lds_chol = (size_t)(2 * (16 * 12 + 16) + dc * (dc + 1) / 2) * 8;
-            hipLaunchKernelGGL((k_chol_reg<512, 12, 6>), dim3(1), dim3(512), lds_chol, c->stream, a);
+        if ((size_t)dc * (dc + 1) / 2 * 8 <= (size_t)(LDS_MAX_BYTES - 1024)) {
+            const size_t lds_chol = (size_t)dc * (dc + 1) / 2 * 8;
+            hipLaunchKernelGGL((k_chol_blk<512>), dim3(1), dim3(512), lds_chol, c->stream, a);
         } else {
             const size_t need = (size_t)dc * (dc + 1) / 2 * 8;
             a.use_lds = need <= (size_t)(LDS_MAX_BYTES - 1024) ? 1 : 0;
@@ -419,6 +419,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<2, 4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<3, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_blk<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_reg<512, 12, 6>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);

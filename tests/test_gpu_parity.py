@@ -194,19 +194,39 @@ def test_error_codes(eng):
     assert res.status == 1 and np.array_equal(res.P_new, prob.P)
 
 
-def test_torch_shares_the_device(eng):
-    """torch (plumbing for the RCCL gather) and the engine in one process: export a
-    block straight into a torch-owned HBM buffer."""
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
-    prob, _ = load_golden("cfg1_A")
-    eng.load(prob); eng.run_compress()
-    host_blk, n = eng.export_block()
-    buf = torch.zeros(eng.block_doubles(), dtype=torch.float64, device="cuda:0")
-    eng.export_block(dst_ptr=buf.data_ptr())
-    torch.cuda.synchronize()
-    assert np.array_equal(buf.cpu().numpy().reshape(host_blk.shape), host_blk)
-    eng.set_state(prob)
-    eng.merge_gain(int(buf.data_ptr()), n, n_blocks=1)
-    assert eng.result().status == 0
+def test_torch_shares_the_device():
+    """torch (plumbing for the RCCL gather) and the engine in one process: export a block
+    straight into a torch-owned HBM buffer and merge from it.  torch must be imported BEFORE
+    the engine library is loaded (both bring a libamdhip64.so.7; the first one loaded serves
+    the process), so this runs in a fresh interpreter."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
+import torch
+assert torch.cuda.is_available(), 'torch sees no GPU'
+import msckf_amd
+from msckf_amd.api import UpdateEngine
+from conftest import load_golden, rel_err
+prob, ref = load_golden('cfg1_A')
+eng = UpdateEngine(max_clones=10, max_features=64, max_track=8)
+eng.load(prob); eng.run_compress()
+host_blk, n = eng.export_block()
+buf = torch.zeros(eng.block_doubles(), dtype=torch.float64, device='cuda:0')
+eng.export_block(dst_ptr=buf.data_ptr())
+torch.cuda.synchronize()
+assert np.array_equal(buf.cpu().numpy().reshape(host_blk.shape), host_blk)
+eng.set_state(prob)
+eng.merge_gain(int(buf.data_ptr()), n, n_blocks=1)
+res = eng.result()
+assert res.status == 0 and rel_err(res.dx, ref['dx']) < 1e-8 and rel_err(res.P_new, ref['P_new']) < 1e-8
+out = torch.zeros(prob.d + prob.d ** 2, dtype=torch.float64, device='cuda:0')
+eng.export_result(out.data_ptr(), out.data_ptr() + 8 * prob.d)
+torch.cuda.synchronize()
+assert np.array_equal(out[:prob.d].cpu().numpy(), res.dx)
+print('TORCH_INTEROP_OK')
+""" % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "TORCH_INTEROP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
