@@ -460,16 +460,19 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
     }
     __syncthreads();
     if (nd.kind == 1) {
+        // adopt the first child's R: one wavefront per row, lanes over the columns (coalesced, no div)
         const FoldNode c0 = p.nodes[nd.src_begin];
         const int off = 6 * (c0.win_lo - nd.win_lo);
         const int cw = c0.w, cld = c0.w + 1;
         const double* blk = p.rbuf + c0.out_off;
-        for (int e = t; e < cw * cld; e += T) {
-            const int ri = e / cld, cc = e - ri * cld;
-            if (cc < ri) continue;
+        for (int ri = t >> 6; ri < cw; ri += T / 64) {
             const int j = off + ri;
-            const int c = (cc == cw) ? w : off + cc;
-            racc[j * (w + 1) - (j * (j - 1)) / 2 + (c - j)] = blk[e];
+            double* dst = racc + j * (w + 1) - (j * (j - 1)) / 2;        // row j, entry (c - j)
+            const double* srcrow = blk + (size_t)ri * cld;
+            for (int cc = ri + (t & 63); cc <= cw; cc += 64) {
+                const int c = (cc == cw) ? w : off + cc;
+                dst[c - j] = srcrow[cc];
+            }
         }
     }
     if (t == 0) {

@@ -201,80 +201,16 @@ __global__ __launch_bounds__(64) void k_solve(SolveArgs s) {
     if (lane == 0) s.dx[row] = dot;
 }
 
-// Register-resident Cholesky for n <= 16*RI and n <= (T/16)*QJ: thread (ti, tj) =
-// (t & 15, t >> 4) owns the entries (ti + 16 r, tj + NTJ q) of the lower triangle.
-// Per column k the owners publish the (unscaled) column through a double-buffered
-// LDS vector -> one barrier per column; every thread scales by rsqrt(pivot) itself
-// and applies the rank-1 update to its registers.  The factor is collected in LDS
-// (packed) and written to HBM once at the end: the loop touches no global memory.
-template <int T, int RI, int QJ>
-__global__ __launch_bounds__(T) void k_chol_reg(CholArgs c) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int NTJ = T / 16;                  // column residues
-    constexpr int CB = 16 * RI + 16;
-    const int t = threadIdx.x, n = c.n;
-    const int ti = t & 15, tj = t >> 4;
-    double* colbuf = smem;                       // [2][CB]
-    double* lp = smem + 2 * CB;                  // packed lower factor: (i, k) at i(i+1)/2 + k
-    double a[RI][QJ];
-#pragma unroll
-    for (int r = 0; r < RI; ++r)
-#pragma unroll
-        for (int q = 0; q < QJ; ++q) {
-            const int i = ti + 16 * r, j = tj + NTJ * q;
-            a[r][q] = (i < n && j <= i) ? c.S[(size_t)i * c.lds_ + j] : 0.0;
-        }
-    int bad = 0;
-    for (int k = 0; k < n; ++k) {
-        double* cb = colbuf + (k & 1) * CB;
-        const int qk = k / NTJ;
-        const bool owner = (tj == k - qk * NTJ);
-        if (owner) {
-#pragma unroll
-            for (int q = 0; q < QJ; ++q)
-                if (q == qk) {
-#pragma unroll
-                    for (int r = 0; r < RI; ++r) cb[ti + 16 * r] = a[r][q];
-                }
-        }
-        __syncthreads();
-        const double piv = cb[k];
-        if (!(piv > 0.0)) { bad = 1; break; }
-        const double dinv = rsqrt(piv);
-        double lj[QJ];
-#pragma unroll
-        for (int q = 0; q < QJ; ++q) {
-            const int j = tj + NTJ * q;
-            lj[q] = (j > k && j < n) ? cb[j] * dinv : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < RI; ++r) {
-            const int i = ti + 16 * r;
-            const double x = (i >= k && i < n) ? cb[i] * dinv : 0.0;
-            if (owner && i >= k && i < n) lp[i * (i + 1) / 2 + k] = x;     // final column k of L
-            const double li = (i > k) ? x : 0.0;
-#pragma unroll
-            for (int q = 0; q < QJ; ++q) a[r][q] -= li * lj[q];
-        }
-    }
-    __syncthreads();
-    if (bad) { if (t == 0) c.status[0] = 1; return; }
-    for (int i = t >> 6; i < n; i += T / 64)
-        for (int j = (t & 63); j <= i; j += 64) {
-            const double x = lp[i * (i + 1) / 2 + j];
-            c.L[(size_t)i * n + j] = x;
-            c.U[(size_t)j * n + i] = x;
-            if (i == j) c.invd[j] = 1.0 / x;
-        }
-}
-
 // Blocked Cholesky, block = 6 columns (one clone block; n = 6N is always a multiple of 6).
 // The packed lower triangle lives in LDS.  Per block: every thread reads the 6x6 diagonal
 // block and factors it redundantly in registers (the six dependent rsqrt steps cost no
 // barrier and no LDS round trip), one thread per row solves the panel, then the trailing
 // matrix takes a rank-6 update in 4x4 register tiles.  Two barriers per SIX columns instead
 // of one per column: the per-column latency chain (tools/ubench/step_latency.hip) is what
-// bounds an unblocked factorisation at ~1 us per column.
+// bounds an unblocked factorisation at ~1 us per column.  (Variants measured and dropped: an
+// unblocked register-resident factorisation, 290 us at n = 180, and MFMA accumulator tiles for
+// the trailing update, 131 us; this kernel: 126 us, of which the 30 in-register diagonal
+// factorisations are 45 us.)
 template <int T, int DBG = 0>
 __global__ __launch_bounds__(T) void k_chol_blk(CholArgs c) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -334,42 +270,41 @@ __global__ __launch_bounds__(T) void k_chol_blk(CholArgs c) {
                 for (int b = 0; b <= a; ++b) A[(c0 + a) * (c0 + a + 1) / 2 + c0 + b] = Ld[a][b];
         }
         __syncthreads();
-        // 3. trailing update in 4x4 tiles: A[i][j] -= sum_a L[i][c0+a] L[j][c0+a], j <= i
+        // 3. trailing update in 4x4 register tiles: A[i][j] -= sum_a L[i][c0+a] L[j][c0+a], j <= i.
+        //    The nt(nt+1)/2 lower tiles are dealt round-robin over the threads (balanced).
         const int nt = (n - c1 + 3) >> 2;                // tiles per side
-        const int tx = t & 15, ty = t >> 4;
+        const int ntile = nt * (nt + 1) / 2;
         if (DBG < 1)
-        for (int ti = ty; ti < nt; ti += T / 16) {
-            const int i0 = c1 + 4 * ti;
-            double Li[4][NB];
+        for (int e = t; e < ntile; e += T) {
+            int ti = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+            while (ti * (ti + 1) / 2 > e) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+            const int tj = e - ti * (ti + 1) / 2;
+            const int i0 = c1 + 4 * ti, j0 = c1 + 4 * tj;
+            double Li[4][NB], Lj[4][NB];
+            int bi[4], bj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u, n - 1), j = min(j0 + u, n - 1);
+                bi[u] = i * (i + 1) / 2;
+                bj[u] = j * (j + 1) / 2;
+#pragma unroll
+                for (int a = 0; a < NB; ++a) {
+                    Li[u][a] = A[bi[u] + c0 + a];
+                    Lj[u][a] = A[bj[u] + c0 + a];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u;
 #pragma unroll
-                for (int a = 0; a < NB; ++a) Li[u][a] = (i < n) ? A[i * (i + 1) / 2 + c0 + a] : 0.0;
-            }
-            for (int tj = tx; tj <= ti; tj += 16) {
-                const int j0 = c1 + 4 * tj;
-                double Lj[4][NB];
+                for (int v = 0; v < 4; ++v) {
+                    const int j = j0 + v;
+                    if (i < n && j <= i) {
+                        double x = A[bi[u] + j];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + u;
-#pragma unroll
-                    for (int a = 0; a < NB; ++a) Lj[u][a] = (j < n) ? A[j * (j + 1) / 2 + c0 + a] : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u;
-                    if (i < n) {
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int j = j0 + v;
-                            if (j <= i) {
-                                double x = A[i * (i + 1) / 2 + j];
-#pragma unroll
-                                for (int a = 0; a < NB; ++a) x = fma(-Li[u][a], Lj[v][a], x);
-                                A[i * (i + 1) / 2 + j] = x;
-                            }
-                        }
+                        for (int a = 0; a < NB; ++a) x = fma(-Li[u][a], Lj[v][a], x);
+                        A[bi[u] + j] = x;
                     }
                 }
             }

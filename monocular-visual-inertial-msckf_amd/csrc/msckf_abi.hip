@@ -422,8 +422,6 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_blk<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_reg<512, 12, 6>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature), hipFuncAttributeMaxDynamicSharedMemorySize,
