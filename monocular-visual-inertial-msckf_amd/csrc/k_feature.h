@@ -44,9 +44,9 @@ struct FeatureArgs {
     const long long* blk_off;    // [F] offset (doubles) of the feature's stack block
     double* stack;               // blocks: column-major (6M+1) columns x 2M rows
     int* rank;                   // [F] rank of H_f (rows < rank are not part of the projection)
-    unsigned char* accepted;     // [F] (sorted order)
+    unsigned char* accepted;     // [F] (sorted order): 1 accepted, 0 gate-rejected, 2 not-SPD
     double* gamma;               // [F]
-    int* counters;               // [0] accepted, [1] stacked rows, [2] not-SPD gate matrices
+    long long* stamps;           // optional diagnostics (8 per feature), may be null
 };
 
 // LDS doubles needed for a track of M views.
@@ -56,6 +56,8 @@ __host__ __device__ inline int feature_lds_doubles(int M) {
     return R2 * 6 + R2 * 3 + 3 * C6 + 3 * C6 + R2 * ldE + (R2 + 1) * ldS + M /*slots as doubles*/ + 8;
 }
 
+// RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
+template <int RMAX>
 __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int f = blockIdx.x;
@@ -72,6 +74,8 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
     double* sS = sE + R2 * ldE;            // [R2+1][ldS]
     int* sSlot = reinterpret_cast<int*>(sS + (R2 + 1) * ldS);   // [M]
 
+    long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.stamps) tq[0] = wall_clock64();
     // ---------------- K1: one measurement row per lane -----------------------
     double res = 0.0, a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, h0 = 0, h1 = 0, h2 = 0;
     const int view = lane >> 1;
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
         }
     }
 
+    if (p.stamps) tq[1] = wall_clock64();
     // ---------------- K2: column-pivoted Householder QR of H_f ---------------
     // After step k the lane k holds R_kk; rows >= rank span the left null space.
     double vv0 = 0, vv1 = 0, vv2 = 0;       // this lane's row of V
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
     }
     __syncthreads();
 
+    if (p.stamps) tq[2] = wall_clock64();
     // ---------------- K4: write the compact block [H_o | r_o] ----------------
     const int q = R2 - rank;
     {
@@ -238,16 +244,25 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
         }
     }
 
+    if (p.stamps) tq[3] = wall_clock64();
     // ---------------- K3: gate ------------------------------------------------
     // pass 1, lanes over columns c of P_sub: E = D P_sub (block rows) and ZP = Z P_sub
     for (int c = lane; c < C6; c += 64) {
         const int colg = 15 + 6 * sSlot[c / 6] + (c % 6);
         double zp0 = 0, zp1 = 0, zp2 = 0;
-        for (int vw = 0; vw < M; ++vw) {
-            const double* prow = p.P + (size_t)(15 + 6 * sSlot[vw]) * p.ldp + colg;
-            double pv[6];
+        double pv[6], pn[6];
+        {
+            const double* prow = p.P + (size_t)(15 + 6 * sSlot[0]) * p.ldp + colg;
 #pragma unroll
             for (int a = 0; a < 6; ++a) pv[a] = prow[(size_t)a * p.ldp];
+        }
+        for (int vw = 0; vw < M; ++vw) {
+            // prefetch the next 6 rows of this P_sub column while the current ones are consumed
+            if (vw + 1 < M) {
+                const double* prow = p.P + (size_t)(15 + 6 * sSlot[vw + 1]) * p.ldp + colg;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pn[a] = prow[(size_t)a * p.ldp];
+            }
             double e0 = 0, e1 = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -260,6 +275,8 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
             }
             sE[(2 * vw) * ldE + c] = e0;
             sE[(2 * vw + 1) * ldE + c] = e1;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) pv[a] = pn[a];
         }
         sZP[c] = zp0; sZP[C6 + c] = zp1; sZP[2 * C6 + c] = zp2;
         // E -= V ZP  (same column, all rows)
@@ -268,6 +285,7 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
         }
     }
     __syncthreads();
+    if (p.stamps) tq[4] = wall_clock64();
     // pass 2, lanes over rows: S[L][L'] = E[L,:] . H_o[L',:]
     if (lane < R2) {
         double ez0 = 0, ez1 = 0, ez2 = 0;
@@ -289,26 +307,43 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
     }
     if (lane == 0) sS[R2 * ldS + R2] = 0.0;
     __syncthreads();
-    // elimination over rows/cols rank..R2-1; the extra row R2 ends with -gamma in the corner
+    if (p.stamps) tq[5] = wall_clock64();
+    // elimination over rows/cols rank..R2-1 with one matrix row per lane in REGISTERS (pivot row
+    // entries travel by v_readlane, no LDS round trip per step); the extra row R2 ends with
+    // -gamma in the corner
+    double srow[RMAX];
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) srow[j] = (j <= R2 && lane <= R2) ? sS[lane * ldS + j] : 0.0;
     int bad = 0;
-    for (int k = rank; k < R2; ++k) {
-        const double piv = sS[k * ldS + k];
-        if (!(piv > 0.0)) { bad = 1; break; }
-        if (lane > k && lane <= R2) {
-            const double l = sS[lane * ldS + k] / piv;
-            for (int j = k + 1; j <= R2; ++j) sS[lane * ldS + j] -= l * sS[k * ldS + j];
+#pragma unroll
+    for (int k = 0; k < RMAX - 1; ++k) {
+        if (k >= rank && k < R2 && !bad) {
+            const double piv = readlane_d(srow[k], k);
+            if (!(piv > 0.0)) {
+                bad = 1;
+            } else {
+                const double l = (lane > k) ? srow[k] * fast_rcp(piv) : 0.0;
+#pragma unroll
+                for (int j = k + 1; j < RMAX; ++j)
+                    if (j <= R2) srow[j] = fma(-l, readlane_d(srow[j], k), srow[j]);
+            }
         }
-        __syncthreads();
     }
-    const double gam = -sS[R2 * ldS + R2];
+    double gam = 0.0;
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j)
+        if (j == R2) gam = -readlane_d(srow[j], R2);
+    if (p.stamps) tq[6] = wall_clock64();
     bool ok = (q >= 1) && (bad == 0) && (q < p.n_chi2);
     if (ok) ok = (gam <= p.chi2[q]);
     if (lane == 0) {
         p.rank[f] = rank;
         p.gamma[f] = gam;
-        p.accepted[f] = ok ? 1 : 0;
-        if (ok) { atomicAdd(&p.counters[0], 1); atomicAdd(&p.counters[1], q); }
-        if (bad) atomicAdd(&p.counters[2], 1);
+        // 1 accepted, 0 rejected by the gate, 2 rejected because the gate matrix was not SPD.
+        // (No global counters: 2000 workgroups adding to one word serialise at ~13 ns each and
+        // were 50 us of this kernel; the host sums the per-feature results instead.)
+        p.accepted[f] = ok ? 1 : (bad ? 2 : 0);
+        if (p.stamps) { tq[7] = wall_clock64(); for (int i = 0; i < 8; ++i) p.stamps[8 * f + i] = tq[i]; }
     }
 }
 

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(T) void k_fold_g(FoldArgs p) {
         int rows;
         if (nd.kind == 0) {
             const int f = nd.src_begin + i;
-            rows = p.accepted[f] ? 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f] : 0;
+            rows = (p.accepted[f] == 1) ? 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f] : 0;
         } else {
             rows = p.nodes[nd.src_begin + 1 + i].w;
         }
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
         int rows;
         if (nd.kind == 0) {
             const int f = nd.src_begin + i;
-            rows = p.accepted[f] ? 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f] : 0;
+            rows = (p.accepted[f] == 1) ? 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f] : 0;
         } else {
             rows = p.nodes[nd.src_begin + 1 + i].w;
         }

@@ -129,7 +129,7 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
                 const std::vector<int>& view_sorted) {
     const int F = c->F, N = c->N;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 160;
-    const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 4;
+    const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 6;
     c->nodes.clear();
     c->levels.clear();
     size_t off = 0;
@@ -251,7 +251,6 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
 }
 
 int launch_feature(msckf_ctx* c) {
-    HIPCHK(c, hipMemsetAsync(c->dCounters.p, 0, 64, c->stream));
     if (c->F == 0) return MSCKF_OK;
     FeatureArgs a{};
     a.F = c->F; a.ldp = c->d;
@@ -265,9 +264,11 @@ int launch_feature(msckf_ctx* c) {
     a.sigma2 = c->sigma * c->sigma;
     a.blk_off = ptr<long long>(c->dBlkOff); a.stack = ptr<double>(c->dStack);
     a.rank = ptr<int>(c->dRank); a.accepted = ptr<unsigned char>(c->dAcc); a.gamma = ptr<double>(c->dGamma);
-    a.counters = ptr<int>(c->dCounters);
+    a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
     const size_t lds = (size_t)feature_lds_doubles(c->Mmax) * 8;
-    hipLaunchKernelGGL(k_feature, dim3(c->F), dim3(64), lds, c->stream, a);
+    if (2 * c->Mmax + 1 <= 24) hipLaunchKernelGGL(k_feature<24>, dim3(c->F), dim3(64), lds, c->stream, a);
+    else if (2 * c->Mmax + 1 <= 32) hipLaunchKernelGGL(k_feature<32>, dim3(c->F), dim3(64), lds, c->stream, a);
+    else hipLaunchKernelGGL(k_feature<64>, dim3(c->F), dim3(64), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -335,6 +336,23 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
     hipLaunchKernelGGL(k_symmetrize, dim3((d + 15) / 16, (d + 15) / 16), dim3(16, 16), 0, c->stream, Pn,
                        ptr<double>(c->dPout), d, d);
     HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+// Gate results of the last run, summed on the host: {accepted, stacked rows, not-SPD gate matrices}.
+int gate_counts(msckf_ctx* c, int out[3], std::vector<unsigned char>* acc_sorted) {
+    out[0] = out[1] = out[2] = 0;
+    if (c->F == 0) return MSCKF_OK;
+    std::vector<unsigned char> acc(c->F);
+    std::vector<int> rk(c->F);
+    HIPCHK(c, hipMemcpyAsync(acc.data(), c->dAcc.p, c->F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(rk.data(), c->dRank.p, (size_t)c->F * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < c->F; ++s) {
+        if (acc[s] == 1) { out[0]++; out[1] += 2 * (c->h_view_sorted[s + 1] - c->h_view_sorted[s]) - rk[s]; }
+        else if (acc[s] == 2) out[2]++;
+    }
+    if (acc_sorted) acc_sorted->swap(acc);
     return MSCKF_OK;
 }
 
@@ -424,8 +442,12 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         LDS_MAX_BYTES - 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<24>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_MAX_BYTES - 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS_MAX_BYTES - 1024);
     const int N = c->maxN, d = 15 + 6 * N, dc = 6 * N;
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
@@ -654,18 +676,17 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_us();
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int counters[16] = {0};
+    int counters[3] = {0, 0, 0};
     int status[4] = {0};
-    HIPCHK(c, hipMemcpy(counters, c->dCounters.p, 64, hipMemcpyDeviceToHost));
+    std::vector<unsigned char> acc_sorted;
+    if (int rc0 = gate_counts(c, counters, &acc_sorted)) return rc0;
     HIPCHK(c, hipMemcpy(status, c->dStatus.p, 16, hipMemcpyDeviceToHost));
-    const int n_acc = (c->acc_override >= 0) ? c->acc_override : ((c->F > 0) ? counters[0] : 0);
+    const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
     const size_t d = c->d;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && status[0] != 0) rc = MSCKF_ERR_NOT_SPD;
     if (accepted && c->F > 0) {
-        std::vector<unsigned char> tmp(c->F);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->dAcc.p, c->F, hipMemcpyDeviceToHost));
-        for (int s = 0; s < c->F; ++s) accepted[c->perm[s]] = tmp[s];
+        for (int s = 0; s < c->F; ++s) accepted[c->perm[s]] = (acc_sorted[s] == 1) ? 1 : 0;
     }
     if (dx) {
         if (rc == MSCKF_OK && c->ran_gain) HIPCHK(c, hipMemcpy(dx, c->dDx.p, d * 8, hipMemcpyDeviceToHost));
@@ -692,10 +713,10 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
 int msckf_commit_covariance(msckf_ctx* c) {
     if (!c || !c->ran || !c->ran_gain) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
-    int counters[16] = {0};
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(counters, c->dCounters.p, 64, hipMemcpyDeviceToHost));
-    if (c->F == 0 || counters[0] == 0) return MSCKF_NOOP;
+    int counters[3] = {0, 0, 0};
+    if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
+    const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
+    if (n_acc == 0) return MSCKF_NOOP;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSCKF_OK;
@@ -746,9 +767,8 @@ int msckf_export_block(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accep
     }
     HIPCHK(c, hipMemcpyAsync(dst, root_block(c), bytes, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                              c->stream));
-    int counters[16] = {0};
-    HIPCHK(c, hipMemcpyAsync(counters, c->dCounters.p, 64, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int counters[3] = {0, 0, 0};
+    if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
     if (n_accepted) *n_accepted = counters[0];
     return MSCKF_OK;
 }
@@ -877,6 +897,11 @@ int msckf_debug_fold_stamps(msckf_ctx* c, long long* out, int32_t max_nodes) {
     if (!out) { return ensure(c, c->dStamps, (size_t)65536 * 8 * 8, true); }
     if (!c->dStamps.p) return MSCKF_ERR_STATE;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (max_nodes < 0) {   // feature-kernel stamps: -max_nodes features
+        const size_t nf = std::min<size_t>((size_t)(-max_nodes), (size_t)c->F);
+        HIPCHK(c, hipMemcpy(out, ptr<long long>(c->dStamps) + 8 * 8192, nf * 64, hipMemcpyDeviceToHost));
+        return (int)nf;
+    }
     const size_t n = std::min<size_t>((size_t)max_nodes, c->nodes.size());
     HIPCHK(c, hipMemcpy(out, c->dStamps.p, n * 64, hipMemcpyDeviceToHost));
     return (int)n;

@@ -34,3 +34,30 @@ for i in list(range(0, 3)) + list(range(n - 4, n)):
     cC, cD = int(fine[i, 1]) >> 32, int(fine[i, 1]) & 0xffffffff
     steps = max(1, int(a[i, 4]))
     print(f"node {i}: w={int(a[i,4])} rows={int(a[i,5])} cycles/step: to-barrier={cA/steps:.0f} vread+sigma={cB/steps:.0f} rsq={cC/steps:.0f} kloop={cD/steps:.0f}  total={(cA+cB+cC+cD)/steps:.0f}")
+
+# feature-kernel phases (100 MHz ticks)
+nf = eng._lib.msckf_debug_fold_stamps(eng._h, buf, -1024)
+fa = np.frombuffer(buf, dtype=np.int64)[:8 * nf].reshape(nf, 8)
+d = np.diff(fa, axis=1) / 100.0
+names = ["K1 rows", "K2 QR+Z", "K4 store", "gate pass1 (E, ZP)", "gate pass2 (S)", "elimination", "epilogue"]
+print("k_feature phases, mean us over", nf, "features:", ", ".join(f"{n}={d[:, i].mean():.1f}" for i, n in enumerate(names)),
+      f" total={(fa[:, 7] - fa[:, 0]).mean() / 100.0:.1f}")
+nf = eng._lib.msckf_debug_fold_stamps(eng._h, buf, -8192)
+fa = np.frombuffer(buf, dtype=np.int64)[:8 * nf].reshape(nf, 8)
+ev = sorted([(int(r[0]), 1) for r in fa] + [(int(r[7]), -1) for r in fa])
+cur = mx = 0
+for _, dlt in ev:
+    cur += dlt; mx = max(mx, cur)
+t0 = fa[:, 0].min()
+print("features", nf, "max concurrent blocks", mx, "first start..last start", (fa[:, 0].max() - t0) / 100.0, "us; last end", (fa[:, 7].max() - t0) / 100.0, "us")
+hist = np.histogram((fa[:, 0] - t0) / 100.0, bins=8)
+print("start-time histogram (us):", [f"{b:.0f}" for b in hist[1]], hist[0].tolist())
+d = np.diff(fa, axis=1) / 100.0
+tot = (fa[:, 7] - fa[:, 0]) / 100.0
+print("per-phase p50 / p95 / max (us):")
+for i, nme in enumerate(names):
+    print(f"  {nme:22s} {np.percentile(d[:, i], 50):6.1f} {np.percentile(d[:, i], 95):6.1f} {d[:, i].max():6.1f}")
+print(f"  {'total':22s} {np.percentile(tot, 50):6.1f} {np.percentile(tot, 95):6.1f} {tot.max():6.1f}")
+order = np.argsort(tot)[-5:]
+print("slowest features:", order.tolist(), "their phases:", np.round(d[order], 1).tolist())
+print("mean total by feature-index decile:", [round(float(tot[i::10].mean()), 1) for i in range(1)], [round(float(tot[k * 200:(k + 1) * 200].mean()), 1) for k in range(10)])
