@@ -612,7 +612,9 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
         // at two wavefronts per SIMD, tools/ubench/step_latency.hip -- not the barrier itself.)
         int roff = jmin * (w + 1) - (jmin * (jmin - 1)) / 2;          // start of R row j in racc
         const int cgw = (t >> 6) * (64 / RL);                         // first column group of this wave
+        unsigned long long cA = 0, cB = 0, cC = 0, cD = 0, c0 = 0, c1 = 0;
         for (int j = jmin; j < w; ++j) {
+            if (p.stamps) c0 = __builtin_amdgcn_s_memtime();
             double* vb = vbuf + (j & 1) * (BMAX + 4);
             // live register rows, in blocks of 4 (uniform over the workgroup)
             const int rb = TRI ? (((nalive[j] + RL - 1) / RL) + 3) >> 2 : RPT / 4;
@@ -631,7 +633,9 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 }
                 if (rq == 0) vb[BMAX] = racc[roff];                  // pivot R_jj
             }
+            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cA += c1 - c0; c0 = c1; }
             __syncthreads();
+            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cB += c1 - c0; c0 = c1; }
             double v[RPT];
             double sg0 = 0.0, sg1 = 0.0, sg2 = 0.0, sg3 = 0.0;
 #pragma unroll
@@ -655,14 +659,16 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 const double ss = fma(x0, x0, sg);
                 double nrm, beta;
                 if (ss > 1e-200 && ss < 1e200) {
-                    nrm = ss * fast_rsqrt(ss);
-                    beta = fast_rcp(nrm * (nrm + fabs(x0)));
+                    const double y = fast_rsqrt(ss);
+                    nrm = fast_norm(ss, y);
+                    beta = y * fast_rcp(nrm + fabs(x0));
                 } else {
                     nrm = sqrt(ss);
                     beta = 1.0 / (nrm * (nrm + fabs(x0)));
                 }
                 const double alpha = (x0 > 0.0) ? -nrm : nrm;
                 const double v0 = x0 - alpha;
+                if (p.stamps) { asm volatile("" :: "v"(beta), "v"(v0)); c1 = __builtin_amdgcn_s_memtime(); cC += c1 - c0; c0 = c1; }
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     // slot k of this wave's groups holds columns cgw + NCG k .. + 64/RL - 1: all retired?
@@ -692,10 +698,15 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 }
                 if (t == 0) racc[roff] = alpha;
             }
+            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cD += c1 - c0; }
             roff += (w + 1) - j;
         }
         __syncthreads();
         if (p.stamps) { const long long tn = wall_clock64(); tk3 += tn - ts0; }
+        if (p.stamps && (t & 63) == 0 && blockIdx.x == 0) {   // per-wave cycle sums of node 0 of this launch
+            long long* o = p.stamps + 8 * 8192 + 8 * 8192 + 4 * (t >> 6);
+            o[0] = (long long)cA; o[1] = (long long)cB; o[2] = (long long)cC; o[3] = (long long)cD;
+        }
     }
 
     // ---- flush R to the node's block (row-major w x (w+1), entries at and right of the diagonal)

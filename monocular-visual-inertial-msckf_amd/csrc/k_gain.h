@@ -236,7 +236,7 @@ __global__ __launch_bounds__(T) void k_chol_blk(CholArgs c) {
             if (!(piv > 0.0)) bad = 1;
             const double di = (piv > 1e-200 && piv < 1e200) ? fast_rsqrt(piv) : 1.0 / sqrt(piv);
             dinv[a] = di;
-            Ld[a][a] = piv * di;
+            Ld[a][a] = fast_norm(piv, di);
 #pragma unroll
             for (int b = a + 1; b < NB; ++b) {
                 double x = Ld[b][a];

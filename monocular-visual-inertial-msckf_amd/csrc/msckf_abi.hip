@@ -897,6 +897,10 @@ int msckf_debug_fold_stamps(msckf_ctx* c, long long* out, int32_t max_nodes) {
     if (!out) { return ensure(c, c->dStamps, (size_t)65536 * 8 * 8, true); }
     if (!c->dStamps.p) return MSCKF_ERR_STATE;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (max_nodes == -1000000) {   // per-wave cycle sums of the last fold launch's first node
+        HIPCHK(c, hipMemcpy(out, ptr<long long>(c->dStamps) + 16 * 8192, 64 * 8, hipMemcpyDeviceToHost));
+        return 64;
+    }
     if (max_nodes < 0) {   // feature-kernel stamps: -max_nodes features
         const size_t nf = std::min<size_t>((size_t)(-max_nodes), (size_t)c->F);
         HIPCHK(c, hipMemcpy(out, ptr<long long>(c->dStamps) + 8 * 8192, nf * 64, hipMemcpyDeviceToHost));

@@ -51,21 +51,23 @@ __device__ __forceinline__ double rowN_sum(double x) {
     else return row8_sum(x);
 }
 
-// 1/sqrt(s) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64, ~2^-26) plus two
-// Newton steps each: ~1 ulp, a short dependent chain instead of the IEEE sqrt/div expansions.
-// Valid for normal, well-scaled arguments (callers fall back to sqrt / division otherwise).
+// 1/sqrt(s) and 1/x from the hardware seeds (v_rsq_f64 / v_rcp_f64, about 2^-26 accurate) plus
+// ONE Newton step each (error ~1.5 e0^2, a few 1e-16): a short dependent chain instead of the
+// IEEE sqrt / division expansions.  Valid for normal, well-scaled arguments (callers fall back
+// to sqrt / division otherwise).  fast_norm() additionally corrects s * rsqrt(s) with the exact
+// residual so the pivot magnitude itself is good to the last bit or two.
 __device__ __forceinline__ double fast_rsqrt(double s) {
-    double y = __builtin_amdgcn_rsq(s);
-    const double h = 0.5 * s;
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    y = fma(y, fma(-h * y, y, 0.5), y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(s);
+    return fma(y, fma(-0.5 * s * y, y, 0.5), y);
 }
 __device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(r, fma(-x, r, 1.0), r);
-    r = fma(r, fma(-x, r, 1.0), r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+// sqrt(s) given y ~ 1/sqrt(s)
+__device__ __forceinline__ double fast_norm(double s, double y) {
+    const double n = s * y;
+    return fma(fma(-n, n, s), 0.5 * y, n);
 }
 
 __device__ __forceinline__ double lane_bcast(double x, int lane) { return readlane_d(x, lane); }
