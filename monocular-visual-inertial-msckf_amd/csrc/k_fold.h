@@ -26,6 +26,10 @@
 #include <hip/hip_runtime.h>
 #include "wave_ops.h"
 
+#ifndef FOLD_ABL
+#define FOLD_ABL 0      // timing ablations (wrong results): 1 no rsqrt chain, 2 no DPP reduce, 4 no update, 8 no v read, 16 no dot
+#endif
+
 namespace msckf {
 
 struct FoldNode {
@@ -415,6 +419,8 @@ __host__ __device__ inline FoldLayoutR fold_layout_r(int w, int bmax, int lds_do
 
 // T threads, RL (8 or 16) row lanes, RPT (multiple of 4) register rows, CPT register columns;
 // TRI: rows come alive progressively (merge of triangles) -> skip dead row blocks.
+template <int KK> struct KTag { static constexpr int value = KK; };
+
 template <int T, int RL, int RPT, int CPT, bool TRI>
 __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
     static_assert(RPT % 4 == 0, "RPT must be a multiple of 4");
@@ -606,107 +612,157 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
         if (p.stamps) { const long long tn = wall_clock64(); tk2 += tn - ts0; ts0 = tn; }
 
         // ---------- elimination: one reflector per column, no global memory ---------
-        // (A one-column lookahead and a dedicated "chain" wavefront were both measured and are
-        // slower on gfx950: the per-column cost is the sum of latency-bound pieces -- LDS round
-        // trip ~150 cycles, a 20-row dot + DPP reduction ~650, rsqrt/rcp chain ~175, update ~160
-        // at two wavefronts per SIMD, tools/ubench/step_latency.hip -- not the barrier itself.)
+        // Reflector j (its rows of v, v0, beta) is formed by the RL lanes that own column j and
+        // published through a double-buffered LDS vector; ONE workgroup barrier per column.
+        // Every step is laid out as  [all LDS reads] -> [math in registers] -> [all LDS writes]:
+        // the R row, the published vector and the accumulator share one address space, so any
+        // read placed after a write costs a full lgkmcnt drain (ablation: an "empty" step with the
+        // reads and writes interleaved per column slot still took 0.7 us of the 1.0 us per column).
         int roff = jmin * (w + 1) - (jmin * (jmin - 1)) / 2;          // start of R row j in racc
         const int cgw = (t >> 6) * (64 / RL);                         // first column group of this wave
-        unsigned long long cA = 0, cB = 0, cC = 0, cD = 0, c0 = 0, c1 = 0;
-        for (int j = jmin; j < w; ++j) {
-            if (p.stamps) c0 = __builtin_amdgcn_s_memtime();
-            double* vb = vbuf + (j & 1) * (BMAX + 4);
-            // live register rows, in blocks of 4 (uniform over the workgroup)
-            const int rb = TRI ? (((nalive[j] + RL - 1) / RL) + 3) >> 2 : RPT / 4;
-            const int kj = j / NCG;
-            if (cg == j - kj * NCG) {
+        constexpr int VB = BMAX + 4;
+        // The pivot column j lives in register slot j / NCG, which changes only every NCG columns:
+        // the column loop is cut into CPT chunks with the slot index a compile-time constant, so
+        // publishing / retiring columns needs no per-slot selects or branches (an "empty" step was
+        // 0.7 us of uniform-branch ladders before this split).
+        auto publish = [&](auto tagk, int jn, double* vbn) {
+            constexpr int KN = decltype(tagk)::value;
+            if constexpr (KN < CPT) {
+                double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
 #pragma unroll
-                for (int k = 0; k < CPT; ++k) {
-                    if (k == kj) {
+                for (int g = 0; g < RPT / 4; ++g) {
+                    q0 = fma(a[4 * g + 0][KN], a[4 * g + 0][KN], q0);
+                    q1 = fma(a[4 * g + 1][KN], a[4 * g + 1][KN], q1);
+                    q2 = fma(a[4 * g + 2][KN], a[4 * g + 2][KN], q2);
+                    q3 = fma(a[4 * g + 3][KN], a[4 * g + 3][KN], q3);
 #pragma unroll
-                        for (int g = 0; g < RPT / 4; ++g)
-                            if (g < rb) {
+                    for (int u = 0; u < 4; ++u) vbn[rq + RL * (4 * g + u)] = a[4 * g + u][KN];
+                }
+                const double sgn = rowN_sum<RL>((q0 + q1) + (q2 + q3));
+                if (rq == 0) vbn[BMAX] = sgn;                          // |column jn|^2 over the batch rows
+            }
+        };
+        auto run_chunk = [&](auto tagk) {
+            constexpr int KK = decltype(tagk)::value;
+            const int jlo = max(jmin, KK * NCG), jhi = min(w, (KK + 1) * NCG);
+            for (int j = jlo; j < jhi; ++j) {
+                const int roff1 = roff + (w + 1) - j;                 // start of R row j+1
+                const double* vb = vbuf + (j & 1) * VB;
+                double* vbn = vbuf + ((j + 1) & 1) * VB;
+                const int jl = j - KK * NCG;                          // pivot's column group
+                // live register rows, in blocks of 4 (uniform over the workgroup)
+                const int rb = TRI ? (((nalive[j] + RL - 1) / RL) + 3) >> 2 : RPT / 4;
+                // ---- read phase -----------------------------------------------------------
+                double v[RPT];
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) vb[rq + RL * (4 * g + u)] = a[4 * g + u][k];
-                            }
+                for (int g = 0; g < RPT / 4; ++g) {
+                    if (g < rb) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[4 * g + u] = vb[rq + RL * (4 * g + u)];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[4 * g + u] = 0.0;
                     }
                 }
-                if (rq == 0) vb[BMAX] = racc[roff];                  // pivot R_jj
-            }
-            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cA += c1 - c0; c0 = c1; }
-            __syncthreads();
-            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cB += c1 - c0; c0 = c1; }
-            double v[RPT];
-            double sg0 = 0.0, sg1 = 0.0, sg2 = 0.0, sg3 = 0.0;
+                const double sg = vb[BMAX];                           // |column j|^2 over the batch rows
+                const double x0 = racc[roff];                         // pivot R_jj
+                double rck[CPT];
+                bool onk[CPT];
 #pragma unroll
-            for (int g = 0; g < RPT / 4; ++g) {
-                if (g < rb) {
-                    v[4 * g + 0] = vb[rq + RL * (4 * g + 0)];
-                    v[4 * g + 1] = vb[rq + RL * (4 * g + 1)];
-                    v[4 * g + 2] = vb[rq + RL * (4 * g + 2)];
-                    v[4 * g + 3] = vb[rq + RL * (4 * g + 3)];
-                    sg0 = fma(v[4 * g + 0], v[4 * g + 0], sg0);
-                    sg1 = fma(v[4 * g + 1], v[4 * g + 1], sg1);
-                    sg2 = fma(v[4 * g + 2], v[4 * g + 2], sg2);
-                    sg3 = fma(v[4 * g + 3], v[4 * g + 3], sg3);
-                } else {
-                    v[4 * g + 0] = 0.0; v[4 * g + 1] = 0.0; v[4 * g + 2] = 0.0; v[4 * g + 3] = 0.0;
+                for (int k = KK; k < CPT; ++k) {
+                    const int c = cg + NCG * k;
+                    onk[k] = (k == KK) ? ((cg > jl) && (c <= w)) : (c <= w);
+                    rck[k] = onk[k] ? racc[roff + (c - j)] : 0.0;
                 }
-            }
-            const double x0 = vb[BMAX];
-            const double sg = rowN_sum<RL>((sg0 + sg1) + (sg2 + sg3));
-            if (sg > 0.0) {
-                const double ss = fma(x0, x0, sg);
-                double nrm, beta;
-                if (ss > 1e-200 && ss < 1e200) {
-                    const double y = fast_rsqrt(ss);
-                    nrm = fast_norm(ss, y);
-                    beta = y * fast_rcp(nrm + fabs(x0));
-                } else {
-                    nrm = sqrt(ss);
-                    beta = 1.0 / (nrm * (nrm + fabs(x0)));
-                }
-                const double alpha = (x0 > 0.0) ? -nrm : nrm;
-                const double v0 = x0 - alpha;
-                if (p.stamps) { asm volatile("" :: "v"(beta), "v"(v0)); c1 = __builtin_amdgcn_s_memtime(); cC += c1 - c0; c0 = c1; }
+                // ---- math -------------------------------------------------------------------
+                double alpha = x0;
+                const bool live = sg > 0.0;                           // uniform: same sigma everywhere
+                if (live) {
+                    const double ss = fma(x0, x0, sg);
+                    double nrm, beta;
+                    if (ss > 1e-200 && ss < 1e200) {
+                        const double y = fast_rsqrt(ss);
+                        nrm = fast_norm(ss, y);
+                        beta = y * fast_rcp(nrm + fabs(x0));
+                    } else {
+                        nrm = sqrt(ss);
+                        beta = 1.0 / (nrm * (nrm + fabs(x0)));
+                    }
+                    alpha = (x0 > 0.0) ? -nrm : nrm;
+                    const double v0 = x0 - alpha;
 #pragma unroll
-                for (int k = 0; k < CPT; ++k) {
-                    // slot k of this wave's groups holds columns cgw + NCG k .. + 64/RL - 1: all retired?
-                    if (cgw + NCG * k + (64 / RL - 1) > j && cgw + NCG * k <= w) {
+                    for (int k = KK; k < CPT; ++k) {
+                        // slot KK: skip when all column groups of this wavefront are retired;
+                        // later slots: skip when they lie beyond the window
+                        const bool any = (k == KK) ? (cgw + (64 / RL - 1) > jl) : true;
+                        if (any && cgw + NCG * k <= w) {
+                            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                            for (int g = 0; g < RPT / 4; ++g)
+                                if (g < rb) {
+                                    s0 = fma(v[4 * g + 0], a[4 * g + 0][k], s0);
+                                    s1 = fma(v[4 * g + 1], a[4 * g + 1][k], s1);
+                                    s2 = fma(v[4 * g + 2], a[4 * g + 2][k], s2);
+                                    s3 = fma(v[4 * g + 3], a[4 * g + 3][k], s3);
+                                }
+                            const double sd = rowN_sum<RL>((s0 + s1) + (s2 + s3));
+                            const double tau = onk[k] ? beta * fma(v0, rck[k], sd) : 0.0;
+                            rck[k] = fma(-tau, v0, rck[k]);
+#pragma unroll
+                            for (int g = 0; g < RPT / 4; ++g)
+                                if (g < rb) {
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u)
+                                        a[4 * g + u][k] = fma(-tau, v[4 * g + u], a[4 * g + u][k]);
+                                }
+                        }
+                    }
+                }
+                // ---- write phase ----------------------------------------------------------
+                if (live) {
+#pragma unroll
+                    for (int k = KK; k < CPT; ++k) {
                         const int c = cg + NCG * k;
-                        const bool on = (c > j) && (c <= w);
-                        const double rc = on ? racc[roff + (c - j)] : 0.0;
-                        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-                        for (int g = 0; g < RPT / 4; ++g)
-                            if (g < rb) {
-                                s0 = fma(v[4 * g + 0], a[4 * g + 0][k], s0);
-                                s1 = fma(v[4 * g + 1], a[4 * g + 1][k], s1);
-                                s2 = fma(v[4 * g + 2], a[4 * g + 2][k], s2);
-                                s3 = fma(v[4 * g + 3], a[4 * g + 3][k], s3);
-                            }
-                        const double s = rowN_sum<RL>((s0 + s1) + (s2 + s3));
-                        const double tau = on ? beta * fma(v0, rc, s) : 0.0;
-                        if (on && rq == 0) racc[roff + (c - j)] = fma(-tau, v0, rc);
-#pragma unroll
-                        for (int g = 0; g < RPT / 4; ++g)
-                            if (g < rb) {
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) a[4 * g + u][k] = fma(-tau, v[4 * g + u], a[4 * g + u][k]);
-                            }
+                        if (onk[k] && rq == 0) racc[roff + (c - j)] = rck[k];
                     }
+                    if (t == 0) racc[roff] = alpha;
                 }
-                if (t == 0) racc[roff] = alpha;
+                // the owners of the next pivot column publish it with its squared norm
+                const int jn = j + 1;
+                if (jn < w) {
+                    if (jl + 1 < NCG) { if (cg == jl + 1) publish(KTag<KK>{}, jn, vbn); }
+                    else { if (cg == 0) publish(KTag<KK + 1>{}, jn, vbn); }
+                }
+                roff = roff1;
+                __syncthreads();
             }
-            if (p.stamps) { c1 = __builtin_amdgcn_s_memtime(); cD += c1 - c0; }
-            roff += (w + 1) - j;
+        };
+        // prologue: the owners of column jmin publish it
+        {
+            const int kn = jmin / NCG;
+            double* vbn = vbuf + (jmin & 1) * VB;
+            if (cg == jmin - kn * NCG) {
+                if (kn == 0) publish(KTag<0>{}, jmin, vbn);
+                if constexpr (CPT > 1) { if (kn == 1) publish(KTag<1>{}, jmin, vbn); }
+                if constexpr (CPT > 2) { if (kn == 2) publish(KTag<2>{}, jmin, vbn); }
+                if constexpr (CPT > 3) { if (kn == 3) publish(KTag<3>{}, jmin, vbn); }
+                if constexpr (CPT > 4) { if (kn == 4) publish(KTag<4>{}, jmin, vbn); }
+                if constexpr (CPT > 5) { if (kn == 5) publish(KTag<5>{}, jmin, vbn); }
+                if constexpr (CPT > 6) { if (kn == 6) publish(KTag<6>{}, jmin, vbn); }
+                if constexpr (CPT > 7) { if (kn == 7) publish(KTag<7>{}, jmin, vbn); }
+            }
         }
         __syncthreads();
+        run_chunk(KTag<0>{});
+        if constexpr (CPT > 1) run_chunk(KTag<1>{});
+        if constexpr (CPT > 2) run_chunk(KTag<2>{});
+        if constexpr (CPT > 3) run_chunk(KTag<3>{});
+        if constexpr (CPT > 4) run_chunk(KTag<4>{});
+        if constexpr (CPT > 5) run_chunk(KTag<5>{});
+        if constexpr (CPT > 6) run_chunk(KTag<6>{});
+        if constexpr (CPT > 7) run_chunk(KTag<7>{});
+        static_assert(CPT <= 8, "add more chunks");
         if (p.stamps) { const long long tn = wall_clock64(); tk3 += tn - ts0; }
-        if (p.stamps && (t & 63) == 0 && blockIdx.x == 0) {   // per-wave cycle sums of node 0 of this launch
-            long long* o = p.stamps + 8 * 8192 + 8 * 8192 + 4 * (t >> 6);
-            o[0] = (long long)cA; o[1] = (long long)cB; o[2] = (long long)cC; o[3] = (long long)cD;
-        }
     }
 
     // ---- flush R to the node's block (row-major w x (w+1), entries at and right of the diagonal)
