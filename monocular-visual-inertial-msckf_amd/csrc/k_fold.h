@@ -410,7 +410,7 @@ __host__ __device__ inline FoldLayoutR fold_layout_r(int w, int bmax, int lds_do
     L.ld = (w + 1) | 1;
     L.vbuf = 0;
     L.ints = 2 * (bmax + 4);            // double-buffered published column
-    const int nints = (FOLD_MAX_SRC + 1) + 8 + 2 * bmax + 16 * 32 + w;
+    const int nints = (FOLD_MAX_SRC + 1) + 8 + 2 * bmax + 16 * 32;
     L.racc = L.ints + (nints + 1) / 2;
     L.panel = L.racc + (w + 1) * (w + 2) / 2;
     L.prow = (lds_doubles - L.panel) / L.ld;
@@ -421,7 +421,7 @@ __host__ __device__ inline FoldLayoutR fold_layout_r(int w, int bmax, int lds_do
 // TRI: rows come alive progressively (merge of triangles) -> skip dead row blocks.
 template <int KK> struct KTag { static constexpr int value = KK; };
 
-template <int T, int RL, int RPT, int CPT, bool TRI>
+template <int T, int RL, int RPT, int CPT>
 __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
     static_assert(RPT % 4 == 0, "RPT must be a multiple of 4");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -442,7 +442,6 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
     int* blead = s_ctl + 8;                                   // [BMAX] leading column of each batch row
     int* bsrc = blead + BMAX;                                 // [BMAX] merge: (child << 20) | child row
     int* slotmap = bsrc + BMAX;                               // [T/64][32] leaf: per-wave clone slots of a track
-    int* nalive = slotmap + 16 * 32;                          // [w] live batch rows per column
     double* racc = smem + lay.racc;                           // packed R accumulator
     double* panel = smem + lay.panel;                         // [prow][ld] leaf staging panel
     const int nracc = (w + 1) * (w + 2) / 2;
@@ -601,12 +600,6 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
             }
         }
         __syncthreads();
-        // live-row count per column: rows are sorted by lead -> binary search
-        for (int j = t; j < w; j += T) {
-            int lo = 0, hi = nb;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (blead[mid] <= j) lo = mid + 1; else hi = mid; }
-            nalive[j] = lo;
-        }
         __syncthreads();
         const int jmin = blead[0];
         if (p.stamps) { const long long tn = wall_clock64(); tk2 += tn - ts0; ts0 = tn; }
@@ -625,7 +618,7 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
         // the column loop is cut into CPT chunks with the slot index a compile-time constant, so
         // publishing / retiring columns needs no per-slot selects or branches (an "empty" step was
         // 0.7 us of uniform-branch ladders before this split).
-        auto publish = [&](auto tagk, int jn, double* vbn) {
+        auto publish = [&](auto tagk, int jn, double* vbn, int roff_n) {
             constexpr int KN = decltype(tagk)::value;
             if constexpr (KN < CPT) {
                 double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
@@ -639,7 +632,10 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                     for (int u = 0; u < 4; ++u) vbn[rq + RL * (4 * g + u)] = a[4 * g + u][KN];
                 }
                 const double sgn = rowN_sum<RL>((q0 + q1) + (q2 + q3));
-                if (rq == 0) vbn[BMAX] = sgn;                          // |column jn|^2 over the batch rows
+                if (rq == 0) {
+                    vbn[BMAX] = sgn;                                   // |column jn|^2 over the batch rows
+                    vbn[BMAX + 1] = racc[roff_n];                      // pivot R[jn][jn] (static until step jn;
+                }                                                      //  thread 0 overwrites it with alpha then)
             }
         };
         auto run_chunk = [&](auto tagk) {
@@ -650,22 +646,13 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 const double* vb = vbuf + (j & 1) * VB;
                 double* vbn = vbuf + ((j + 1) & 1) * VB;
                 const int jl = j - KK * NCG;                          // pivot's column group
-                // live register rows, in blocks of 4 (uniform over the workgroup)
-                const int rb = TRI ? (((nalive[j] + RL - 1) / RL) + 3) >> 2 : RPT / 4;
                 // ---- read phase -----------------------------------------------------------
                 double v[RPT];
 #pragma unroll
-                for (int g = 0; g < RPT / 4; ++g) {
-                    if (g < rb) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v[4 * g + u] = vb[rq + RL * (4 * g + u)];
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v[4 * g + u] = 0.0;
-                    }
-                }
+                for (int r = 0; r < RPT; ++r) v[r] = vb[rq + RL * r];
                 const double sg = vb[BMAX];                           // |column j|^2 over the batch rows
-                const double x0 = racc[roff];                         // pivot R_jj
+                const double x0 = vb[BMAX + 1];                       // pivot R_jj (published: reading racc here
+                                                                      // would race with thread 0 writing alpha)
                 double rck[CPT];
                 bool onk[CPT];
 #pragma unroll
@@ -698,23 +685,17 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                         if (any && cgw + NCG * k <= w) {
                             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-                            for (int g = 0; g < RPT / 4; ++g)
-                                if (g < rb) {
-                                    s0 = fma(v[4 * g + 0], a[4 * g + 0][k], s0);
-                                    s1 = fma(v[4 * g + 1], a[4 * g + 1][k], s1);
-                                    s2 = fma(v[4 * g + 2], a[4 * g + 2][k], s2);
-                                    s3 = fma(v[4 * g + 3], a[4 * g + 3][k], s3);
-                                }
+                            for (int g = 0; g < RPT / 4; ++g) {
+                                s0 = fma(v[4 * g + 0], a[4 * g + 0][k], s0);
+                                s1 = fma(v[4 * g + 1], a[4 * g + 1][k], s1);
+                                s2 = fma(v[4 * g + 2], a[4 * g + 2][k], s2);
+                                s3 = fma(v[4 * g + 3], a[4 * g + 3][k], s3);
+                            }
                             const double sd = rowN_sum<RL>((s0 + s1) + (s2 + s3));
                             const double tau = onk[k] ? beta * fma(v0, rck[k], sd) : 0.0;
                             rck[k] = fma(-tau, v0, rck[k]);
 #pragma unroll
-                            for (int g = 0; g < RPT / 4; ++g)
-                                if (g < rb) {
-#pragma unroll
-                                    for (int u = 0; u < 4; ++u)
-                                        a[4 * g + u][k] = fma(-tau, v[4 * g + u], a[4 * g + u][k]);
-                                }
+                            for (int r = 0; r < RPT; ++r) a[r][k] = fma(-tau, v[r], a[r][k]);
                         }
                     }
                 }
@@ -730,8 +711,8 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 // the owners of the next pivot column publish it with its squared norm
                 const int jn = j + 1;
                 if (jn < w) {
-                    if (jl + 1 < NCG) { if (cg == jl + 1) publish(KTag<KK>{}, jn, vbn); }
-                    else { if (cg == 0) publish(KTag<KK + 1>{}, jn, vbn); }
+                    if (jl + 1 < NCG) { if (cg == jl + 1) publish(KTag<KK>{}, jn, vbn, roff1); }
+                    else { if (cg == 0) publish(KTag<KK + 1>{}, jn, vbn, roff1); }
                 }
                 roff = roff1;
                 __syncthreads();
@@ -742,14 +723,14 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
             const int kn = jmin / NCG;
             double* vbn = vbuf + (jmin & 1) * VB;
             if (cg == jmin - kn * NCG) {
-                if (kn == 0) publish(KTag<0>{}, jmin, vbn);
-                if constexpr (CPT > 1) { if (kn == 1) publish(KTag<1>{}, jmin, vbn); }
-                if constexpr (CPT > 2) { if (kn == 2) publish(KTag<2>{}, jmin, vbn); }
-                if constexpr (CPT > 3) { if (kn == 3) publish(KTag<3>{}, jmin, vbn); }
-                if constexpr (CPT > 4) { if (kn == 4) publish(KTag<4>{}, jmin, vbn); }
-                if constexpr (CPT > 5) { if (kn == 5) publish(KTag<5>{}, jmin, vbn); }
-                if constexpr (CPT > 6) { if (kn == 6) publish(KTag<6>{}, jmin, vbn); }
-                if constexpr (CPT > 7) { if (kn == 7) publish(KTag<7>{}, jmin, vbn); }
+                if (kn == 0) publish(KTag<0>{}, jmin, vbn, roff);
+                if constexpr (CPT > 1) { if (kn == 1) publish(KTag<1>{}, jmin, vbn, roff); }
+                if constexpr (CPT > 2) { if (kn == 2) publish(KTag<2>{}, jmin, vbn, roff); }
+                if constexpr (CPT > 3) { if (kn == 3) publish(KTag<3>{}, jmin, vbn, roff); }
+                if constexpr (CPT > 4) { if (kn == 4) publish(KTag<4>{}, jmin, vbn, roff); }
+                if constexpr (CPT > 5) { if (kn == 5) publish(KTag<5>{}, jmin, vbn, roff); }
+                if constexpr (CPT > 6) { if (kn == 6) publish(KTag<6>{}, jmin, vbn, roff); }
+                if constexpr (CPT > 7) { if (kn == 7) publish(KTag<7>{}, jmin, vbn, roff); }
             }
         }
         __syncthreads();

@@ -225,19 +225,16 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
             const bool leaf = all_nodes[lv.first].kind == 0;
             const bool small = leaf && leaf_rows_max <= FOLD_RL * FOLD_RPT_LEAF;
             const int cls = fold_class(maxw);
-#define FOLD_LAUNCH(RPT, CPT, TRI) \
-    hipLaunchKernelGGL((k_fold<FOLD_T, FOLD_RL, RPT, CPT, TRI>), grid, block, FOLD_LDS_BYTES, c->stream, a)
+#define FOLD_LAUNCH(RPT, CPT) \
+    hipLaunchKernelGGL((k_fold<FOLD_T, FOLD_RL, RPT, CPT>), grid, block, FOLD_LDS_BYTES, c->stream, a)
             if (cls == 1) {
-                if (small) FOLD_LAUNCH(FOLD_RPT_LEAF, FOLD_CPT1, false);
-                else if (leaf) FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT1, false);
-                else FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT1, true);
+                if (small) FOLD_LAUNCH(FOLD_RPT_LEAF, FOLD_CPT1);
+                else FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT1);
             } else if (cls == 2) {
-                if (small) FOLD_LAUNCH(FOLD_RPT_LEAF, FOLD_CPT2, false);
-                else if (leaf) FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT2, false);
-                else FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT2, true);
+                if (small) FOLD_LAUNCH(FOLD_RPT_LEAF, FOLD_CPT2);
+                else FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT2);
             } else {
-                if (leaf) FOLD_LAUNCH(FOLD_RPT_W3, FOLD_CPT3, false);
-                else FOLD_LAUNCH(FOLD_RPT_W3, FOLD_CPT3, true);
+                FOLD_LAUNCH(FOLD_RPT_W3, FOLD_CPT3);
             }
 #undef FOLD_LAUNCH
         } else {                                // wide windows: R streamed through HBM
@@ -420,11 +417,9 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     for (auto& e : c->ev) (void)hipEventCreate(&e);
     // kernels that use more than the default 64 KiB of dynamic LDS
     {
-#define FK(RPT, CPT, TRI) reinterpret_cast<const void*>(&k_fold<FOLD_T, FOLD_RL, RPT, CPT, TRI>)
-        const void* fk[] = {
-            FK(FOLD_RPT_LEAF, FOLD_CPT1, false), FK(FOLD_RPT_BIG, FOLD_CPT1, false), FK(FOLD_RPT_BIG, FOLD_CPT1, true),
-            FK(FOLD_RPT_LEAF, FOLD_CPT2, false), FK(FOLD_RPT_BIG, FOLD_CPT2, false), FK(FOLD_RPT_BIG, FOLD_CPT2, true),
-            FK(FOLD_RPT_W3, FOLD_CPT3, false), FK(FOLD_RPT_W3, FOLD_CPT3, true)};
+#define FK(RPT, CPT) reinterpret_cast<const void*>(&k_fold<FOLD_T, FOLD_RL, RPT, CPT>)
+        const void* fk[] = {FK(FOLD_RPT_LEAF, FOLD_CPT1), FK(FOLD_RPT_BIG, FOLD_CPT1), FK(FOLD_RPT_LEAF, FOLD_CPT2),
+                            FK(FOLD_RPT_BIG, FOLD_CPT2), FK(FOLD_RPT_W3, FOLD_CPT3)};
 #undef FK
         for (const void* f : fk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
     }

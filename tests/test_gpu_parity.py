@@ -81,6 +81,21 @@ def test_resident_path_equals_one_shot(eng):
     assert ms > 0 and len(stages) == 3 and all(s > 0 for s in stages)
 
 
+def test_bitwise_repeatability_stress(eng):
+    """Race screen: the same update 25 times must give bit-identical dx / P+ (the kernels
+    hand data between wavefronts through LDS with one barrier per eliminated column)."""
+    for case in ("cfg2_A", "cfg3_A", "edge_variable_tracks"):
+        prob, ref = load_golden(case)
+        eng.load(prob)
+        eng.run()
+        first = eng.result()
+        assert rel_err(first.dx, ref["dx"]) < TOL
+        for _ in range(24):
+            eng.run()
+            r = eng.result()
+            assert np.array_equal(r.dx, first.dx) and np.array_equal(r.P_new, first.P_new)
+
+
 def test_feature_order_invariance_full_size(eng):
     """Headline size (N=30, F=2000, M=10): dx and P+ do not depend on the order of
     the feature dict nor on the QR tree shape."""
