@@ -47,6 +47,23 @@ def algorithmic_costs(N, F, M):
                 bytes_A=bytes_inputs + bytes_stack, t_roof_s=t_roof, rows=m)
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
+    same command; raw counters, see the note in profiles/*_summary.md).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    tot, calls = 0.0, 0
+    for name, k in d["kernels"].items():
+        if kernel_prefix in name and k["fetch_kb"] is not None and k["write_kb"] is not None:
+            tot += (k["fetch_kb"] + k["write_kb"]) * 1024.0 * k["calls"]
+            calls += k["calls"]
+    return tot / calls if calls else None
+
+
 def cpu_baseline(prob, reps=2):
     """The oracle (NumPy restatement of the reference path) on this box's host
     cores: reference-faithful per-feature Python loop, SVD nullspace, np.linalg.qr,
@@ -197,7 +214,7 @@ def main():
                 "achieved": costs["flops_B"] / (us_qr * 1e-6) / 1e12,
                 "peak": FP64_PEAK_TFLOPS,
                 "frac": costs["flops_B"] / (us_qr * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic("k_fold<"),
                 "flops_per_launch": costs["flops_B"] / n_lv,
                 "avg_launch_us": us_qr / n_lv,
             }

@@ -33,4 +33,11 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
             "which is uncalibrated, so the raw counter is listed.\n")
     if line:
         f.write("\nbench line of the profiled run (profiled runs clock lower than un-profiled ones):\n\n```json\n" + json.dumps(line) + "\n```\n")
+# machine-readable companion used by bench.py for roofline.traffic
+pm = {}
+for r in rows:
+    n = r["Name"].strip('"')
+    pm[n] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1000.0,
+             "fetch_kb": fetch.get(n, (None,))[0], "write_kb": write.get(n, (None,))[0]}
+json.dump({"tag": tag, "kernels": pm, "workload": line.get("config", {}).get("workload")}, open(f"{dst}/{tag}_pmc.json", "w"), indent=1)
 print(open(f"{dst}/{tag}_summary.md").read())
