@@ -241,6 +241,23 @@ out = torch.zeros(prob.d + prob.d ** 2, dtype=torch.float64, device='cuda:0')
 eng.export_result(out.data_ptr(), out.data_ptr() + 8 * prob.d)
 torch.cuda.synchronize()
 assert np.array_equal(out[:prob.d].cpu().numpy(), res.dx)
+# the bench's N>1 data path with 3 shards on one device: blocks gathered in a torch HBM buffer
+from msckf_amd.shard import partition_features
+prob2, ref2 = load_golden('cfg2_B')
+eng2 = UpdateEngine(max_clones=20, max_features=600, max_track=8)
+nb = None; total = 0
+parts = partition_features(prob2.view_ptr, 3)
+gathered = None
+for r, (lo, hi) in enumerate(parts):
+    eng2.load(prob2.subset(lo, hi)); eng2.run_compress()
+    if gathered is None:
+        nb = eng2.block_doubles(); gathered = torch.zeros(3 * nb, dtype=torch.float64, device='cuda:0')
+    _, n = eng2.export_block(dst_ptr=gathered.data_ptr() + 8 * nb * r); total += n
+torch.cuda.synchronize()
+eng2.set_state(prob2)
+eng2.merge_gain(int(gathered.data_ptr()), total, n_blocks=3)
+r2 = eng2.result()
+assert r2.status == 0 and rel_err(r2.dx, ref2['dx']) < 1e-8 and rel_err(r2.P_new, ref2['P_new']) < 1e-8
 print('TORCH_INTEROP_OK')
 """ % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)

@@ -45,7 +45,7 @@ template <int MODE> void run(const char* name, int threads) {
 }
 
 int main() {
-    for (int th : {64, 256, 512}) {
+    for (int th : {64, 256, 512, 1024}) {
         run<0>("dependent v_fma_f64", th);
         run<1>("4 independent v_fma_f64", th);
         run<2>("1 DPP stage (2 mov_dpp + add_f64)", th);
