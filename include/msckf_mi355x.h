@@ -146,6 +146,42 @@ int msckf_get_result(msckf_ctx* ctx, double* dx, double* P_out, uint8_t* accepte
 /* Keep the updated covariance as the state for the next update (P <- P_out on device). */
 int msckf_commit_covariance(msckf_ctx* ctx);
 
+/* ---- f1: feature selection + triangulation in front of the update ---------- *
+ * Replaces MSCKF.get_valid_features (MSCKF.py:458-495): the lost / too-short /
+ * parallax tests, intersection_of_lines (geometry.py:274-303), the re-projection
+ * into the anchor clone (Camera.py:13-52) and the refresh of the inverse-depth
+ * point (geometry.py:61-71).  Candidates are the batch of msckf_set_features
+ * (ALL tracks the caller would pass to get_valid_features, same order);
+ * msckf_set_tracks adds what that function reads besides the views. */
+typedef struct msckf_select_params {
+    int32_t min_frames_lost;        /* MSCKFParameters.min_number_of_frames_to_be_lost   (clamped >= 1, MSCKF.py:119) */
+    int32_t min_frames_tracked;     /* MSCKFParameters.min_number_of_frames_to_be_tracked (clamped >= 2, MSCKF.py:120) */
+    int32_t use_parallax;           /* MSCKFParameters.use_parallax                                       */
+    int32_t width, height;          /* Camera.width / .height (Camera.py:24-25)                           */
+    int32_t reserved;
+    double min_parallax_deg;        /* MSCKFParameters.min_parallax                                       */
+    double K[9];                    /* Camera.K, row-major (Camera.py:20)                                 */
+} msckf_select_params;
+
+#define MSCKF_SEL_VALID 1           /* in valid_features: goes into the update          (MSCKF.py:492) */
+#define MSCKF_SEL_LOST 2            /* in lost_features: the caller removes it afterwards (:468, :493)  */
+#define MSCKF_SEL_REFRESHED 4       /* inverse-depth point was re-estimated              (:484-488)     */
+
+/* Per-view Feature.lines (line_base / line_dir 3*sumM, line_conf sumM; lines[i] belongs to
+ * keypoints[i], MSCKF.py:410) and per-feature lost_for_n_frames / tracked_for_n_frames (F). */
+int msckf_set_tracks(msckf_ctx* ctx, const double* line_base, const double* line_dir,
+                     const double* line_conf, const int32_t* lost_for, const int32_t* tracked_for);
+/* Enqueue the selection kernel (async).  It writes the flags and refreshes the inverse-depth
+ * points in HBM; from then on msckf_run / msckf_run_compress process only the MSCKF_SEL_VALID
+ * features of the batch (the others report accepted = 0 and are not counted as rejected),
+ * until the next msckf_set_features or msckf_clear_selection. */
+int msckf_run_select(msckf_ctx* ctx, const msckf_select_params* params);
+int msckf_clear_selection(msckf_ctx* ctx);
+/* Download the selection (any pointer may be NULL), input order: flags[F], idp_m[F*3] and
+ * idp_rho[F] as they stand after the refresh, world[F*3] = triangulated point (NaN when the
+ * feature was not triangulated; the reference's estimated_world_points, MSCKF.py:489). */
+int msckf_get_selection(msckf_ctx* ctx, uint8_t* flags, double* idp_m, double* idp_rho, double* world);
+
 /* ---- feature-sharded path (one context per GPU / rank) ------------------ *
  * Each rank holds a shard of the features and the full state.  It runs K1-K5
  * locally and exports its compressed block [R | Q^T r]: (6N) x (6N+1) doubles,
@@ -173,6 +209,9 @@ int msckf_debug_compressed(msckf_ctx* ctx, double* T, double* rn);
 /* Diagnostics: out == NULL enables per-node cycle stamps in the fold kernel; otherwise copies
  * 8 int64 per tree node {setup, staging, steps, total (100 MHz ticks), w, rows, -, -}. */
 int msckf_debug_fold_stamps(msckf_ctx* ctx, long long* out, int32_t max_nodes);
+/* Average device time of the selection kernel (HIP events, `iters` re-launches of the last
+ * msckf_run_select; the kernel is idempotent). */
+int msckf_debug_time_select(msckf_ctx* ctx, int32_t iters, float* us_per_launch);
 /* Raw device pointers (as integers) for zero-copy interop: which = 0 dx, 1 P_out, 2 block. */
 uint64_t msckf_device_pointer(msckf_ctx* ctx, int which);
 void* msckf_stream(msckf_ctx* ctx);                     /* hipStream_t of the context */

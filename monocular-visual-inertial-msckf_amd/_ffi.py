@@ -22,6 +22,8 @@ SYMBOLS = [
     "msckf_get_result", "msckf_commit_covariance", "msckf_run_compress", "msckf_block_doubles",
     "msckf_export_block", "msckf_run_merge_gain", "msckf_export_result", "msckf_import_covariance", "msckf_debug_gate", "msckf_debug_compressed", "msckf_debug_fold_stamps",
     "msckf_device_pointer", "msckf_stream",
+    "msckf_set_tracks", "msckf_run_select", "msckf_clear_selection", "msckf_get_selection",
+    "msckf_debug_time_select",
 ]
 
 
@@ -41,6 +43,14 @@ class Stats(C.Structure):
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
 
+
+class SelectParamsC(C.Structure):
+    _fields_ = [("min_frames_lost", C.c_int32), ("min_frames_tracked", C.c_int32), ("use_parallax", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("reserved", C.c_int32),
+                ("min_parallax_deg", C.c_double), ("K", C.c_double * 9)]
+
+
+SEL_VALID, SEL_LOST, SEL_REFRESHED = 1, 2, 4
 
 _lib = None
 
@@ -104,6 +114,16 @@ def load():
     lib.msckf_device_pointer.restype = C.c_uint64
     lib.msckf_stream.argtypes = [vp]
     lib.msckf_stream.restype = vp
+    lib.msckf_set_tracks.argtypes = [vp, _dp, _dp, _dp, _ip, _ip]
+    lib.msckf_set_tracks.restype = C.c_int
+    lib.msckf_run_select.argtypes = [vp, C.POINTER(SelectParamsC)]
+    lib.msckf_run_select.restype = C.c_int
+    lib.msckf_clear_selection.argtypes = [vp]
+    lib.msckf_clear_selection.restype = C.c_int
+    lib.msckf_get_selection.argtypes = [vp, _up, _dp, _dp, _dp]
+    lib.msckf_get_selection.restype = C.c_int
+    lib.msckf_debug_time_select.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
+    lib.msckf_debug_time_select.restype = C.c_int
     _lib = lib
     return lib
 

@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 
 from . import _ffi
-from .synth import UpdateProblem
+from .synth import SelectParams, TrackTable, UpdateProblem
 
 _CHI2 = None
 
@@ -41,7 +41,31 @@ class UpdateResult:
 
     @property
     def n_rejected(self) -> int:
+        """Features that went through the gate and failed it (unselected ones do not count)."""
+        if "n_rejected" in self.stats:
+            return int(self.stats["n_rejected"])
         return int(self.accepted.size - int(self.accepted.sum()))
+
+
+@dataclass
+class Selection:
+    """Outcome of `get_valid_features` (reference `MSCKF.py:458-495`), input order."""
+    flags: np.ndarray        # (F,) uint8: 1 valid, 2 lost, 4 inverse-depth point refreshed
+    idp_m: np.ndarray        # (F, 3) after the refresh
+    idp_rho: np.ndarray      # (F,)
+    world: np.ndarray        # (F, 3) triangulated points, NaN where none
+
+    @property
+    def valid(self) -> np.ndarray:
+        return (self.flags & _ffi.SEL_VALID) > 0
+
+    @property
+    def lost(self) -> np.ndarray:
+        return (self.flags & _ffi.SEL_LOST) > 0
+
+    @property
+    def refreshed(self) -> np.ndarray:
+        return (self.flags & _ffi.SEL_REFRESHED) > 0
 
 
 class UpdateEngine:
@@ -170,6 +194,48 @@ class UpdateEngine:
     def commit_covariance(self) -> int:
         return self._check(self._lib.msckf_commit_covariance(self._h))
 
+    # -- f1: selection + triangulation in front of the update -----------------
+    def set_tracks(self, tracks: TrackTable):
+        """Lines and frame counters of the batch given to `set_features` (same order)."""
+        b, dvec, c = _ffi.f64(tracks.line_base).reshape(-1), _ffi.f64(tracks.line_dir).reshape(-1), _ffi.f64(tracks.line_conf)
+        lo, tr = _ffi.i32(tracks.lost_for), _ffi.i32(tracks.tracked_for)
+        self._check(self._lib.msckf_set_tracks(self._h, _ffi.dptr(b), _ffi.dptr(dvec), _ffi.dptr(c), _ffi.iptr(lo),
+                                               _ffi.iptr(tr)), allow_noop=False)
+
+    def run_select(self, params: SelectParams, K):
+        """Enqueue `get_valid_features` on the device; the following `run()` processes only
+        the valid features, with their inverse-depth points refreshed in HBM."""
+        sp = _ffi.SelectParamsC()
+        sp.min_frames_lost, sp.min_frames_tracked = int(params.min_frames_lost), int(params.min_frames_tracked)
+        sp.use_parallax, sp.width, sp.height = int(bool(params.use_parallax)), int(params.width), int(params.height)
+        sp.min_parallax_deg = float(params.min_parallax_deg)
+        sp.K = (C.c_double * 9)(*np.asarray(K, dtype=np.float64).reshape(9))
+        self._check(self._lib.msckf_run_select(self._h, C.byref(sp)), allow_noop=False)
+
+    def clear_selection(self):
+        self._check(self._lib.msckf_clear_selection(self._h), allow_noop=False)
+
+    def selection(self) -> Selection:
+        F = self._F
+        fl = np.zeros(max(F, 1), dtype=np.uint8)
+        m, rho, w = np.zeros((max(F, 1), 3)), np.zeros(max(F, 1)), np.zeros((max(F, 1), 3))
+        self._check(self._lib.msckf_get_selection(self._h, _ffi.uptr(fl), _ffi.dptr(m), _ffi.dptr(rho), _ffi.dptr(w)),
+                    allow_noop=False)
+        return Selection(fl[:F].copy(), m[:F].copy(), rho[:F].copy(), w[:F].copy())
+
+    def time_select(self, iters: int = 50) -> float:
+        """Average device microseconds of the selection kernel (HIP events)."""
+        us = C.c_float(0)
+        self._check(self._lib.msckf_debug_time_select(self._h, iters, C.byref(us)), allow_noop=False)
+        return float(us.value)
+
+    def select_problem(self, prob: UpdateProblem, tracks: TrackTable, params: SelectParams) -> Selection:
+        """Flat `get_valid_features`: upload, select, download."""
+        self.load(prob)
+        self.set_tracks(tracks)
+        self.run_select(params, prob.K)
+        return self.selection()
+
     # -- sharded path -------------------------------------------------------
     def block_doubles(self) -> int:
         return int(self._lib.msckf_block_doubles(self._h))
@@ -244,3 +310,37 @@ class UpdateEngine:
         filt.state.covariance = res.P_new                                             # MSCKF.py:614 (rebinds)
         inject_state(filt.state, res.dx)                                              # MSCKF.py:616-661
         return 0
+
+    def process_features(self, filt) -> int:
+        """Drop-in for `MSCKF.process_features()` (reference `MSCKF.py:450-456`):
+        `get_valid_features(self.features)` and `update(valid_features)` in one device pass,
+        then `remove_features(lost_features)` through the filter's own method.  Mutates the
+        features' inverse-depth points (`:488`) and the filter like the reference does.
+        Returns 0 updated / 1 no-op."""
+        from .pack import problem_from_reference, select_params_from_reference, tracks_from_reference
+        from .inject import inject_state
+        feats = filt.features
+        if len(feats) == 0:
+            return 1
+        prob = problem_from_reference(filt, feats)
+        self.load(prob)
+        self.set_tracks(tracks_from_reference(feats))
+        self.run_select(select_params_from_reference(filt), prob.K)
+        self.run()
+        sel = self.selection()
+        res = self.result()
+        items = list(feats.items())
+        for j, (_, ft) in enumerate(items):
+            if sel.flags[j] & _ffi.SEL_REFRESHED:                                     # MSCKF.py:488
+                ft.inverse_depth_point.m = sel.idp_m[j].copy()
+                ft.inverse_depth_point.rho = float(sel.idp_rho[j])
+                if hasattr(filt, "estimated_world_points"):
+                    filt.estimated_world_points.append(sel.world[j].copy())           # :489
+        if not sel.valid.any():
+            return 1                                                                  # :454
+        filt.number_of_residuals_discarded_for_gasting_test += res.n_rejected        # :578
+        if res.status == 0:
+            filt.state.covariance = res.P_new                                         # :614
+            inject_state(filt.state, res.dx)                                          # :616-661
+        filt.remove_features({k: ft for j, (k, ft) in enumerate(items) if sel.flags[j] & _ffi.SEL_LOST})   # :456
+        return res.status

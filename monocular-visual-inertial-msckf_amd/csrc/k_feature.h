@@ -44,7 +44,8 @@ struct FeatureArgs {
     const long long* blk_off;    // [F] offset (doubles) of the feature's stack block
     double* stack;               // blocks: column-major (6M+1) columns x 2M rows
     int* rank;                   // [F] rank of H_f (rows < rank are not part of the projection)
-    unsigned char* accepted;     // [F] (sorted order): 1 accepted, 0 gate-rejected, 2 not-SPD
+    unsigned char* accepted;     // [F] (sorted order): 1 accepted, 0 gate-rejected, 2 not-SPD, 3 not selected
+    const unsigned char* select; // optional [F] flags of k_select: features without bit 0 are skipped
     double* gamma;               // [F]
     long long* stamps;           // optional diagnostics (8 per feature), may be null
 };
@@ -74,6 +75,10 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
     double* sS = sE + R2 * ldE;            // [R2+1][ldS]
     int* sSlot = reinterpret_cast<int*>(sS + (R2 + 1) * ldS);   // [M]
 
+    if (p.select && !(p.select[f] & 1)) {      // not in valid_features (MSCKF.py:453-455): no rows, not a rejection
+        if (lane == 0) { p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3; }
+        return;
+    }
     long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (p.stamps) tq[0] = wall_clock64();
     // ---------------- K1: one measurement row per lane -----------------------

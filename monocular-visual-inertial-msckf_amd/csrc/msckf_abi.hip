@@ -16,6 +16,7 @@
 #include "k_feature.h"
 #include "k_fold.h"
 #include "k_gain.h"
+#include "k_select.h"
 
 using namespace msckf;
 
@@ -78,6 +79,7 @@ struct msckf_ctx {
     Buf dP, dPout, dCamR, dCamT, dCamR0, dCamT0, dChi2;
     Buf dViewPtr, dObsUV, dObsSlot, dBase, dMvec, dRho, dFmin, dBlkOff, dStack, dRank, dAcc, dGamma, dCounters;
     Buf dNodes, dRbuf, dStamps;
+    Buf dLineBase, dLineDir, dLineConf, dLostFor, dTrackedFor, dSelFlags, dWorld;   // f1 (k_select)
     Buf dY, dS, dL, dU, dInvd, dK, dB2, dD, dPn, dDx, dCholWork, dStatus;
     // host-side plan
     std::vector<int> perm;                // sorted position -> input index
@@ -93,6 +95,9 @@ struct msckf_ctx {
     float us_stage[3] = {0, 0, 0};
     float us_total = 0;
     std::vector<int> h_view_sorted;
+    std::vector<int> h_view_in;           // view_ptr as the caller gave it (set_tracks permutes with it)
+    bool have_tracks = false, use_select = false;
+    msckf_select_params sel_params{};     // of the last msckf_run_select
 };
 
 namespace {
@@ -261,6 +266,7 @@ int launch_feature(msckf_ctx* c) {
     a.sigma2 = c->sigma * c->sigma;
     a.blk_off = ptr<long long>(c->dBlkOff); a.stack = ptr<double>(c->dStack);
     a.rank = ptr<int>(c->dRank); a.accepted = ptr<unsigned char>(c->dAcc); a.gamma = ptr<double>(c->dGamma);
+    a.select = c->use_select ? ptr<unsigned char>(c->dSelFlags) : nullptr;
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
     const size_t lds = (size_t)feature_lds_doubles(c->Mmax) * 8;
     if (2 * c->Mmax + 1 <= 24) hipLaunchKernelGGL(k_feature<24>, dim3(c->F), dim3(64), lds, c->stream, a);
@@ -336,9 +342,10 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
     return MSCKF_OK;
 }
 
-// Gate results of the last run, summed on the host: {accepted, stacked rows, not-SPD gate matrices}.
-int gate_counts(msckf_ctx* c, int out[3], std::vector<unsigned char>* acc_sorted) {
-    out[0] = out[1] = out[2] = 0;
+// Gate results of the last run, summed on the host:
+// {accepted, stacked rows, not-SPD gate matrices, not selected by k_select}.
+int gate_counts(msckf_ctx* c, int out[4], std::vector<unsigned char>* acc_sorted) {
+    out[0] = out[1] = out[2] = out[3] = 0;
     if (c->F == 0) return MSCKF_OK;
     std::vector<unsigned char> acc(c->F);
     std::vector<int> rk(c->F);
@@ -348,6 +355,7 @@ int gate_counts(msckf_ctx* c, int out[3], std::vector<unsigned char>* acc_sorted
     for (int s = 0; s < c->F; ++s) {
         if (acc[s] == 1) { out[0]++; out[1] += 2 * (c->h_view_sorted[s + 1] - c->h_view_sorted[s]) - rk[s]; }
         else if (acc[s] == 2) out[2]++;
+        else if (acc[s] == 3) out[3]++;
     }
     if (acc_sorted) acc_sorted->swap(acc);
     return MSCKF_OK;
@@ -467,7 +475,8 @@ void msckf_destroy(msckf_ctx* c) {
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
                   &c->dRank, &c->dAcc, &c->dGamma, &c->dCounters, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dY, &c->dS, &c->dL,
-                  &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus};
+                  &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
+                  &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -511,6 +520,8 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const int N = c->N;
     c->F = F;
     c->ran = false;
+    c->have_tracks = false;
+    c->use_select = false;
     if (F == 0) {
         c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->root = -1; c->perm.clear();
         c->have_features = true;
@@ -573,6 +584,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     }
     h_view[F] = pos;
     c->h_view_sorted = h_view;
+    c->h_view_in.assign(view_ptr, view_ptr + F + 1);
     build_plan(c, h_fmin, h_fmax, h_view);
     // room for gathered shard blocks behind the plan's blocks
     c->gather_off = c->rbuf_doubles;
@@ -671,7 +683,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_us();
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int counters[3] = {0, 0, 0};
+    int counters[4] = {0, 0, 0, 0};
     int status[4] = {0};
     std::vector<unsigned char> acc_sorted;
     if (int rc0 = gate_counts(c, counters, &acc_sorted)) return rc0;
@@ -695,7 +707,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     c->us_d2h = (float)(now_us() - t0);
     if (st) {
         std::memset(st, 0, sizeof(*st));
-        st->n_features = c->F; st->n_accepted = n_acc; st->n_rejected = c->F - n_acc;
+        st->n_features = c->F - counters[3]; st->n_accepted = n_acc; st->n_rejected = c->F - counters[3] - n_acc;
         st->stacked_rows = counters[1]; st->not_spd = counters[2];
         st->n_leaves = c->n_leaves; st->n_levels = (int)c->levels.size();
         st->us_total = c->us_total; st->us_feature = c->us_stage[0]; st->us_qr = c->us_stage[1];
@@ -708,7 +720,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
 int msckf_commit_covariance(msckf_ctx* c) {
     if (!c || !c->ran || !c->ran_gain) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
-    int counters[3] = {0, 0, 0};
+    int counters[4] = {0, 0, 0, 0};
     if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
     const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
@@ -746,6 +758,119 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
     return msckf_get_result(c, dx, P_out, accepted, stats);
 }
 
+// ---- f1: get_valid_features -------------------------------------------------
+int msckf_set_tracks(msckf_ctx* c, const double* line_base, const double* line_dir, const double* line_conf,
+                     const int32_t* lost_for, const int32_t* tracked_for) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (!c->have_features) return MSCKF_ERR_STATE;
+    const int F = c->F, sumM = c->sumM;
+    c->have_tracks = false;
+    c->use_select = false;
+    if (F == 0) { c->have_tracks = true; return MSCKF_OK; }
+    if (!line_base || !line_dir || !line_conf || !lost_for || !tracked_for) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<double> hb((size_t)sumM * 3), hd((size_t)sumM * 3), hc(sumM);
+    std::vector<int> hl(F), ht(F);
+    for (int sidx = 0; sidx < F; ++sidx) {                 // same permutation as set_features
+        const int f = c->perm[sidx];
+        const int a = c->h_view_in[f], M = c->h_view_in[f + 1] - a, pos = c->h_view_sorted[sidx];
+        std::memcpy(&hb[(size_t)pos * 3], &line_base[(size_t)a * 3], (size_t)M * 24);
+        std::memcpy(&hd[(size_t)pos * 3], &line_dir[(size_t)a * 3], (size_t)M * 24);
+        std::memcpy(&hc[pos], &line_conf[a], (size_t)M * 8);
+        hl[sidx] = lost_for[f];
+        ht[sidx] = tracked_for[f];
+    }
+    int rc = MSCKF_OK;
+    auto E = [&](Buf& b, size_t bytes) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes); };
+    E(c->dLineBase, (size_t)sumM * 24); E(c->dLineDir, (size_t)sumM * 24); E(c->dLineConf, (size_t)sumM * 8);
+    E(c->dLostFor, (size_t)F * 4); E(c->dTrackedFor, (size_t)F * 4); E(c->dSelFlags, (size_t)F); E(c->dWorld, (size_t)F * 24);
+    if (rc != MSCKF_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dLineBase.p, hb.data(), (size_t)sumM * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dLineDir.p, hd.data(), (size_t)sumM * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dLineConf.p, hc.data(), (size_t)sumM * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dLostFor.p, hl.data(), (size_t)F * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dTrackedFor.p, ht.data(), (size_t)F * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_tracks = true;
+    return MSCKF_OK;
+}
+
+int msckf_run_select(msckf_ctx* c, const msckf_select_params* sp) {
+    if (!c || !sp) return MSCKF_ERR_ARG;
+    if (!c->have_state || !c->have_features || !c->have_tracks) return MSCKF_ERR_STATE;
+    if (sp->width < 1 || sp->height < 1) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->use_select = true;
+    c->ran = false;
+    c->sel_params = *sp;
+    if (c->F == 0) return MSCKF_OK;
+    SelectArgs a{};
+    a.F = c->F;
+    a.view_ptr = ptr<int>(c->dViewPtr); a.obs_slot = ptr<int>(c->dObsSlot);
+    a.line_base = ptr<double>(c->dLineBase); a.line_dir = ptr<double>(c->dLineDir); a.line_conf = ptr<double>(c->dLineConf);
+    a.lost_for = ptr<int>(c->dLostFor); a.tracked_for = ptr<int>(c->dTrackedFor);
+    a.cam_R = ptr<double>(c->dCamR); a.cam_t = ptr<double>(c->dCamT);
+    for (int i = 0; i < 9; ++i) { a.K[i] = sp->K[i]; a.Kinv[i] = c->Kinv[i]; }
+    a.width = sp->width; a.height = sp->height;
+    a.min_lost = std::max(sp->min_frames_lost, 1);          // MSCKF.py:119
+    a.min_tracked = std::max(sp->min_frames_tracked, 2);    // MSCKF.py:120
+    a.use_parallax = sp->use_parallax; a.min_parallax_deg = sp->min_parallax_deg;
+    a.flags = ptr<unsigned char>(c->dSelFlags); a.idp_m = ptr<double>(c->dMvec); a.idp_rho = ptr<double>(c->dRho);
+    a.world = ptr<double>(c->dWorld);
+    hipLaunchKernelGGL(k_select, dim3((c->F * 8 + 255) / 256), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+int msckf_debug_time_select(msckf_ctx* c, int32_t iters, float* us_per_launch) {
+    if (!c || iters < 1 || !us_per_launch) return MSCKF_ERR_ARG;
+    if (!c->use_select) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const msckf_select_params sp = c->sel_params;
+    const bool ran = c->ran;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    for (int i = 0; i < iters; ++i)
+        if (int rc = msckf_run_select(c, &sp)) return rc;       // idempotent: reads lines, rewrites the same outputs
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev[5]));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+    *us_per_launch = ms * 1000.0f / iters;
+    c->ran = ran;                                                // outputs unchanged: results stay valid
+    return MSCKF_OK;
+}
+
+int msckf_clear_selection(msckf_ctx* c) {
+    if (!c) return MSCKF_ERR_ARG;
+    c->use_select = false;
+    c->ran = false;
+    return MSCKF_OK;
+}
+
+int msckf_get_selection(msckf_ctx* c, uint8_t* flags, double* idp_m, double* idp_rho, double* world) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (!c->use_select) return MSCKF_ERR_STATE;
+    const int F = c->F;
+    if (F == 0) return MSCKF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<unsigned char> hf(F);
+    std::vector<double> hm((size_t)F * 3), hr(F), hw((size_t)F * 3);
+    HIPCHK(c, hipMemcpyAsync(hf.data(), c->dSelFlags.p, F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hm.data(), c->dMvec.p, (size_t)F * 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hr.data(), c->dRho.p, (size_t)F * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hw.data(), c->dWorld.p, (size_t)F * 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int s = 0; s < F; ++s) {
+        const int f = c->perm[s];
+        if (flags) flags[f] = hf[s];
+        if (idp_rho) idp_rho[f] = hr[s];
+        if (idp_m) std::memcpy(&idp_m[(size_t)f * 3], &hm[(size_t)s * 3], 24);
+        if (world) std::memcpy(&world[(size_t)f * 3], &hw[(size_t)s * 3], 24);
+    }
+    return MSCKF_OK;
+}
+
 size_t msckf_block_doubles(const msckf_ctx* c) { return c ? (size_t)c->dc * (c->dc + 1) : 0; }
 
 int msckf_export_block(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accepted) {
@@ -762,7 +887,7 @@ int msckf_export_block(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accep
     }
     HIPCHK(c, hipMemcpyAsync(dst, root_block(c), bytes, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                              c->stream));
-    int counters[3] = {0, 0, 0};
+    int counters[4] = {0, 0, 0, 0};
     if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
     if (n_accepted) *n_accepted = counters[0];
     return MSCKF_OK;

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .synth import UpdateProblem
+from .synth import SelectParams, TrackTable, UpdateProblem
 
 
 def problem_from_reference(filt, features) -> UpdateProblem:
@@ -46,3 +46,33 @@ def problem_from_reference(filt, features) -> UpdateProblem:
         obs_uv=np.asarray(uv, dtype=np.float64).reshape(-1, 2), obs_slot=np.asarray(slots, dtype=np.int32),
         idp_base=np.asarray(base, dtype=np.float64).reshape(F, 3), idp_m=np.asarray(m, dtype=np.float64).reshape(F, 3),
         idp_rho=np.asarray(rho, dtype=np.float64), meta={"keys": keys})
+
+
+def tracks_from_reference(features) -> TrackTable:
+    """What `MSCKF.get_valid_features` reads besides the views (reference
+    `MSCKF.py:461-480`): `Feature.lines[i].{base,direction,confidence}` and the frame
+    counters `lost_for_n_frames`, `tracked_for_n_frames`."""
+    base, direction, conf, lost, tracked = [], [], [], [], []
+    for ft in features.values():
+        if len(ft.lines) != len(ft.keypoints):
+            raise ValueError("a feature needs one line per view (reference MSCKF.py:410, :765-769)")
+        for ln in ft.lines:
+            base.append(np.asarray(ln.base, dtype=np.float64).reshape(3))
+            direction.append(np.asarray(ln.direction, dtype=np.float64).reshape(3))
+            conf.append(float(ln.confidence))
+        lost.append(int(ft.lost_for_n_frames))
+        tracked.append(int(ft.tracked_for_n_frames))
+    return TrackTable(line_base=np.asarray(base, dtype=np.float64).reshape(-1, 3),
+                      line_dir=np.asarray(direction, dtype=np.float64).reshape(-1, 3),
+                      line_conf=np.asarray(conf, dtype=np.float64), lost_for=np.asarray(lost, dtype=np.int32),
+                      tracked_for=np.asarray(tracked, dtype=np.int32))
+
+
+def select_params_from_reference(filt) -> SelectParams:
+    """The filter attributes `get_valid_features` reads (`MSCKF.py:114-120`; image size from the
+    cameras, `Camera.py:24-25`)."""
+    cam = next(iter(filt.state.cameras.values()))
+    return SelectParams(min_frames_lost=int(filt.min_number_of_frames_to_be_lost),
+                        min_frames_tracked=int(filt.min_number_of_frames_to_be_tracked),
+                        use_parallax=bool(filt.use_parallax), min_parallax_deg=float(filt.min_parallax),
+                        width=int(cam.width), height=int(cam.height))

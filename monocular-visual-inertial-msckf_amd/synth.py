@@ -59,6 +59,22 @@ class UpdateProblem:
     def d(self) -> int:
         return 15 + 6 * self.N
 
+    def take(self, idx) -> "UpdateProblem":
+        """The features `idx` (any order, e.g. the ones `get_valid_features` selected) with the
+        shared state kept; optional replacement inverse-depth points go in afterwards."""
+        idx = np.asarray(idx, dtype=np.int64)
+        lens = (self.view_ptr[1:] - self.view_ptr[:-1])[idx]
+        vp = np.zeros(len(idx) + 1, dtype=np.int32)
+        vp[1:] = np.cumsum(lens)
+        rows = np.concatenate([np.arange(self.view_ptr[j], self.view_ptr[j + 1]) for j in idx]) if len(idx) \
+            else np.zeros(0, dtype=np.int64)
+        return UpdateProblem(
+            P=self.P, cam_R=self.cam_R, cam_t=self.cam_t, cam_R0=self.cam_R0, cam_t0=self.cam_t0,
+            gravity=self.gravity, K=self.K, sigma=self.sigma, view_ptr=vp,
+            obs_uv=self.obs_uv[rows].reshape(-1, 2), obs_slot=self.obs_slot[rows].astype(np.int32),
+            idp_base=self.idp_base[idx].reshape(-1, 3), idp_m=self.idp_m[idx].reshape(-1, 3),
+            idp_rho=self.idp_rho[idx], meta=dict(self.meta, take=idx))
+
     def subset(self, lo: int, hi: int) -> "UpdateProblem":
         """Contiguous feature shard [lo, hi) with the shared state (P, poses) kept."""
         a, b = int(self.view_ptr[lo]), int(self.view_ptr[hi])
@@ -69,6 +85,56 @@ class UpdateProblem:
             obs_uv=self.obs_uv[a:b], obs_slot=self.obs_slot[a:b],
             idp_base=self.idp_base[lo:hi], idp_m=self.idp_m[lo:hi], idp_rho=self.idp_rho[lo:hi],
             meta=dict(self.meta, shard=(lo, hi)))
+
+
+@dataclass
+class SelectParams:
+    """The `MSCKFParameters` fields `MSCKF.get_valid_features` reads (reference
+    `src/msckf/MSCKF.py:24-25, 39-44` defaults)."""
+
+    min_frames_lost: int = 1          # min_number_of_frames_to_be_lost
+    min_frames_tracked: int = 5       # min_number_of_frames_to_be_tracked
+    use_parallax: bool = True
+    min_parallax_deg: float = 20.0
+    width: int = WIDTH
+    height: int = HEIGHT
+
+
+@dataclass
+class TrackTable:
+    """Per-view `Feature.lines` and per-feature frame counters, aligned with an
+    `UpdateProblem`'s CSR (`Feature.lines[i]` belongs to `Feature.keypoints[i]`,
+    reference `MSCKF.py:305, 410, 430, 765-769`)."""
+
+    line_base: np.ndarray     # (sum M, 3) Line.base  (camera position when the view was added)
+    line_dir: np.ndarray      # (sum M, 3) Line.direction (world bearing, not normalised)
+    line_conf: np.ndarray     # (sum M,)   Line.confidence (match score)
+    lost_for: np.ndarray      # (F,) int32 Feature.lost_for_n_frames
+    tracked_for: np.ndarray   # (F,) int32 Feature.tracked_for_n_frames
+
+
+def make_tracks(prob: UpdateProblem, seed: int = 0, *, lost_fraction: float = 0.5,
+                pose_jitter: float = 0.005, flip_fraction: float = 0.0) -> TrackTable:
+    """Seeded lines and counters for `prob`'s tracks: every view's line starts at the
+    clone position (plus a small jitter: the reference stores the pose the view was
+    added with, `MSCKF.py:410`) along R K^-1 [u, v, 1]; `flip_fraction` of the features
+    get their bearings in reversed view order, so that the lines cross behind the cameras."""
+    rng = np.random.default_rng(5000 + seed)
+    Kinv = np.linalg.inv(np.asarray(prob.K, dtype=np.float64))
+    n = int(prob.view_ptr[-1])
+    uv1 = np.concatenate([prob.obs_uv, np.ones((n, 1))], axis=1)
+    dirs = np.einsum("nij,nj->ni", prob.cam_R[prob.obs_slot], uv1 @ Kinv.T)
+    base = prob.cam_t[prob.obs_slot] + pose_jitter * rng.standard_normal((n, 3))
+    conf = rng.uniform(0.2, 1.0, n)
+    F = prob.F
+    lens = prob.view_ptr[1:] - prob.view_ptr[:-1]
+    lost = np.where(rng.uniform(size=F) < lost_fraction, rng.integers(1, 4, F), 0).astype(np.int32)
+    tracked = np.maximum(1, lens + rng.integers(-2, 3, F)).astype(np.int32)    # views get pruned with their clones
+    flip = rng.uniform(size=F) < flip_fraction
+    for j in np.nonzero(flip)[0]:
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        dirs[a:b] = dirs[a:b][::-1].copy()
+    return TrackTable(line_base=base, line_dir=dirs, line_conf=conf, lost_for=lost, tracked_for=tracked)
 
 
 def so3_exp(w: np.ndarray) -> np.ndarray:

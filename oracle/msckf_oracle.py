@@ -2,7 +2,8 @@
 
 This file is a plain NumPy/SciPy restatement of the reference algorithm
 (`/root/reference/src/msckf/MSCKF.py:497-661`, `src/msckf/Camera.py:38-67`,
-`src/utils/geometry.py:222-235`).  Only `tests/`, `__graft_entry__.smoke()` and
+`src/utils/geometry.py:222-235`) and of the step before it, `get_valid_features`
+(`MSCKF.py:458-495`, `geometry.py:237-303`, `Camera.py:13-52`).  Only `tests/`, `__graft_entry__.smoke()` and
 `bench.py`'s `cpu_baseline` leg may import it; the product path
 (`monocular-visual-inertial-msckf_amd/`) never does and fails loudly when the
 HIP library is missing.
@@ -146,6 +147,79 @@ def update(prob, dense_noise: bool = False):
     Pn = (Pn + Pn.T) / 2                                     # :614
     out.update(status=0, dx=dx, P_new=Pn, T_H=T_H, r_n=r_n, H_X=H_X, r_o=r_o)
     return out
+
+
+# ---- f1: MSCKF.get_valid_features (the step before update) ------------------------------------
+FLAG_VALID, FLAG_LOST, FLAG_REFRESHED = 1, 2, 4
+
+
+def angle_between_directions(d1, d2):
+    """reference `src/utils/geometry.py:237-256`."""
+    d1 = d1 / np.linalg.norm(d1)
+    d2 = d2 / np.linalg.norm(d2)
+    return np.arccos(np.clip(np.dot(d1, d2), -1.0, 1.0))
+
+
+def intersection_of_lines(base, direction, conf):
+    """Weighted least-squares meeting point of lines, reference `geometry.py:274-303`."""
+    X = np.zeros((3, 3))
+    y = np.zeros(3)
+    for b, dvec, c in zip(base, direction, conf):
+        dn = dvec / np.linalg.norm(dvec)                    # :291
+        Pm = np.eye(3) - np.outer(dn, dn)                   # :294
+        X += c * Pm                                         # :296
+        y += c * Pm @ b                                     # :297
+    return np.linalg.pinv(X) @ y, X                         # :299
+
+
+def select_features(prob, tracks, params):
+    """`MSCKF.get_valid_features` (`MSCKF.py:458-495`) on the flat arrays.  Returns flags
+    (bit 0 valid, bit 1 lost, bit 2 inverse-depth point refreshed), the inverse-depth points
+    after the call, the triangulated world points (NaN where none was computed) and cond(X)."""
+    F = prob.F
+    K = np.asarray(prob.K, dtype=np.float64)
+    Kinv = np.linalg.inv(K)
+    min_lost = max(int(params.min_frames_lost), 1)          # the constructor's clamps, MSCKF.py:119
+    min_tracked = max(int(params.min_frames_tracked), 2)    # :120
+    flags = np.zeros(F, dtype=np.uint8)
+    idp_m, idp_rho = prob.idp_m.copy(), prob.idp_rho.copy()
+    world = np.full((F, 3), np.nan)
+    cond = np.ones(F)
+    for j in range(F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        lost = tracks.lost_for[j] >= min_lost                       # :463-465
+        if lost and tracks.tracked_for[j] < min_tracked:            # :467-469
+            flags[j] = FLAG_LOST
+            continue
+        enough = False
+        if params.use_parallax and b - a > 1:                                     # :472
+            par = np.rad2deg(angle_between_directions(tracks.line_dir[a], tracks.line_dir[b - 1]))
+            enough = par > params.min_parallax_deg                                # :475-477
+        if not (lost or enough):                                                  # :479
+            continue
+        Wp, X = intersection_of_lines(tracks.line_base[a:b], tracks.line_dir[a:b], tracks.line_conf[a:b])
+        world[j] = Wp
+        sv = np.linalg.svd(X, compute_uv=False)
+        cond[j] = sv[0] / max(sv[-1], 1e-300)
+        s = int(prob.obs_slot[a])                                                 # camera_indices[0], :481
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = prob.cam_R[s], prob.cam_t[s]
+        Ti = np.linalg.inv(T)                                                     # geometry.py:35-37
+        Cp = Ti[:3, :3] @ Wp + Ti[:3, 3]                                          # Camera.py:46-52
+        flags[j] = FLAG_VALID | (FLAG_LOST if lost else 0)                        # :492-493
+        if Cp[2] <= 0:                                                            # Camera.py:18
+            continue
+        im = K @ Cp
+        im = im[:2] / im[2]                                                       # Camera.py:20-21
+        if im[0] < 0 or im[0] >= params.width or im[1] < 0 or im[1] >= params.height:   # :24-26
+            continue
+        Wv = prob.cam_R[s] @ (Kinv @ np.append(im, 1.0))                          # MSCKF.py:486-487
+        idp_rho[j] = 1.0 / Cp[2]                                                  # geometry.py:61-62
+        theta = np.arctan2(Wv[0], Wv[2])                                          # geometry.py:64-67
+        phi = np.arctan2(-Wv[1], np.sqrt(Wv[0] ** 2 + Wv[2] ** 2))
+        idp_m[j] = [np.cos(phi) * np.sin(theta), -np.sin(phi), np.cos(phi) * np.cos(theta)]
+        flags[j] |= FLAG_REFRESHED
+    return dict(flags=flags, idp_m=idp_m, idp_rho=idp_rho, world=world, cond=cond)
 
 
 def so3_correction(R, dtheta):

@@ -16,8 +16,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
-def golden_cases():
+def _fixture_names():
     return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def golden_cases():
+    """Fixtures of the update path (MSCKF.update)."""
+    return [n for n in _fixture_names() if not n.startswith("sel_")]
+
+
+def select_cases():
+    """Fixtures of get_valid_features + the chained update."""
+    return [n for n in _fixture_names() if n.startswith("sel_")]
+
+
+def load_golden_select(name):
+    """Returns (UpdateProblem, TrackTable, SelectParams, dict of expected outputs)."""
+    from msckf_amd import synth
+    prob, z = load_golden(name)
+    tracks = synth.TrackTable(line_base=z["line_base"], line_dir=z["line_dir"], line_conf=z["line_conf"],
+                              lost_for=z["lost_for"], tracked_for=z["tracked_for"])
+    sp = z["select_params"]
+    params = synth.SelectParams(min_frames_lost=int(sp[0]), min_frames_tracked=int(sp[1]), use_parallax=bool(sp[2]),
+                                min_parallax_deg=float(sp[3]), width=int(sp[4]), height=int(sp[5]))
+    return prob, tracks, params, z
 
 
 def load_golden(name):

@@ -45,7 +45,7 @@ from src.msckf.MSCKF import MSCKF, MSCKFParameters  # noqa: E402
 from src.msckf.Camera import Camera  # noqa: E402
 from src.msckf.FeatureExtractor import Feature  # noqa: E402
 from src.msckf.IMU import IMUMeasurement  # noqa: E402
-from src.utils.geometry import Isometry3D, InverseDepthPoint  # noqa: E402
+from src.utils.geometry import Isometry3D, InverseDepthPoint, Line  # noqa: E402
 
 import scipy  # noqa: E402
 from scipy.stats import chi2  # noqa: E402
@@ -171,6 +171,95 @@ def run_reference(prob, keys=None, imu_seed=0):
     return out
 
 
+def run_reference_select(prob, tracks, sp, keys=None):
+    """f1: build the reference's Feature objects (with lines and frame counters), call the
+    reference's `get_valid_features`, then `update(valid_features)` as `process_features` does
+    (`MSCKF.py:450-456`).  Returns the selection outputs and the chained update outputs."""
+    N, F = prob.N, prob.F
+    params = MSCKFParameters()
+    params.K = prob.K
+    params.sigma_image = prob.sigma
+    params.W_gravity = prob.gravity.copy()
+    params.width, params.height = sp.width, sp.height
+    params.use_parallax = sp.use_parallax
+    params.min_parallax = sp.min_parallax_deg
+    params.min_number_of_frames_to_be_lost = sp.min_frames_lost
+    params.min_number_of_frames_to_be_tracked = sp.min_frames_tracked
+    f = MSCKF(params)
+    if keys is None:
+        keys = [10 * (i + 1) for i in range(N)]
+    for i, k in enumerate(keys):
+        f.state.cameras[k] = Camera(prob.K, sp.width, sp.height, Isometry3D(prob.cam_R[i].copy(), prob.cam_t[i].copy()))
+    f.state.covariance = prob.P.copy()
+    feats = {}
+    for j in range(F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        ft = Feature()
+        ft.keypoints = [prob.obs_uv[i].copy() for i in range(a, b)]
+        ft.camera_indices = [keys[int(prob.obs_slot[i])] for i in range(a, b)]
+        ft.lines = [Line(tracks.line_base[i].copy(), tracks.line_dir[i].copy(), float(tracks.line_conf[i]))
+                    for i in range(a, b)]
+        ft.lost_for_n_frames = int(tracks.lost_for[j])
+        ft.tracked_for_n_frames = int(tracks.tracked_for[j])
+        idp = InverseDepthPoint()
+        idp.base = prob.idp_base[j].copy()
+        idp.m = prob.idp_m[j].copy()
+        idp.rho = float(prob.idp_rho[j])
+        ft.inverse_depth_point = idp
+        feats[100 + j] = ft
+    f.estimated_world_points = []
+    f.currently_processed_world_points = []
+    valid, lost = f.get_valid_features(feats)
+    flags = np.zeros(F, dtype=np.uint8)
+    idp_m = np.stack([feats[100 + j].inverse_depth_point.m for j in range(F)])
+    idp_rho = np.array([feats[100 + j].inverse_depth_point.rho for j in range(F)])
+    for j in range(F):
+        k = 100 + j
+        refreshed = not (np.array_equal(idp_m[j], prob.idp_m[j]) and idp_rho[j] == prob.idp_rho[j])
+        flags[j] = (1 if k in valid else 0) | (2 if k in lost else 0) | (4 if refreshed else 0)
+    world = np.full((F, 3), np.nan)
+    refreshed_idx = [j for j in range(F) if flags[j] & 4]
+    assert len(refreshed_idx) == len(f.estimated_world_points)
+    for j, w in zip(refreshed_idx, f.estimated_world_points):      # appended in dict order, MSCKF.py:489
+        world[j] = w
+    captured = {}
+    orig_correct = f.correct
+
+    def wrapped(Kg, T_H, R_n, delta_x):
+        captured["dx"] = np.array(delta_x).flatten()
+        return orig_correct(Kg, T_H, R_n, delta_x)
+
+    f.correct = wrapped
+    rej0 = f.number_of_residuals_discarded_for_gasting_test
+    if len(valid) > 0:
+        f.update(valid)
+    d = prob.d
+    return dict(sel_flags=flags, sel_idp_m=idp_m, sel_idp_rho=idp_rho, sel_world=world,
+                status=np.int32(0 if "dx" in captured else 1), dx=captured.get("dx", np.zeros(d)),
+                P_new=f.state.covariance.copy(),
+                n_rejected=np.int32(f.number_of_residuals_discarded_for_gasting_test - rej0))
+
+
+def save_select(name, prob, tracks, sp, out):
+    arrays = dict(
+        P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
+        gravity=prob.gravity, K=prob.K, sigma=np.float64(prob.sigma), view_ptr=prob.view_ptr,
+        obs_uv=prob.obs_uv, obs_slot=prob.obs_slot, idp_base=prob.idp_base, idp_m=prob.idp_m,
+        idp_rho=prob.idp_rho,
+        line_base=tracks.line_base, line_dir=tracks.line_dir, line_conf=tracks.line_conf,
+        lost_for=tracks.lost_for, tracked_for=tracks.tracked_for,
+        select_params=np.array([sp.min_frames_lost, sp.min_frames_tracked, int(sp.use_parallax),
+                                sp.min_parallax_deg, sp.width, sp.height], dtype=np.float64),
+        versions=np.array([np.__version__, scipy.__version__, sys.version.split()[0]]))
+    arrays.update(out)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    fl = out["sel_flags"]
+    print(f"{name:28s} N={prob.N:3d} F={prob.F:5d} valid={int((fl & 1).sum()):4d} lost={int(((fl & 2) > 0).sum()):4d} "
+          f"refreshed={int(((fl & 4) > 0).sum()):4d} status={int(out['status'])} rejected={int(out['n_rejected'])} "
+          f"size={os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
 def save(name, prob, out):
     arrays = dict(
         P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
@@ -224,6 +313,33 @@ def main():
         prob, keys = mk()
         out = run_reference(prob, keys)
         save(name, prob, out)
+
+    # f1: get_valid_features (+ the chained update), SURVEY.md §8(f1)
+    SP = synth.SelectParams
+    sel_cases = {}
+    sel_cases["sel_default"] = lambda: (synth.make_problem(12, 150, 8, seed=20), dict(seed=20), SP(), None)
+    sel_cases["sel_parallax5"] = lambda: (synth.make_problem(20, 400, 10, seed=21, outlier_fraction=0.1, outlier_px=400.0), dict(seed=21, lost_fraction=0.3),
+                                          SP(min_parallax_deg=5.0), None)
+    sel_cases["sel_no_parallax"] = lambda: (synth.make_problem(10, 80, 6, seed=22), dict(seed=22), SP(use_parallax=False), None)
+    sel_cases["sel_behind_camera"] = lambda: (synth.make_problem(10, 80, 6, seed=23), dict(seed=23, flip_fraction=0.3),
+                                              SP(min_parallax_deg=2.0, min_frames_tracked=3), None)
+    sel_cases["sel_variable_tracks"] = lambda: (synth.make_problem(12, 120, 12, seed=24, variable_tracks=True, min_track=1),
+                                                dict(seed=24, lost_fraction=0.8), SP(min_frames_tracked=1), None)
+    sel_cases["sel_none_valid"] = lambda: (synth.make_problem(8, 30, 5, seed=25), dict(seed=25, lost_fraction=0.0), SP(), None)
+    sel_cases["sel_small_image"] = lambda: (synth.make_problem(10, 100, 6, seed=26), dict(seed=26, lost_fraction=0.9),
+                                            SP(min_frames_tracked=2, width=330, height=250), None)
+
+    def sel_recipe_b():
+        P, cam_R, cam_t, keys = realistic_state(15, 27)
+        prob = synth.make_problem(15, 200, 8, seed=27, P=P, poses=(cam_R, cam_t))
+        return prob, dict(seed=27), SP(min_parallax_deg=4.0), keys
+    sel_cases["sel_recipe_B"] = sel_recipe_b
+    for name, mk in sel_cases.items():
+        if args.only and name != args.only:
+            continue
+        prob, tk, sp, keys = mk()
+        tracks = synth.make_tracks(prob, **tk)
+        save_select(name, prob, tracks, sp, run_reference_select(prob, tracks, sp, keys))
 
     if not args.only:
         table = np.array([0.0] + [chi2.ppf(0.95, k) for k in range(1, 513)])

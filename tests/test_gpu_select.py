@@ -1,0 +1,168 @@
+"""Parity of f1: the device `get_valid_features` (k_select) and the fused
+select -> update pass, called through the C-ABI, against the fixtures captured from the
+reference's own `get_valid_features` + `update`, and against the oracle on seeded problems.
+
+Tolerances: flags bit-exact; inverse-depth points and triangulated points within
+200 eps cond(X) relative (floor 1e-12) (the 3x3 normal matrix X of `intersection_of_lines` is solved by
+pinv in both, forward error ~ eps cond) and never looser than 1e-8; dx and P+ of the chained
+update within 1e-8 relative (BASELINE.json north_star)."""
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from conftest import load_golden_select, rel_err, select_cases
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from msckf_amd.api import UpdateEngine
+    e = UpdateEngine(max_clones=31, max_features=12000, max_track=31)
+    yield e
+    e.close()
+
+
+def check_selection(sel, exp_flags, exp_m, exp_rho, exp_world, cond):
+    assert np.array_equal(sel.flags, exp_flags)
+    tol = np.minimum(np.maximum(200 * EPS * cond, 1e-12), TOL)
+    ref_mask = (exp_flags & 4) > 0
+    assert np.all(np.abs(sel.idp_rho - exp_rho) <= tol * np.abs(exp_rho))
+    assert np.all(np.abs(sel.idp_m - exp_m).max(axis=1) <= tol)
+    scale = np.maximum(np.linalg.norm(exp_world[ref_mask], axis=1), 1.0)
+    assert np.all(np.linalg.norm(sel.world[ref_mask] - exp_world[ref_mask], axis=1) <= tol[ref_mask] * scale)
+    # features that were not refreshed keep their inverse-depth point bit for bit
+    keep = ~ref_mask
+    assert np.array_equal(sel.idp_rho[keep], exp_rho[keep]) and np.array_equal(sel.idp_m[keep], exp_m[keep])
+
+
+@pytest.mark.parametrize("case", select_cases())
+def test_select_and_chained_update_match_reference(eng, case):
+    from oracle import msckf_oracle as oracle
+    prob, tracks, params, ref = load_golden_select(case)
+    cond = oracle.select_features(prob, tracks, params)["cond"]
+    eng.load(prob)
+    eng.set_tracks(tracks)
+    eng.run_select(params, prob.K)
+    eng.run()
+    sel = eng.selection()
+    check_selection(sel, ref["sel_flags"], ref["sel_idp_m"], ref["sel_idp_rho"], ref["sel_world"], cond)
+    res = eng.result()
+    assert res.status == int(ref["status"])
+    assert res.n_rejected == int(ref["n_rejected"])
+    assert not res.accepted[~sel.valid].any()
+    if res.status == 0:
+        assert rel_err(res.dx, ref["dx"]) < TOL
+        assert rel_err(res.P_new, ref["P_new"]) < TOL
+    else:
+        assert np.array_equal(res.P_new, prob.P) and not res.dx.any()
+
+
+@pytest.mark.parametrize("N,F,M,seed,pk,tk,sp", [
+    (30, 2000, 10, 41, {}, {"lost_fraction": 0.4}, {"min_parallax_deg": 8.0}),                 # headline size
+    (30, 10000, 10, 42, {"outlier_fraction": 0.05}, {"lost_fraction": 0.2}, {"min_parallax_deg": 12.0}),
+    (16, 600, 16, 43, {"variable_tracks": True, "min_track": 1}, {"lost_fraction": 0.7, "flip_fraction": 0.2},
+     {"min_frames_tracked": 3, "min_parallax_deg": 3.0, "width": 400, "height": 300}),
+    (31, 200, 31, 44, {}, {"lost_fraction": 1.0}, {"use_parallax": False}),                   # 31 lines per feature
+])
+def test_select_against_oracle(eng, N, F, M, seed, pk, tk, sp):
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=seed, **pk)
+    tracks = synth.make_tracks(prob, seed, **tk)
+    params = synth.SelectParams(**sp)
+    exp = oracle.select_features(prob, tracks, params)
+    eng.load(prob)
+    eng.set_tracks(tracks)
+    eng.run_select(params, prob.K)
+    eng.run()
+    sel = eng.selection()
+    check_selection(sel, exp["flags"], exp["idp_m"], exp["idp_rho"], exp["world"], exp["cond"])
+    res = eng.result()
+    assert 0.0 < eng.time_select(5) < 1000.0           # re-launching is idempotent ...
+    again = eng.selection()
+    assert np.array_equal(again.flags, sel.flags) and np.array_equal(again.idp_rho, sel.idp_rho)
+    valid = np.nonzero(exp["flags"] & 1)[0]
+    chained = prob.take(valid)
+    chained.idp_m, chained.idp_rho = exp["idp_m"][valid], exp["idp_rho"][valid]
+    out = oracle.update(chained)
+    assert res.status == out["status"] and res.n_rejected == out["n_rejected"]
+    assert np.array_equal(res.accepted[valid], out["accepted"])
+    assert rel_err(res.dx, out["dx"]) < TOL and rel_err(res.P_new, out["P_new"]) < TOL
+
+
+def test_fused_pass_equals_two_calls(eng):
+    """select -> run on the full batch == update_problem on the valid subset with refreshed points."""
+    prob, tracks, params, _ = load_golden_select("sel_parallax5")
+    sel = eng.select_problem(prob, tracks, params)
+    eng.run()
+    fused = eng.result()
+    valid = np.nonzero(sel.valid)[0]
+    two = prob.take(valid)
+    two.idp_m, two.idp_rho = sel.idp_m[valid], sel.idp_rho[valid]
+    sep = eng.update_problem(two)
+    assert np.array_equal(fused.accepted[valid], sep.accepted)
+    assert rel_err(fused.dx, sep.dx) < 1e-11 and rel_err(fused.P_new, sep.P_new) < 1e-12
+
+
+def test_clear_selection_and_call_order(eng):
+    from msckf_amd import _ffi
+    prob, tracks, params, _ = load_golden_select("sel_default")
+    eng.load(prob)
+    with pytest.raises(_ffi.EngineError) as e:
+        eng.run_select(params, prob.K)                  # no tracks uploaded for this batch
+    assert e.value.code == _ffi.ERR_STATE
+    eng.set_tracks(tracks)
+    eng.run_select(params, prob.K)
+    eng.run()
+    n_sel = int(eng.result().stats["n_features"])
+    assert n_sel == int(eng.selection().valid.sum()) < prob.F
+    eng.clear_selection()
+    eng.run()
+    assert int(eng.result().stats["n_features"]) == prob.F
+    eng.set_features(prob)                              # a new batch drops the tracks and the selection
+    with pytest.raises(_ffi.EngineError):
+        eng.selection()
+
+
+def test_process_features_on_reference_shaped_objects(eng):
+    """`UpdateEngine.process_features(filt)` mutates reference-shaped objects the way
+    MSCKF.process_features does (MSCKF.py:450-456): refreshed inverse-depth points, covariance,
+    counter, and lost features handed to the filter's own remove_features."""
+    prob, tracks, params, ref = load_golden_select("sel_variable_tracks")
+    keys = [5 * (i + 2) for i in range(prob.N)]
+    cams = OrderedDict()
+    for i, k in enumerate(keys):
+        pose = SimpleNamespace(R=prob.cam_R[i].copy(), t=prob.cam_t[i].copy())
+        cams[k] = SimpleNamespace(T_W_Ci=pose, T_W_Ci_null=pose, width=params.width, height=params.height)
+    imu = SimpleNamespace(W_gravity=prob.gravity.copy(), T_W_Ii=SimpleNamespace(R=np.eye(3), t=np.zeros(3)),
+                          v_W_Ii=np.zeros(3), gyroscope_bias=np.zeros(3), accelerometer_bias=np.zeros(3))
+    feats = OrderedDict()
+    for j in range(prob.F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        feats[300 + j] = SimpleNamespace(
+            keypoints=[prob.obs_uv[i].copy() for i in range(a, b)],
+            camera_indices=[keys[int(prob.obs_slot[i])] for i in range(a, b)],
+            lines=[SimpleNamespace(base=tracks.line_base[i], direction=tracks.line_dir[i], confidence=tracks.line_conf[i])
+                   for i in range(a, b)],
+            lost_for_n_frames=int(tracks.lost_for[j]), tracked_for_n_frames=int(tracks.tracked_for[j]),
+            inverse_depth_point=SimpleNamespace(base=prob.idp_base[j].copy(), m=prob.idp_m[j].copy(),
+                                                rho=float(prob.idp_rho[j])))
+    removed = {}
+    filt = SimpleNamespace(
+        state=SimpleNamespace(cameras=cams, covariance=prob.P.copy(), imu=imu), K=prob.K, sigma_image=prob.sigma,
+        features=feats, number_of_residuals_discarded_for_gasting_test=0, estimated_world_points=[],
+        min_number_of_frames_to_be_lost=params.min_frames_lost, min_number_of_frames_to_be_tracked=max(params.min_frames_tracked, 2),
+        use_parallax=params.use_parallax, min_parallax=params.min_parallax_deg, remove_features=removed.update)
+    assert eng.process_features(filt) == int(ref["status"])
+    assert rel_err(filt.state.covariance, ref["P_new"]) < TOL
+    assert filt.number_of_residuals_discarded_for_gasting_test == int(ref["n_rejected"])
+    assert sorted(removed) == [300 + j for j in np.nonzero(ref["sel_flags"] & 2)[0]]
+    assert len(filt.estimated_world_points) == int(((ref["sel_flags"] & 4) > 0).sum())
+    rho = np.array([ft.inverse_depth_point.rho for ft in feats.values()])
+    np.testing.assert_allclose(rho, ref["sel_idp_rho"], rtol=1e-8)

@@ -99,3 +99,50 @@ def test_subset_shares_state():
     s = p.subset(10, 25)
     assert s.F == 15 and s.view_ptr[0] == 0 and s.P is p.P
     assert np.array_equal(s.obs_uv, p.obs_uv[p.view_ptr[10]:p.view_ptr[25]])
+
+
+def test_take_matches_subset_and_reorders():
+    from msckf_amd import synth
+    prob = synth.make_problem(8, 20, 5, seed=2, variable_tracks=True)
+    a, b = prob.take(np.arange(3, 9)), prob.subset(3, 9)
+    for name in ("view_ptr", "obs_uv", "obs_slot", "idp_base", "idp_m", "idp_rho"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    r = prob.take([7, 2])
+    assert np.array_equal(r.idp_rho, prob.idp_rho[[7, 2]])
+    assert np.array_equal(r.obs_uv[: r.view_ptr[1]], prob.obs_uv[prob.view_ptr[7]:prob.view_ptr[8]])
+    assert prob.take([]).F == 0
+
+
+def test_tracks_pack_roundtrip():
+    """Reference-shaped Feature.lines / counters -> TrackTable (pack.tracks_from_reference)."""
+    from collections import OrderedDict as OD
+    from conftest import load_golden_select
+    from msckf_amd.pack import select_params_from_reference, tracks_from_reference
+    prob, tracks, params, _ = load_golden_select("sel_variable_tracks")
+    feats = OD()
+    for j in range(prob.F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        feats[j] = SimpleNamespace(
+            keypoints=[None] * (b - a),
+            lines=[SimpleNamespace(base=tracks.line_base[i], direction=tracks.line_dir[i].reshape(3, 1),
+                                   confidence=tracks.line_conf[i]) for i in range(a, b)],
+            lost_for_n_frames=int(tracks.lost_for[j]), tracked_for_n_frames=int(tracks.tracked_for[j]))
+    got = tracks_from_reference(feats)
+    for name in ("line_base", "line_dir", "line_conf", "lost_for", "tracked_for"):
+        assert np.array_equal(getattr(got, name), getattr(tracks, name)), name
+    feats[0].lines.pop()
+    with pytest.raises(ValueError):
+        tracks_from_reference(feats)
+    cam = SimpleNamespace(width=320, height=200)
+    filt = SimpleNamespace(state=SimpleNamespace(cameras=OD([(1, cam)])), min_number_of_frames_to_be_lost=1,
+                           min_number_of_frames_to_be_tracked=5, use_parallax=True, min_parallax=20)
+    sp = select_params_from_reference(filt)
+    assert (sp.width, sp.height, sp.min_frames_tracked, sp.min_parallax_deg) == (320, 200, 5, 20.0)
+
+
+def test_make_tracks_is_seeded():
+    from msckf_amd import synth
+    prob = synth.make_problem(8, 20, 5, seed=2)
+    a, b = synth.make_tracks(prob, 3, flip_fraction=0.2), synth.make_tracks(prob, 3, flip_fraction=0.2)
+    assert np.array_equal(a.line_dir, b.line_dir) and np.array_equal(a.lost_for, b.lost_for)
+    assert not np.array_equal(a.line_conf, synth.make_tracks(prob, 4).line_conf)

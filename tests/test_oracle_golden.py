@@ -3,7 +3,7 @@ the reference (tests/golden/gen_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden, rel_err
+from conftest import golden_cases, load_golden, load_golden_select, rel_err, select_cases
 from oracle import msckf_oracle as oracle
 
 FAST = [c for c in golden_cases() if c != "cfg3_A"]
@@ -67,3 +67,25 @@ def test_chi2_table():
     assert t.shape == (513,)
     for k in (1, 2, 7, 17, 27, 61, 256, 512):
         assert abs(t[k] - chi2.ppf(0.95, k)) <= 1e-12 * t[k]
+
+
+@pytest.mark.parametrize("case", select_cases())
+def test_oracle_select_matches_reference(case):
+    """f1: get_valid_features restated vs the reference's own run, then the chained update."""
+    prob, tracks, params, ref = load_golden_select(case)
+    sel = oracle.select_features(prob, tracks, params)
+    assert np.array_equal(sel["flags"], ref["sel_flags"])
+    np.testing.assert_allclose(sel["idp_rho"], ref["sel_idp_rho"], rtol=1e-12)
+    np.testing.assert_allclose(sel["idp_m"], ref["sel_idp_m"], rtol=0, atol=1e-12)
+    got = (sel["flags"] & 4) > 0
+    np.testing.assert_allclose(sel["world"][got], ref["sel_world"][got], rtol=1e-11, atol=1e-11)
+    valid = np.nonzero(sel["flags"] & 1)[0]
+    if len(valid) == 0:
+        assert int(ref["status"]) == 1
+        return
+    chained = prob.take(valid)
+    chained.idp_m, chained.idp_rho = sel["idp_m"][valid], sel["idp_rho"][valid]
+    out = oracle.update(chained)
+    assert out["status"] == int(ref["status"]) and out["n_rejected"] == int(ref["n_rejected"])
+    assert rel_err(out["dx"], ref["dx"]) < 1e-9
+    assert rel_err(out["P_new"], ref["P_new"]) < 1e-11
