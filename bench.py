@@ -233,6 +233,28 @@ def main():
                 e_dx = float(np.linalg.norm(res.dx - ref["dx"]) / np.linalg.norm(ref["dx"]))
                 e_P = float(np.linalg.norm(res.P_new - ref["P_new"]) / np.linalg.norm(ref["P_new"]))
                 line["parity_vs_cpu_baseline"] = {"dx_rel": e_dx, "P_rel": e_P}
+            # f1, reported beside the headline, never inside `value`: the selection +
+            # triangulation kernel on the same tracks, and the fused select -> update pass.
+            tracks = synth.make_tracks(prob, 0, lost_fraction=0.5)
+            sp = synth.SelectParams(min_parallax_deg=8.0)
+            eng.load(prob)
+            eng.set_tracks(tracks)
+            eng.run_select(sp, prob.K)
+            us_sel = eng.time_select(50)
+            for _ in range(3):
+                eng.run_select(sp, prob.K); eng.run()
+            eng.sync()
+            t2 = time.perf_counter()
+            for _ in range(50):
+                eng.run_select(sp, prob.K); eng.run()
+            eng.sync()
+            us_fused = (time.perf_counter() - t2) / 50 * 1e6
+            n_views = int(prob.view_ptr[-1])
+            sel_bytes = n_views * (7 * 8 + 4) + prob.F * (3 * 4 + 1 + 7 * 8)
+            line["select_f1"] = {"kernel": "k_select (get_valid_features)", "us_per_launch": us_sel,
+                                 "candidates": prob.F, "valid": int(eng.selection().valid.sum()),
+                                 "bytes_algorithmic": sel_bytes, "hbm_gbs_algorithmic": sel_bytes / (us_sel * 1e-6) / 1e9,
+                                 "fused_select_update_us": us_fused}
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:
