@@ -182,6 +182,30 @@ int msckf_clear_selection(msckf_ctx* ctx);
  * feature was not triangulated; the reference's estimated_world_points, MSCKF.py:489). */
 int msckf_get_selection(msckf_ctx* ctx, uint8_t* flags, double* idp_m, double* idp_rho, double* world);
 
+/* ---- f2 / f3: the covariance steps either side of the update --------------- *
+ * With these the covariance never leaves HBM between frames: msckf_set_state once
+ * (N = 0 is allowed: the 15x15 IMU prior), then per IMU sample msckf_propagate, per
+ * image msckf_augment -> msckf_set_features [-> msckf_set_tracks / msckf_run_select]
+ * -> msckf_run -> msckf_get_result(dx only) -> msckf_commit_covariance ->
+ * msckf_set_poses (poses after the host's state injection), and msckf_remove_clones
+ * when the window is pruned.  Each call that changes N drops the feature batch. */
+/* Covariance half of MSCKF.process_imu (MSCKF.py:236-244): P_II <- Phi P_II Phi^T + Q,
+ * P_IC <- Phi P_IC, P_CI <- P_IC^T, P <- (P + P^T)/2.  Phi, Q: 15x15 row-major, built by
+ * the host from the IMU state (:179-237; propagation.py does it for the Python mirror). */
+int msckf_propagate(msckf_ctx* ctx, const double* Phi, const double* Q);
+/* MSCKF.state_augmentation (MSCKF.py:250-265): append a clone with pose (R, t) (its null
+ * pose is the same, Camera.py:11) and P <- sym([I; J] P [I; J]^T).  J15 = the 6x15
+ * non-zero part of J (:259-261), row-major. */
+int msckf_augment(msckf_ctx* ctx, const double* J15, const double* R, const double* t);
+/* MSCKF.remove_cameras covariance half (MSCKF.py:751-757): drop the rows/columns and
+ * poses of `n` clones given by their slots (positions at call time, any order). */
+int msckf_remove_clones(msckf_ctx* ctx, int32_t n, const int32_t* slots);
+/* Clone poses after the host applied the state correction (MSCKF.py:642-661). */
+int msckf_set_poses(msckf_ctx* ctx, const double* cam_R, const double* cam_t,
+                    const double* cam_R0, const double* cam_t0);
+/* Download the resident prior covariance (d x d, d = 15 + 6 N) and N; P may be NULL. */
+int msckf_get_covariance(msckf_ctx* ctx, double* P, int32_t* N);
+
 /* ---- feature-sharded path (one context per GPU / rank) ------------------ *
  * Each rank holds a shard of the features and the full state.  It runs K1-K5
  * locally and exports its compressed block [R | Q^T r]: (6N) x (6N+1) doubles,

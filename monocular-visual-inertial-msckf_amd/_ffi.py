@@ -24,6 +24,7 @@ SYMBOLS = [
     "msckf_device_pointer", "msckf_stream",
     "msckf_set_tracks", "msckf_run_select", "msckf_clear_selection", "msckf_get_selection",
     "msckf_debug_time_select",
+    "msckf_propagate", "msckf_augment", "msckf_remove_clones", "msckf_set_poses", "msckf_get_covariance",
 ]
 
 
@@ -122,6 +123,16 @@ def load():
     lib.msckf_clear_selection.restype = C.c_int
     lib.msckf_get_selection.argtypes = [vp, _up, _dp, _dp, _dp]
     lib.msckf_get_selection.restype = C.c_int
+    lib.msckf_propagate.argtypes = [vp, _dp, _dp]
+    lib.msckf_propagate.restype = C.c_int
+    lib.msckf_augment.argtypes = [vp, _dp, _dp, _dp]
+    lib.msckf_augment.restype = C.c_int
+    lib.msckf_remove_clones.argtypes = [vp, C.c_int32, _ip]
+    lib.msckf_remove_clones.restype = C.c_int
+    lib.msckf_set_poses.argtypes = [vp, _dp, _dp, _dp, _dp]
+    lib.msckf_set_poses.restype = C.c_int
+    lib.msckf_get_covariance.argtypes = [vp, _dp, _ip]
+    lib.msckf_get_covariance.restype = C.c_int
     lib.msckf_debug_time_select.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.msckf_debug_time_select.restype = C.c_int
     _lib = lib

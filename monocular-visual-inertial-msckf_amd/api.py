@@ -236,6 +236,70 @@ class UpdateEngine:
         self.run_select(params, prob.K)
         return self.selection()
 
+    # -- f2 / f3: covariance resident in HBM between frames ---------------------
+    def set_prior(self, P, gravity, K, sigma, cam_R=None, cam_t=None, cam_R0=None, cam_t0=None):
+        """Upload the filter state once; N = 0 (the 15x15 IMU prior, no clone yet) is allowed."""
+        P = _ffi.f64(P)
+        N = (P.shape[0] - 15) // 6
+        z9, z3 = np.zeros((0, 3, 3)), np.zeros((0, 3))
+        cam_R = z9 if cam_R is None else cam_R
+        cam_t = z3 if cam_t is None else cam_t
+        prob = UpdateProblem(P=P, cam_R=np.asarray(cam_R, dtype=np.float64).reshape(N, 3, 3),
+                             cam_t=np.asarray(cam_t, dtype=np.float64).reshape(N, 3),
+                             cam_R0=np.asarray(cam_R if cam_R0 is None else cam_R0, dtype=np.float64).reshape(N, 3, 3),
+                             cam_t0=np.asarray(cam_t if cam_t0 is None else cam_t0, dtype=np.float64).reshape(N, 3),
+                             gravity=np.asarray(gravity, dtype=np.float64), K=np.asarray(K), sigma=float(sigma),
+                             view_ptr=np.zeros(1, dtype=np.int32), obs_uv=np.zeros((0, 2)),
+                             obs_slot=np.zeros(0, dtype=np.int32), idp_base=z3, idp_m=z3, idp_rho=np.zeros(0))
+        self.set_state(prob)
+        self._F = 0
+
+    def propagate(self, Phi, Q):
+        """Covariance half of `process_imu` (reference `MSCKF.py:236-244`); async."""
+        a, b = _ffi.f64(Phi).reshape(-1), _ffi.f64(Q).reshape(-1)
+        if a.size != 225 or b.size != 225:
+            raise ValueError("Phi and Q are 15x15")
+        self._check(self._lib.msckf_propagate(self._h, _ffi.dptr(a), _ffi.dptr(b)), allow_noop=False)
+
+    def augment(self, J15, R, t):
+        """`state_augmentation` (reference `MSCKF.py:250-265`): one more clone, P grows by 6."""
+        j, r, tt = _ffi.f64(J15).reshape(-1), _ffi.f64(R).reshape(-1), _ffi.f64(t).reshape(-1)
+        if j.size != 90 or r.size != 9 or tt.size != 3:
+            raise ValueError("J15 is 6x15, R 3x3, t 3")
+        self._check(self._lib.msckf_augment(self._h, _ffi.dptr(j), _ffi.dptr(r), _ffi.dptr(tt)), allow_noop=False)
+        self._N += 1
+        self._F = 0
+
+    def remove_clones(self, slots):
+        """Covariance half of `remove_cameras` (reference `MSCKF.py:751-757`)."""
+        s = _ffi.i32(np.asarray(slots).reshape(-1))
+        self._check(self._lib.msckf_remove_clones(self._h, int(s.size), _ffi.iptr(s)), allow_noop=False)
+        self._N -= int(s.size)
+        self._F = 0
+
+    def set_poses(self, cam_R, cam_t, cam_R0=None, cam_t0=None):
+        """Clone poses after the host's state injection (reference `MSCKF.py:642-661`)."""
+        r, t = _ffi.f64(cam_R).reshape(-1), _ffi.f64(cam_t).reshape(-1)
+        r0 = r if cam_R0 is None else _ffi.f64(cam_R0).reshape(-1)
+        t0 = t if cam_t0 is None else _ffi.f64(cam_t0).reshape(-1)
+        if r.size != 9 * self._N or t.size != 3 * self._N or r0.size != r.size or t0.size != t.size:
+            raise ValueError("pose arrays do not match the number of clones")
+        self._check(self._lib.msckf_set_poses(self._h, _ffi.dptr(r), _ffi.dptr(t), _ffi.dptr(r0), _ffi.dptr(t0)),
+                    allow_noop=False)
+
+    def covariance(self) -> np.ndarray:
+        """The resident prior covariance (d x d)."""
+        n = C.c_int32(0)
+        self._check(self._lib.msckf_get_covariance(self._h, None, C.byref(n)), allow_noop=False)
+        d = 15 + 6 * int(n.value)
+        P = np.zeros((d, d))
+        self._check(self._lib.msckf_get_covariance(self._h, _ffi.dptr(P), C.byref(n)), allow_noop=False)
+        return P
+
+    @property
+    def n_clones(self) -> int:
+        return self._N
+
     # -- sharded path -------------------------------------------------------
     def block_doubles(self) -> int:
         return int(self._lib.msckf_block_doubles(self._h))

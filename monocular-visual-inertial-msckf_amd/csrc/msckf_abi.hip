@@ -17,6 +17,7 @@
 #include "k_fold.h"
 #include "k_gain.h"
 #include "k_select.h"
+#include "k_state.h"
 
 using namespace msckf;
 
@@ -77,7 +78,7 @@ struct msckf_ctx {
     int n_chi2 = 0;
     // device buffers
     Buf dP, dPout, dCamR, dCamT, dCamR0, dCamT0, dChi2;
-    Buf dViewPtr, dObsUV, dObsSlot, dBase, dMvec, dRho, dFmin, dBlkOff, dStack, dRank, dAcc, dGamma, dCounters;
+    Buf dViewPtr, dObsUV, dObsSlot, dBase, dMvec, dRho, dFmin, dBlkOff, dStack, dRank, dAcc, dGamma, dKeep;
     Buf dNodes, dRbuf, dStamps;
     Buf dLineBase, dLineDir, dLineConf, dLostFor, dTrackedFor, dSelFlags, dWorld;   // f1 (k_select)
     Buf dY, dS, dL, dU, dInvd, dK, dB2, dD, dPn, dDx, dCholWork, dStatus;
@@ -98,6 +99,7 @@ struct msckf_ctx {
     std::vector<int> h_view_in;           // view_ptr as the caller gave it (set_tracks permutes with it)
     bool have_tracks = false, use_select = false;
     msckf_select_params sel_params{};     // of the last msckf_run_select
+    std::vector<double> h_cam[4];         // host mirror of cam_R / cam_t / cam_R0 / cam_t0 (clone bookkeeping, f2)
 };
 
 namespace {
@@ -125,6 +127,26 @@ int ensure(msckf_ctx* c, Buf& b, size_t bytes, bool zero = false) {
 
 template <typename Tp>
 Tp* ptr(const Buf& b) { return reinterpret_cast<Tp*>(b.p); }
+
+// clone poses: host mirror -> HBM
+int upload_poses(msckf_ctx* c) {
+    const size_t N = c->h_cam[1].size() / 3;
+    if (N == 0) return MSCKF_OK;
+    HIPCHK(c, hipMemcpyAsync(c->dCamR.p, c->h_cam[0].data(), N * 72, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCamT.p, c->h_cam[1].data(), N * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCamR0.p, c->h_cam[2].data(), N * 72, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dCamT0.p, c->h_cam[3].data(), N * 24, hipMemcpyHostToDevice, c->stream));
+    return MSCKF_OK;
+}
+
+// the clone set changed: feature batch, plan and results of the old layout are void
+void invalidate_batch(msckf_ctx* c) {
+    c->have_features = false;
+    c->have_tracks = false;
+    c->use_select = false;
+    c->ran = false;
+    c->F = 0;
+}
 
 // ---- QR tree plan ---------------------------------------------------------
 // Leaves: consecutive sorted features whose stacked-row bound stays under
@@ -458,7 +480,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     E(c->dCamR, (size_t)N * 9 * 8); E(c->dCamT, (size_t)N * 3 * 8);
     E(c->dCamR0, (size_t)N * 9 * 8); E(c->dCamT0, (size_t)N * 3 * 8);
     E(c->dChi2, 1024 * 8);
-    E(c->dCounters, 64, true); E(c->dStatus, 64, true);
+    E(c->dKeep, (size_t)d * 4); E(c->dStatus, 64, true);                   // dKeep: index map of msckf_remove_clones
     E(c->dY, (size_t)d * dc * 8); E(c->dS, (size_t)dc * dc * 8); E(c->dL, (size_t)dc * dc * 8);
     E(c->dU, (size_t)dc * dc * 8); E(c->dInvd, (size_t)dc * 8); E(c->dK, (size_t)d * dc * 8);
     E(c->dB2, (size_t)d * d * 8); E(c->dD, (size_t)d * dc * 8); E(c->dPn, (size_t)d * d * 8);
@@ -474,7 +496,7 @@ void msckf_destroy(msckf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
-                  &c->dRank, &c->dAcc, &c->dGamma, &c->dCounters, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dY, &c->dS, &c->dL,
+                  &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld};
     for (Buf* b : all) if (b->p) (void)hipFree(b->p);
@@ -486,8 +508,9 @@ void msckf_destroy(msckf_ctx* c) {
 int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, const double* cam_t,
                     const double* cam_R0, const double* cam_t0, const double* gravity, const double* Kinv,
                     double sigma, const double* chi2_crit, int32_t n_crit) {
-    if (!c || !P || !cam_R || !cam_t || !cam_R0 || !cam_t0 || !gravity || !Kinv || !chi2_crit) return MSCKF_ERR_ARG;
-    if (N < 1 || N > c->maxN || n_crit < 2 || n_crit > 1024) return MSCKF_ERR_ARG;
+    if (!c || !P || !gravity || !Kinv || !chi2_crit) return MSCKF_ERR_ARG;
+    if (N < 0 || N > c->maxN || n_crit < 2 || n_crit > 1024) return MSCKF_ERR_ARG;     // N = 0: no clone yet (f2)
+    if (N > 0 && (!cam_R || !cam_t || !cam_R0 || !cam_t0)) return MSCKF_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_us();
     if (N != c->N) c->have_features = false;
@@ -497,10 +520,13 @@ int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_
     std::memcpy(c->Kinv, Kinv, 72);
     const size_t d = c->d;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, P, d * d * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dCamR.p, cam_R, (size_t)N * 72, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dCamT.p, cam_t, (size_t)N * 24, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dCamR0.p, cam_R0, (size_t)N * 72, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dCamT0.p, cam_t0, (size_t)N * 24, hipMemcpyHostToDevice, c->stream));
+    if (N > 0) {
+        c->h_cam[0].assign(cam_R, cam_R + (size_t)N * 9); c->h_cam[1].assign(cam_t, cam_t + (size_t)N * 3);
+        c->h_cam[2].assign(cam_R0, cam_R0 + (size_t)N * 9); c->h_cam[3].assign(cam_t0, cam_t0 + (size_t)N * 3);
+        if (int rcp = upload_poses(c)) return rcp;
+    } else {
+        for (auto& v : c->h_cam) v.clear();
+    }
     HIPCHK(c, hipMemcpyAsync(c->dChi2.p, chi2_crit, (size_t)n_crit * 8, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->us_h2d = (float)(now_us() - t0);
@@ -867,6 +893,108 @@ int msckf_get_selection(msckf_ctx* c, uint8_t* flags, double* idp_m, double* idp
         if (idp_rho) idp_rho[f] = hr[s];
         if (idp_m) std::memcpy(&idp_m[(size_t)f * 3], &hm[(size_t)s * 3], 24);
         if (world) std::memcpy(&world[(size_t)f * 3], &hw[(size_t)s * 3], 24);
+    }
+    return MSCKF_OK;
+}
+
+// ---- f2 / f3: covariance steps either side of the update, P resident in HBM -----
+int msckf_propagate(msckf_ctx* c, const double* Phi, const double* Q) {
+    if (!c || !Phi || !Q) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    PropagateArgs a{};
+    a.P = ptr<double>(c->dP); a.d = c->d;
+    std::memcpy(a.Phi, Phi, sizeof(a.Phi));
+    std::memcpy(a.Q, Q, sizeof(a.Q));
+    const size_t lds = ((size_t)15 * c->d + 225) * 8;
+    hipLaunchKernelGGL(k_propagate, dim3(1), dim3(256), lds, c->stream, a);
+    if (c->d > 15) {
+        const int nb = (c->d - 15 + 15) / 16;
+        hipLaunchKernelGGL(k_symmetrize_tail, dim3(nb, nb), dim3(256), 0, c->stream, ptr<double>(c->dP), c->d, 15);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->ran = false;                       // results of a previous update refer to the old prior
+    return MSCKF_OK;
+}
+
+int msckf_augment(msckf_ctx* c, const double* J15, const double* R, const double* t) {
+    if (!c || !J15 || !R || !t) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    if (c->N + 1 > c->maxN) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    AugmentArgs a{};
+    a.P = ptr<double>(c->dP); a.out = ptr<double>(c->dB2); a.d = c->d;
+    std::memcpy(a.J, J15, sizeof(a.J));
+    const int n = c->d + 6;
+    hipLaunchKernelGGL(k_augment, dim3((n * n + 255) / 256), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    std::swap(c->dP, c->dB2);             // same capacity (d_max^2); dB2 is scratch of the gain stage
+    // the new clone's null pose IS its pose (Camera.py:11)
+    c->h_cam[0].insert(c->h_cam[0].end(), R, R + 9); c->h_cam[1].insert(c->h_cam[1].end(), t, t + 3);
+    c->h_cam[2].insert(c->h_cam[2].end(), R, R + 9); c->h_cam[3].insert(c->h_cam[3].end(), t, t + 3);
+    c->N += 1; c->d = 15 + 6 * c->N; c->dc = 6 * c->N;
+    if (int rc = upload_poses(c)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    invalidate_batch(c);
+    return MSCKF_OK;
+}
+
+int msckf_remove_clones(msckf_ctx* c, int32_t n, const int32_t* slots) {
+    if (!c || n < 0 || (n > 0 && !slots)) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    if (n == 0) return MSCKF_OK;
+    std::vector<char> drop(c->N, 0);
+    for (int i = 0; i < n; ++i) {
+        if (slots[i] < 0 || slots[i] >= c->N || drop[slots[i]]) return MSCKF_ERR_ARG;
+        drop[slots[i]] = 1;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int> keep;
+    for (int i = 0; i < 15; ++i) keep.push_back(i);
+    std::vector<double> nc[4];
+    for (int s = 0; s < c->N; ++s) {
+        if (drop[s]) continue;
+        for (int k = 0; k < 6; ++k) keep.push_back(15 + 6 * s + k);
+        for (int q = 0; q < 4; ++q) {
+            const int w = (q & 1) ? 3 : 9;
+            nc[q].insert(nc[q].end(), c->h_cam[q].begin() + (size_t)s * w, c->h_cam[q].begin() + (size_t)(s + 1) * w);
+        }
+    }
+    const int nn = (int)keep.size();
+    HIPCHK(c, hipMemcpyAsync(c->dKeep.p, keep.data(), (size_t)nn * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_compact, dim3((nn * nn + 255) / 256), dim3(256), 0, c->stream, ptr<double>(c->dP), c->d,
+                       ptr<int>(c->dKeep), nn, ptr<double>(c->dB2));
+    HIPCHK(c, hipGetLastError());
+    std::swap(c->dP, c->dB2);
+    for (int q = 0; q < 4; ++q) c->h_cam[q].swap(nc[q]);
+    c->N -= n; c->d = 15 + 6 * c->N; c->dc = 6 * c->N;
+    if (int rc = upload_poses(c)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    invalidate_batch(c);
+    return MSCKF_OK;
+}
+
+int msckf_set_poses(msckf_ctx* c, const double* cam_R, const double* cam_t, const double* cam_R0, const double* cam_t0) {
+    if (!c || !cam_R || !cam_t || !cam_R0 || !cam_t0) return MSCKF_ERR_ARG;
+    if (!c->have_state || c->N < 1) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->N;
+    c->h_cam[0].assign(cam_R, cam_R + N * 9); c->h_cam[1].assign(cam_t, cam_t + N * 3);
+    c->h_cam[2].assign(cam_R0, cam_R0 + N * 9); c->h_cam[3].assign(cam_t0, cam_t0 + N * 3);
+    if (int rc = upload_poses(c)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ran = false;
+    return MSCKF_OK;
+}
+
+int msckf_get_covariance(msckf_ctx* c, double* P, int32_t* N) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (N) *N = c->N;
+    if (P) {
+        HIPCHK(c, hipMemcpyAsync(P, c->dP.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return MSCKF_OK;
 }

@@ -222,6 +222,85 @@ def select_features(prob, tracks, params):
     return dict(flags=flags, idp_m=idp_m, idp_rho=idp_rho, world=world, cond=cond)
 
 
+# ---- f2 / f3: the covariance steps either side of update -------------------------------------
+def imu_transition(R, t, v, R0, t0, v0, gyro, acc, dt, gravity, w_planet, Qc):
+    """Phi (15x15) and the discrete noise Q of `MSCKF.process_imu` (`MSCKF.py:179-237`).
+    R, t, v are the IMU pose/velocity AFTER `imu.integrate` (:168), R0/t0/v0 the null state,
+    gyro/acc the bias-corrected measurement (:166-167)."""
+    F = np.zeros((15, 15))
+    F[0:3, 0:3] = -skew(gyro)                                                  # :182
+    F[0:3, 3:6] = -np.eye(3)                                                   # :183
+    F[6:9, 0:3] = -R @ skew(acc)                                               # :186
+    F[6:9, 6:9] = -2 * skew(w_planet)                                          # :187
+    F[6:9, 9:12] = -R                                                          # :188
+    F[6:9, 12:15] = -skew(w_planet) @ -skew(w_planet)                          # :189
+    F[12:15, 6:9] = np.eye(3)                                                  # :192
+    G = np.zeros((15, 12))
+    G[0:3, 0:3] = -np.eye(3)                                                   # :203
+    G[3:6, 3:6] = np.eye(3)                                                    # :206
+    G[6:9, 6:9] = -R                                                           # :209
+    G[9:12, 9:12] = np.eye(3)                                                  # :212
+    Fdt = F * dt
+    Fdt2 = Fdt @ Fdt
+    Fdt3 = Fdt2 @ Fdt
+    Phi = np.eye(15) + Fdt + 0.5 * Fdt2 + (1.0 / 6.0) * Fdt3                   # :218
+    Phi[:3, :3] = R @ R0.T                                                     # :221
+    u = R0 @ gravity                                                           # :223
+    sv = u / (u @ u)                                                           # :224
+    A_vel = Phi[6:9, :3].copy()
+    A_pos = Phi[12:15, :3].copy()
+    w1 = skew(v0 - v) @ gravity                                                # :229
+    w2 = skew(dt * v0 + t0 - t) @ gravity                                      # :230
+    Phi[6:9, :3] = A_vel - (A_vel @ u - w1)[:, None] * sv                      # :232
+    Phi[12:15, :3] = A_pos - (A_pos @ u - w2)[:, None] * sv                    # :233
+    Q = Phi @ G @ Qc @ G.T @ Phi.T * dt                                        # :237
+    return Phi, Q
+
+
+def propagate_covariance(P, Phi, Q):
+    """`MSCKF.py:236-244`."""
+    P = P.copy()
+    P[:15, :15] = Phi @ P[:15, :15] @ Phi.T + Q
+    P[:15, 15:] = Phi @ P[:15, 15:]
+    P[15:, :15] = P[:15, 15:].T
+    return (P + P.T) / 2
+
+
+def augmentation_jacobian(imu_R, imu_t, T_W_I_R, T_W_I_t, T_W_C_R, T_W_C_t):
+    """New clone pose and the 6x15 non-zero part of J, `MSCKF.py:252-261`
+    (Isometry3D product/inverse through 4x4 matrices, `geometry.py:31-37`)."""
+    def mat(R, t):
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        return T
+    T_I_C = np.linalg.inv(mat(T_W_I_R, T_W_I_t)) @ mat(T_W_C_R, T_W_C_t)       # :252
+    T_W_Ci = mat(imu_R, imu_t) @ T_I_C                                         # :253
+    J = np.zeros((6, 15))
+    J[:3, :3] = T_I_C[:3, :3].T                                                # :259
+    J[3:6, :3] = skew(imu_R @ T_I_C[:3, 3])                                    # :260
+    J[3:6, 12:15] = np.eye(3)                                                  # :261
+    return J, T_W_Ci[:3, :3], T_W_Ci[:3, 3]
+
+
+def augment_covariance(P, J15):
+    """`MSCKF.py:258-265`."""
+    d = P.shape[0]
+    J = np.zeros((6, d))
+    J[:, :15] = J15
+    M = np.vstack((np.eye(d), J))
+    S = M @ P @ M.T
+    return (S + S.T) / 2
+
+
+def remove_clones_covariance(P, slots):
+    """`MSCKF.remove_cameras` (`MSCKF.py:751-758`); slots are positions in the clone order
+    at call time."""
+    keep = np.ones(P.shape[0], dtype=bool)
+    for s in slots:
+        keep[15 + 6 * s:15 + 6 * (s + 1)] = False
+    return P[np.ix_(keep, keep)]
+
+
 def so3_correction(R, dtheta):
     """R <- R Exp(dtheta)^T followed by the SVD clean-up.
     reference `MSCKF.py:625-635` (IMU) and `:649-660` (clones)."""

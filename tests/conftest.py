@@ -22,12 +22,31 @@ def _fixture_names():
 
 def golden_cases():
     """Fixtures of the update path (MSCKF.update)."""
-    return [n for n in _fixture_names() if not n.startswith("sel_")]
+    return [n for n in _fixture_names() if not n.startswith(("sel_", "seq_"))]
 
 
 def select_cases():
     """Fixtures of get_valid_features + the chained update."""
     return [n for n in _fixture_names() if n.startswith("sel_")]
+
+
+def sequence_cases():
+    """Fixtures of a multi-frame run: process_imu / state_augmentation / update / remove_cameras (f2, f3)."""
+    return [n for n in _fixture_names() if n.startswith("seq_")]
+
+
+def load_sequence(name):
+    """Returns (header dict, list of per-op dicts with key 'kind')."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    kinds = z["op_kind"]
+    ops = [dict(kind=int(k)) for k in kinds]
+    head = {}
+    for key in z.files:
+        if key.startswith("o") and "_" in key and key[1:key.index("_")].isdigit():
+            ops[int(key[1:key.index("_")])][key[key.index("_") + 1:]] = z[key]
+        else:
+            head[key] = z[key]
+    return head, ops
 
 
 def load_golden_select(name):

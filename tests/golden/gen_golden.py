@@ -260,6 +260,107 @@ def save_select(name, prob, tracks, sp, out):
           f"size={os.path.getsize(path) / 1024:.0f} KiB", flush=True)
 
 
+def run_reference_sequence(seed, frames=6, imu_per_frame=8, F=40, M=5, max_clones=6):
+    """f2/f3: a short filter run through the reference's own `process_imu` (x imu_per_frame),
+    `state_augmentation`, `update` and `remove_cameras` (`MSCKF.py:160-265, 570-661, 751-758`),
+    recording what each step reads and the covariance it leaves.  Op kinds: 0 imu, 1 augment,
+    2 update, 3 remove clones."""
+    rng = np.random.default_rng(9000 + seed)
+    params = MSCKFParameters()
+    f = MSCKF(params)
+    imu = f.state.imu
+    imu.is_initialized = True
+    f.first_measurement_arrived = True
+    imu.v_W_Ii = np.array([1.0, 0.1, 0.0])
+    imu.v_W_Ii_null = np.array([1.0, 0.1, 0.0])
+    imu.gyroscope_bias = 1e-3 * rng.standard_normal(3)
+    imu.accelerometer_bias = 1e-2 * rng.standard_normal(3)
+    f.state.covariance = np.diag([1e-4] * 3 + [1e-6] * 3 + [1e-3] * 3 + [1e-5] * 3 + [1e-3] * 3).astype(float)
+    arrays = dict(P0=f.state.covariance.copy(), Qc=f.continuous_noise_covariance.copy(),
+                  T_W_I_R=imu.T_W_I.R.copy(), T_W_I_t=imu.T_W_I.t.copy(),
+                  T_W_C_R=np.array(f.T_W_C.R, dtype=float), T_W_C_t=np.array(f.T_W_C.t, dtype=float),
+                  gravity=np.array(imu.W_gravity, dtype=float), K=np.array(f.K), sigma=np.float64(f.sigma_image))
+    kinds = []
+    snap = {}
+    orig_integrate = imu.integrate
+
+    def integrate(linear_acceleration, angular_velocity, dt):
+        orig_integrate(linear_acceleration=linear_acceleration, angular_velocity=angular_velocity, dt=dt)
+        snap.update(acc=np.array(linear_acceleration), gyro=np.array(angular_velocity), dt=np.float64(dt),
+                    R=imu.T_W_Ii.R.copy(), t=imu.T_W_Ii.t.copy(), v=imu.v_W_Ii.copy(),
+                    R0=imu.T_W_Ii_null.R.copy(), t0=imu.T_W_Ii_null.t.copy(), v0=imu.v_W_Ii_null.copy(),
+                    w_planet=np.array(imu.planet_angular_velocity, dtype=float))
+
+    imu.integrate = integrate
+
+    def put(kind, **kw):
+        i = len(kinds)
+        kinds.append(kind)
+        for k, v in kw.items():
+            arrays[f"o{i}_{k}"] = np.asarray(v)
+
+    tnow = 0.0
+    for frame in range(frames):
+        for _ in range(imu_per_frame):
+            tnow += 0.005
+            R = imu.T_W_Ii.R
+            a_w = np.array([0.4 * np.cos(1.5 * tnow), 0.6 * np.sin(2.0 * tnow), 0.2 * np.sin(1.1 * tnow)])
+            acc = R.T @ (a_w + imu.W_gravity) + 1e-3 * rng.standard_normal(3)
+            gyro = np.array([0.05 * np.sin(tnow), 0.04 * np.cos(0.7 * tnow), 0.1 * np.sin(0.5 * tnow)]) + 1e-4 * rng.standard_normal(3)
+            f.process_imu(IMUMeasurement(tnow, gyro, acc))
+            put(0, **{k: v for k, v in snap.items()}, P_after=f.state.covariance.copy())
+        imu_R, imu_t = imu.T_W_Ii.R.copy(), imu.T_W_Ii.t.copy()
+        f.state_augmentation()
+        new_key = list(f.state.cameras.keys())[-1]
+        cam = f.state.cameras[new_key]
+        put(1, imu_R=imu_R, imu_t=imu_t, cam_R=cam.T_W_Ci.R.copy(), cam_t=cam.T_W_Ci.t.copy(),
+            P_after=f.state.covariance.copy())
+        keys = list(f.state.cameras.keys())
+        N = len(keys)
+        if N >= 3:
+            cam_R = np.stack([f.state.cameras[k].T_W_Ci.R for k in keys])
+            cam_t = np.stack([f.state.cameras[k].T_W_Ci.t for k in keys])
+            prob = synth.make_problem(N, F, min(M, N), seed=100 * seed + frame, P=f.state.covariance.copy(),
+                                      poses=(cam_R, cam_t), variable_tracks=True, min_track=2)
+            feats = {}
+            for j in range(prob.F):
+                a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+                ft = Feature()
+                ft.keypoints = [prob.obs_uv[i].copy() for i in range(a, b)]
+                ft.camera_indices = [keys[int(prob.obs_slot[i])] for i in range(a, b)]
+                idp = InverseDepthPoint()
+                idp.base, idp.m, idp.rho = prob.idp_base[j].copy(), prob.idp_m[j].copy(), float(prob.idp_rho[j])
+                ft.inverse_depth_point = idp
+                feats[j] = ft
+            pre = dict(imu_R=imu.T_W_Ii.R.copy(), imu_t=imu.T_W_Ii.t.copy(), imu_v=imu.v_W_Ii.copy(),
+                       imu_bg=imu.gyroscope_bias.copy(), imu_ba=imu.accelerometer_bias.copy())
+            cap = {}
+            orig_correct = f.correct
+
+            def wrapped(Kg, T_H, R_n, delta_x, _cap=cap, _oc=orig_correct):
+                _cap["dx"] = np.array(delta_x).flatten()
+                return _oc(Kg, T_H, R_n, delta_x)
+
+            f.correct = wrapped
+            f.update(feats)
+            f.correct = orig_correct
+            put(2, view_ptr=prob.view_ptr, obs_uv=prob.obs_uv, obs_slot=prob.obs_slot, idp_base=prob.idp_base,
+                idp_m=prob.idp_m, idp_rho=prob.idp_rho, cam_R=cam_R, cam_t=cam_t, dx=cap.get("dx", np.zeros(15 + 6 * N)),
+                status=np.int32(0 if "dx" in cap else 1), P_after=f.state.covariance.copy(),
+                post_cam_R=np.stack([f.state.cameras[k].T_W_Ci.R for k in keys]),
+                post_cam_t=np.stack([f.state.cameras[k].T_W_Ci.t for k in keys]),
+                post_imu_R=imu.T_W_Ii.R.copy(), post_imu_t=imu.T_W_Ii.t.copy(), post_imu_v=imu.v_W_Ii.copy(),
+                post_imu_bg=imu.gyroscope_bias.copy(), post_imu_ba=imu.accelerometer_bias.copy(), **pre)
+        if N > max_clones:
+            drop = [keys[1], keys[3]]                       # two non-adjacent clones, as prune_* would pick
+            slots = [1, 3]
+            f.remove_cameras({k: f.state.cameras[k] for k in drop})
+            put(3, slots=np.array(slots, dtype=np.int32), P_after=f.state.covariance.copy())
+    arrays["op_kind"] = np.array(kinds, dtype=np.int32)
+    arrays["versions"] = np.array([np.__version__, scipy.__version__, sys.version.split()[0]])
+    return arrays
+
+
 def save(name, prob, out):
     arrays = dict(
         P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
@@ -334,6 +435,17 @@ def main():
         prob = synth.make_problem(15, 200, 8, seed=27, P=P, poses=(cam_R, cam_t))
         return prob, dict(seed=27), SP(min_parallax_deg=4.0), keys
     sel_cases["sel_recipe_B"] = sel_recipe_b
+    for name, kw in {"seq_short": dict(seed=1, frames=5, imu_per_frame=6, F=30, M=4, max_clones=4),
+                     "seq_long": dict(seed=2, frames=12, imu_per_frame=8, F=60, M=6, max_clones=8)}.items():
+        if args.only and name != args.only:
+            continue
+        arrays = run_reference_sequence(**kw)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        k = arrays["op_kind"]
+        print(f"{name:28s} ops={len(k)} imu={int((k == 0).sum())} augment={int((k == 1).sum())} "
+              f"update={int((k == 2).sum())} remove={int((k == 3).sum())} size={os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
     for name, mk in sel_cases.items():
         if args.only and name != args.only:
             continue

@@ -7,7 +7,7 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, load_golden, rel_err
+from conftest import GOLDEN_DIR, load_golden, load_sequence, rel_err, sequence_cases
 
 
 def make_reference_shaped(prob, ref):
@@ -146,3 +146,32 @@ def test_make_tracks_is_seeded():
     a, b = synth.make_tracks(prob, 3, flip_fraction=0.2), synth.make_tracks(prob, 3, flip_fraction=0.2)
     assert np.array_equal(a.line_dir, b.line_dir) and np.array_equal(a.lost_for, b.lost_for)
     assert not np.array_equal(a.line_conf, synth.make_tracks(prob, 4).line_conf)
+
+
+@pytest.mark.parametrize("case", sequence_cases())
+def test_host_transition_and_augmentation_match_reference(case):
+    """propagation.py (the host set-up of msckf_propagate / msckf_augment) against every
+    process_imu / state_augmentation step of the reference run: the 15x15 Phi, Q and the 6x15 J
+    are pinned through the covariance the reference left after the step."""
+    from msckf_amd import propagation
+    head, ops = load_sequence(case)
+    P = head["P0"]
+    for op in ops:
+        if op["kind"] == 0:
+            Phi, Q = propagation.imu_transition(op["R"], op["t"], op["v"], op["R0"], op["t0"], op["v0"], op["gyro"],
+                                                op["acc"], float(op["dt"]), head["gravity"], head["Qc"], op["w_planet"])
+            Pn = P.copy()
+            Pn[:15, :15] = Phi @ P[:15, :15] @ Phi.T + Q
+            Pn[:15, 15:] = Phi @ P[:15, 15:]
+            Pn[15:, :15] = Pn[:15, 15:].T
+            assert rel_err((Pn + Pn.T) / 2, op["P_after"]) < 1e-13
+        elif op["kind"] == 1:
+            J, cR, ct = propagation.augmentation(op["imu_R"], op["imu_t"], (head["T_W_I_R"], head["T_W_I_t"]),
+                                                 (head["T_W_C_R"], head["T_W_C_t"]))
+            np.testing.assert_allclose(cR, op["cam_R"], atol=1e-14)
+            np.testing.assert_allclose(ct, op["cam_t"], atol=1e-14)
+            d = P.shape[0]
+            M = np.vstack([np.eye(d), np.hstack([J, np.zeros((6, d - 15))])])
+            S = M @ P @ M.T
+            assert rel_err((S + S.T) / 2, op["P_after"]) < 1e-14
+        P = op["P_after"]

@@ -3,7 +3,8 @@ the reference (tests/golden/gen_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_golden, load_golden_select, rel_err, select_cases
+from conftest import (golden_cases, load_golden, load_golden_select, load_sequence, rel_err, select_cases,
+                      sequence_cases)
 from oracle import msckf_oracle as oracle
 
 FAST = [c for c in golden_cases() if c != "cfg3_A"]
@@ -89,3 +90,40 @@ def test_oracle_select_matches_reference(case):
     assert out["status"] == int(ref["status"]) and out["n_rejected"] == int(ref["n_rejected"])
     assert rel_err(out["dx"], ref["dx"]) < 1e-9
     assert rel_err(out["P_new"], ref["P_new"]) < 1e-11
+
+
+@pytest.mark.parametrize("case", sequence_cases())
+def test_oracle_sequence_matches_reference(case):
+    """f2/f3: every step of a multi-frame run of the reference (process_imu, state_augmentation,
+    update + correct, remove_cameras) restated; the oracle carries its OWN covariance through the
+    whole run and must stay on the reference's."""
+    from msckf_amd import synth
+    head, ops = load_sequence(case)
+    P = head["P0"].copy()
+    n_clones = 0
+    for op in ops:
+        if op["kind"] == 0:
+            Phi, Q = oracle.imu_transition(op["R"], op["t"], op["v"], op["R0"], op["t0"], op["v0"], op["gyro"], op["acc"],
+                                           float(op["dt"]), head["gravity"], op["w_planet"], head["Qc"])
+            P = oracle.propagate_covariance(P, Phi, Q)
+        elif op["kind"] == 1:
+            J, cR, ct = oracle.augmentation_jacobian(op["imu_R"], op["imu_t"], head["T_W_I_R"], head["T_W_I_t"],
+                                                     head["T_W_C_R"], head["T_W_C_t"])
+            np.testing.assert_allclose(cR, op["cam_R"], atol=1e-14)
+            np.testing.assert_allclose(ct, op["cam_t"], atol=1e-14)
+            P = oracle.augment_covariance(P, J)
+            n_clones += 1
+        elif op["kind"] == 2:
+            prob = synth.UpdateProblem(P=P, cam_R=op["cam_R"], cam_t=op["cam_t"], cam_R0=op["cam_R"], cam_t0=op["cam_t"],
+                                       gravity=head["gravity"], K=head["K"], sigma=float(head["sigma"]),
+                                       view_ptr=op["view_ptr"], obs_uv=op["obs_uv"], obs_slot=op["obs_slot"],
+                                       idp_base=op["idp_base"], idp_m=op["idp_m"], idp_rho=op["idp_rho"])
+            out = oracle.update(prob)
+            assert out["status"] == int(op["status"])
+            assert rel_err(out["dx"], op["dx"]) < 1e-8
+            P = out["P_new"]
+        else:
+            P = oracle.remove_clones_covariance(P, op["slots"])
+            n_clones -= len(op["slots"])
+        assert P.shape == op["P_after"].shape == (15 + 6 * n_clones,) * 2
+        assert rel_err(P, op["P_after"]) < 1e-9, (op["kind"], rel_err(P, op["P_after"]))
