@@ -255,6 +255,28 @@ def main():
                                  "candidates": prob.F, "valid": int(eng.selection().valid.sum()),
                                  "bytes_algorithmic": sel_bytes, "hbm_gbs_algorithmic": sel_bytes / (us_sel * 1e-6) / 1e9,
                                  "fused_select_update_us": us_fused}
+            # f2 / f3: the covariance steps either side of the update on the resident P (host clock
+            # around async launches + one sync; augment / remove include their pose upload and sync)
+            rng = np.random.default_rng(0)
+            eng.set_prior(prob.P, prob.gravity, prob.K, prob.sigma, prob.cam_R, prob.cam_t)
+            Phi = np.eye(15) + 1e-3 * rng.standard_normal((15, 15))
+            Qd = 1e-8 * np.eye(15)
+            for _ in range(10):
+                eng.propagate(Phi, Qd)
+            eng.sync()
+            t3 = time.perf_counter()
+            for _ in range(200):
+                eng.propagate(Phi, Qd)
+            eng.sync()
+            us_prop = (time.perf_counter() - t3) / 200 * 1e6
+            J15 = np.zeros((6, 15)); J15[:3, :3] = np.eye(3); J15[3:, 12:] = np.eye(3)
+            t4 = time.perf_counter()
+            for _ in range(20):
+                eng.remove_clones([0])
+                eng.augment(J15, prob.cam_R[0], prob.cam_t[0])
+            us_window = (time.perf_counter() - t4) / 20 * 1e6
+            line["resident_f2_f3"] = {"propagate_us": us_prop, "remove_plus_augment_us": us_window,
+                                      "clones": N, "bytes_per_propagate": (2 * 15 * prob.d * 2 + prob.d * prob.d * 2) * 8}
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

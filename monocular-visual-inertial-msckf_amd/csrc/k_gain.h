@@ -46,33 +46,35 @@ __global__ __launch_bounds__(64) void k_gemm_f64(GemmArgs g) {
     const bool aok = arow < g.M, bok = bcol < g.N;
     const double* ap = g.A + (size_t)arow * g.lda;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    // 4 k-steps per trip, all 8 loads issued before the first MFMA (the loop is latency bound)
+    // GEMM_TRIP k-steps per trip, all loads of a trip issued before its first MFMA: the loop is bound
+    // by the global-load round trip (K = 180 is 45 doubles per lane), so fewer, wider trips win
+    constexpr int GEMM_TRIP = 16;
     if (g.transB) {
         const double* bp = g.B + (size_t)bcol * g.ldb;
-        for (int s0 = 0; s0 < kq; s0 += 4) {
-            double av[4], bv[4];
+        for (int s0 = 0; s0 < kq; s0 += GEMM_TRIP) {
+            double av[GEMM_TRIP], bv[GEMM_TRIP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GEMM_TRIP; ++u) {
                 const int k = k_lo + s0 + u;
                 const bool kok = (s0 + u < kq) && (k < k_hi);
                 av[u] = (aok && kok) ? ap[k] : 0.0;
                 bv[u] = (bok && kok) ? bp[k] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < GEMM_TRIP; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
     } else {
-        for (int s0 = 0; s0 < kq; s0 += 4) {
-            double av[4], bv[4];
+        for (int s0 = 0; s0 < kq; s0 += GEMM_TRIP) {
+            double av[GEMM_TRIP], bv[GEMM_TRIP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < GEMM_TRIP; ++u) {
                 const int k = k_lo + s0 + u;
                 const bool kok = (s0 + u < kq) && (k < k_hi);
                 av[u] = (aok && kok) ? ap[k] : 0.0;
                 bv[u] = (bok && kok) ? g.B[(size_t)k * g.ldb + bcol] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < GEMM_TRIP; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
         }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(T) void k_chol(CholArgs c) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int t = threadIdx.x, n = c.n;
     double* A = c.use_lds ? smem : c.work;      // packed lower by rows: (i,j) at i(i+1)/2 + j
+    if (t == 0) c.status[0] = 0;                // thread 0 also writes the failure flag: program order
     for (int i = t / 32; i < n; i += T / 32)
         for (int j = t % 32; j <= i; j += 32) A[i * (i + 1) / 2 + j] = c.S[(size_t)i * c.lds_ + j];
     __syncthreads();
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(T) void k_chol(CholArgs c) {
 struct SolveArgs {
     const double* Y; int ldy;     // [d][n]
     const double* L; const double* U; const double* invd; int n;
+    const double* Lp;             // optional: L packed by rows, (i, j) at i(i+1)/2 + j (k_chol_tile writes it)
     const double* z; int zstride; // r_n (column of the compressed block)
     double* Kg; int ldk;          // [d][n]
     double* dx; int d;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(T) void k_chol_blk(CholArgs c) {
     constexpr int NB = 6;
     const int t = threadIdx.x, n = c.n;
     double* A = smem;                            // packed lower by rows: (i, j) at i(i+1)/2 + j
+    if (t == 0) c.status[0] = 0;
     for (int i = t >> 6; i < n; i += T / 64)
         for (int j = (t & 63); j <= i; j += 64) A[i * (i + 1) / 2 + j] = c.S[(size_t)i * c.lds_ + j];
     __syncthreads();
@@ -321,26 +326,204 @@ __global__ __launch_bounds__(T) void k_chol_blk(CholArgs c) {
         }
 }
 
+// Register-resident tiled Cholesky for n <= 4 * CHOL_TILE_MAX_NT.  The whole lower triangle lives
+// in registers as 4x4 tiles (tile e = t + T*s of the row-major enumeration of the lower tiles, up
+// to three per thread), so the trailing update reads only the current 4-column panel from LDS
+// (32 doubles per tile and step) and never re-reads or re-writes the matrix itself -- the LDS
+// traffic of the packed-triangle version (k_chol_blk: 80 LDS operations per tile and step, 79 of
+// its 125 us) was the bound.  Step k:
+//   P(k)  owners of the tiles (i, k), i > k, solve X L11^T = A against the published 4x4 diagonal
+//         factor and publish their rows of the panel;                         barrier
+//   T(k)  every tile (i, j), j > k, subtracts panel_i panel_j^T; the owner of tile (k+1, k+1) takes
+//         it first, factors it (right-looking, so the divisions chain only through the pivots)
+//         and publishes L11 for the next step while the others are still updating;   barrier
+// No global memory is touched inside the loop (a barrier would wait for outstanding stores).
+constexpr int CHOL_TILE_MAX_NT = 47;      // 47 * 48 / 2 = 1128 tiles <= 3 * 512
+
+template <int T, int NS = (CHOL_TILE_MAX_NT * (CHOL_TILE_MAX_NT + 1) / 2 + T - 1) / T>
+__global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
+    // panel, laid out [column q][row-in-tile u][tile row]: lanes with consecutive tile indices read
+    // consecutive doubles (a [row][4] layout put 64 lanes on 4 banks: 16-way conflicts, 120 us)
+    constexpr int NTP = CHOL_TILE_MAX_NT + 1;
+    __shared__ __attribute__((aligned(16))) double sP[16 * NTP];
+    __shared__ __attribute__((aligned(16))) double sD[20];                         // L11 (4x4) + 1/diag
+    __shared__ double sInv[4 * CHOL_TILE_MAX_NT];                                  // 1/L_jj of every factored column
+    __shared__ int sBad;
+    const int t = threadIdx.x, n = c.n;
+    const int nt = (n + 3) >> 2, ntile = nt * (nt + 1) / 2;
+    int ti[NS], tj[NS];
+    double a[NS][4][4];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = t + T * s;
+        ti[s] = -1; tj[s] = -1;
+        if (e < ntile) {
+            int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+            while (r * (r + 1) / 2 > e) --r;
+            while ((r + 1) * (r + 2) / 2 <= e) ++r;
+            ti[s] = r; tj[s] = e - r * (r + 1) / 2;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 4 * ti[s] + u, j = 4 * tj[s] + v;
+                double x = (i == j) ? 1.0 : 0.0;                      // identity padding beyond n
+                if (ti[s] >= 0 && i < n && j < n) x = c.S[(size_t)i * c.lds_ + j];
+                a[s][u][v] = x;
+            }
+    }
+    if (t == 0) { sBad = 0; c.status[0] = 0; }
+    __syncthreads();
+    // in-register factor of a diagonal tile + publication (right-looking: every update of the
+    // remaining entries is independent, only the four pivots form a chain)
+    auto factor_diag = [&](double (&d)[4][4], int kd) {
+        int bad = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const double piv = d[p][p];
+            if (!(piv > 0.0)) bad = 1;
+            const double di = (piv > 1e-200 && piv < 1e200) ? fast_rsqrt(piv) : 1.0 / sqrt(piv);
+            d[p][p] = fast_norm(piv, di);
+            sD[16 + p] = di;
+            sInv[4 * kd + p] = di;
+#pragma unroll
+            for (int b = p + 1; b < 4; ++b) d[b][p] *= di;
+#pragma unroll
+            for (int b = p + 1; b < 4; ++b)
+#pragma unroll
+                for (int q = p + 1; q <= b; ++q) d[b][q] = fma(-d[b][p], d[q][p], d[b][q]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v <= u; ++v) sD[4 * u + v] = d[u][v];
+        if (bad) sBad = 1;
+    };
+    auto update_diag_tile = [&](double (&d)[4][4], int ri) {
+        double Li[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Li[u][q] = sP[(4 * q + u) * NTP + ri];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v <= u; ++v) {
+                double x = d[u][v];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x = fma(-Li[u][q], Li[v][q], x);
+                d[u][v] = x;
+            }
+    };
+    auto update_tile = [&](double (&d)[4][4], int ri, int rj) {
+        double Li[4][4], Lj[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Li[u][q] = sP[(4 * q + u) * NTP + ri];
+                Lj[u][q] = sP[(4 * q + u) * NTP + rj];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double x = d[u][v];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x = fma(-Li[u][q], Lj[v][q], x);
+                d[u][v] = x;
+            }
+    };
+    if (t == 0) factor_diag(a[0], 0);              // tile (0, 0) is e = 0
+    __syncthreads();
+    for (int k = 0; k < nt; ++k) {
+        if (sBad) break;                           // uniform: read after a barrier
+        // ---- P(k): the panel below the diagonal tile -------------------------------------
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (tj[s] == k && ti[s] > k) {
+                double l10 = sD[4], l20 = sD[8], l21 = sD[9], l30 = sD[12], l31 = sD[13], l32 = sD[14];
+                double i0 = sD[16], i1 = sD[17], i2 = sD[18], i3 = sD[19];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double x0 = a[s][u][0] * i0;
+                    const double x1 = fma(-x0, l10, a[s][u][1]) * i1;
+                    const double x2 = fma(-x1, l21, fma(-x0, l20, a[s][u][2])) * i2;
+                    const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, a[s][u][3]))) * i3;
+                    a[s][u][0] = x0; a[s][u][1] = x1; a[s][u][2] = x2; a[s][u][3] = x3;
+                    double* row = sP + u * NTP + ti[s];
+                    row[0] = x0; row[4 * NTP] = x1; row[8 * NTP] = x2; row[12 * NTP] = x3;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- T(k): trailing update, next diagonal tile first ----------------------------------
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (ti[s] == k + 1 && tj[s] == k + 1) {
+                update_diag_tile(a[s], k + 1);
+                factor_diag(a[s], k + 1);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (tj[s] > k && !(ti[s] == k + 1 && tj[s] == k + 1)) update_tile(a[s], ti[s], tj[s]);
+        }
+        __syncthreads();
+    }
+    if (sBad) { if (t == 0) c.status[0] = 1; return; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (ti[s] < 0) continue;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 4 * ti[s] + u, j = 4 * tj[s] + v;
+                if (i < n && j <= i) {
+                    const double x = a[s][u][v];
+                    c.L[(size_t)i * n + j] = x;
+                    c.U[(size_t)j * n + i] = x;
+                    // packed copy for k_solve_lds with columns scaled to a unit diagonal (L D^-1)
+                    if (c.work) c.work[i * (i + 1) / 2 + j] = (i == j) ? 1.0 : x * sInv[j];
+                    if (i == j) c.invd[j] = sInv[j];
+                }
+            }
+    }
+}
+
 // K = Y S^-1 with the packed factor L resident in LDS (n(n+1)/2 doubles): one
 // wavefront per row of Y, WAVES rows per workgroup.
-template <int NREG, int WAVES>
+template <int NREG, int WAVES, int ROWS = 1, bool UNIT = false>
 __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = s.n, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     double* lp = smem;                          // packed lower: (i, j) at i(i+1)/2 + j
     double* sinv = smem + (size_t)n * (n + 1) / 2;
-    for (int i = wv; i < n; i += WAVES)
-        for (int j = lane; j <= i; j += 64) lp[i * (i + 1) / 2 + j] = s.L[(size_t)i * n + j];
+    constexpr bool unit = UNIT;                 // the packed copy s.Lp has unit diagonal (columns scaled by 1/L_jj)
+    if (UNIT) {                                 // flat copy, many loads in flight
+        const int np = n * (n + 1) / 2;
+#pragma unroll 8
+        for (int idx = t; idx < np; idx += 64 * WAVES) lp[idx] = s.Lp[idx];
+    } else {
+        for (int i = wv; i < n; i += WAVES)
+            for (int j = lane; j <= i; j += 64) lp[i * (i + 1) / 2 + j] = s.L[(size_t)i * n + j];
+    }
     for (int j = t; j < n; j += 64 * WAVES) sinv[j] = s.invd[j];
     __syncthreads();
-    const int row = blockIdx.x * WAVES + wv;
-    if (row >= s.d) return;
-    double x[NREG];
+    // ROWS rows of Y per wavefront: the rows are independent, so their pivot -> readlane -> FMA chains
+    // interleave, and each column of L is read from LDS once for all of them
+    const int row0 = (blockIdx.x * WAVES + wv) * ROWS;
+    if (row0 >= s.d) return;
+    double x[ROWS][NREG];
 #pragma unroll
-    for (int m = 0; m < NREG; ++m) {
-        const int i = lane + 64 * m;
-        x[m] = (i < n) ? s.Y[(size_t)row * s.ldy + i] : 0.0;
-    }
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int m = 0; m < NREG; ++m) {
+            const int i = lane + 64 * m;
+            x[r][m] = (row0 + r < s.d && i < n) ? s.Y[(size_t)(row0 + r) * s.ldy + i] : 0.0;
+        }
     // forward sweep  L x = y
 #pragma unroll
     for (int mj = 0; mj < NREG; ++mj) {
@@ -354,12 +537,28 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
                 const int i = lane + 64 * m;
                 lv[m] = (m >= mj && i > j && i < n) ? lp[i * (i + 1) / 2 + j] : 0.0;
             }
-            const double xj = readlane_d(x[mj], jj) * sinv[j];
-            if (lane == jj) x[mj] = xj;
+            const double sj = unit ? 1.0 : sinv[j];
 #pragma unroll
-            for (int m = 0; m < NREG; ++m)
-                if (m >= mj) x[m] -= lv[m] * xj;
+            for (int r = 0; r < ROWS; ++r) {
+                const double xj = unit ? readlane_d(x[r][mj], jj) : readlane_d(x[r][mj], jj) * sj;
+                if (!unit && lane == jj) x[r][mj] = xj;
+#pragma unroll
+                for (int m = 0; m < NREG; ++m)
+                    if (m >= mj) x[r][m] -= lv[m] * xj;
+            }
         }
+    }
+    // unit-diagonal factor L' = L D^-1:  L x = y  <=>  L' (D x) = y  and  L^T k = x  <=>  L'^T k = D^-1 x,
+    // so the two sweeps need no per-step scaling, just D^-2 in between
+    if (unit) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int m = 0; m < NREG; ++m) {
+                const int i = lane + 64 * m;
+                const double di = (i < n) ? sinv[i] : 0.0;
+                x[r][m] *= di * di;
+            }
     }
     // backward sweep  L^T k = x
 #pragma unroll
@@ -374,24 +573,32 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
                 const int i = lane + 64 * m;
                 lv[m] = (m <= mj && i < j) ? lp[j * (j + 1) / 2 + i] : 0.0;
             }
-            const double kj = readlane_d(x[mj], jj) * sinv[j];
-            if (lane == jj) x[mj] = kj;
+            const double sj = unit ? 1.0 : sinv[j];
 #pragma unroll
-            for (int m = 0; m < NREG; ++m)
-                if (m <= mj) x[m] -= lv[m] * kj;
+            for (int r = 0; r < ROWS; ++r) {
+                const double kj = unit ? readlane_d(x[r][mj], jj) : readlane_d(x[r][mj], jj) * sj;
+                if (!unit && lane == jj) x[r][mj] = kj;
+#pragma unroll
+                for (int m = 0; m < NREG; ++m)
+                    if (m <= mj) x[r][m] -= lv[m] * kj;
+            }
         }
     }
-    double dot = 0.0;
 #pragma unroll
-    for (int m = 0; m < NREG; ++m) {
-        const int i = lane + 64 * m;
-        if (i < n) {
-            s.Kg[(size_t)row * s.ldk + i] = x[m];
-            dot += x[m] * s.z[(size_t)i * s.zstride];
+    for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r >= s.d) break;
+        double dot = 0.0;
+#pragma unroll
+        for (int m = 0; m < NREG; ++m) {
+            const int i = lane + 64 * m;
+            if (i < n) {
+                s.Kg[(size_t)(row0 + r) * s.ldk + i] = x[r][m];
+                dot += x[r][m] * s.z[(size_t)i * s.zstride];
+            }
         }
+        dot = wave_sum(dot);
+        if (lane == 0) s.dx[row0 + r] = dot;
     }
-    dot = wave_sum(dot);
-    if (lane == 0) s.dx[row] = dot;
 }
 
 // P_out = (Pn + Pn^T) / 2   (reference MSCKF.py:614)

@@ -39,6 +39,14 @@ constexpr int FOLD_CPT3 = (192 + FOLD_NCG - 1) / FOLD_NCG;
 constexpr int FOLD_RPT_LEAF = ((160 / FOLD_RL + 3) / 4) * 4;   // <= 160-row leaves
 constexpr int FOLD_RPT_BIG = 256 / FOLD_RL;                     // 256-row batches (W1, W2)
 constexpr int FOLD_RPT_W3 = 192 / FOLD_RL;                      // 192-row batches (W3)
+#ifndef MSCKF_SOLVE_WAVES
+#define MSCKF_SOLVE_WAVES 8
+#endif
+constexpr int SOLVE_WAVES = MSCKF_SOLVE_WAVES;   // wavefronts per workgroup of k_solve_lds
+#ifndef MSCKF_SOLVE_ROWS
+#define MSCKF_SOLVE_ROWS 1
+#endif
+constexpr int SOLVE_ROWS = MSCKF_SOLVE_ROWS;     // rows of Y per wavefront
 constexpr int FOLDG_T = 512;                     // fallback kernel (R streamed through HBM)
 constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgroup
 constexpr int FOLD_LDS_BYTES = 160 * 1024 - 512;
@@ -315,17 +323,20 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
     double* B2 = ptr<double>(c->dB2);   // [d][d]    (I - K T) P
     double* D = ptr<double>(c->dD);     // [d][dc]   sigma^2 K - B2[:,15:] T^T
     double* Pn = ptr<double>(c->dPn);   // [d][d]
-    HIPCHK(c, hipMemsetAsync(c->dStatus.p, 0, 16, c->stream));
     // Y = P[:, 15:] T^T                      (P T_H^T, MSCKF.py:606)
     gemm(c, P + 15, d, Tblk, ldt, nullptr, 0, Y, dc, d, dc, dc, 1.0, 0.0, 0.0, 1, 1);
     // S = T Y[15:, :] + sigma^2 I            (MSCKF.py:605)
     gemm(c, Tblk, ldt, Y + (size_t)15 * dc, dc, nullptr, 0, S, dc, dc, dc, dc, 1.0, 0.0, s2, 0, 2);
     // S = L L^T
+    bool packed_L = false;
     {
         CholArgs a{};
         a.S = S; a.lds_ = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = ptr<double>(c->dInvd);
         a.n = dc; a.work = ptr<double>(c->dCholWork); a.status = ptr<int>(c->dStatus);
-        if ((size_t)dc * (dc + 1) / 2 * 8 <= (size_t)(LDS_MAX_BYTES - 1024)) {
+        if (dc <= 4 * CHOL_TILE_MAX_NT) {
+            packed_L = true;
+            hipLaunchKernelGGL((k_chol_tile<512>), dim3(1), dim3(512), 0, c->stream, a);   // matrix in registers
+        } else if ((size_t)dc * (dc + 1) / 2 * 8 <= (size_t)(LDS_MAX_BYTES - 1024)) {
             const size_t lds_chol = (size_t)dc * (dc + 1) / 2 * 8;
             hipLaunchKernelGGL((k_chol_blk<512>), dim3(1), dim3(512), lds_chol, c->stream, a);
         } else {
@@ -338,15 +349,20 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
     {
         SolveArgs a{};
         a.Y = Y; a.ldy = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = ptr<double>(c->dInvd);
+        a.Lp = packed_L ? ptr<double>(c->dCholWork) : nullptr;
         a.n = dc; a.z = Tblk + dc; a.zstride = ldt; a.Kg = Kg; a.ldk = dc; a.dx = ptr<double>(c->dDx); a.d = d;
         const int nreg = (dc + 63) / 64;
         const size_t lds_need = ((size_t)dc * (dc + 1) / 2 + dc) * 8;
         if (nreg <= 3 && lds_need <= (size_t)(LDS_MAX_BYTES - 1024)) {
-            constexpr int WV = 4;
-            const dim3 grid((d + WV - 1) / WV), block(64 * WV);
-            if (nreg <= 1) hipLaunchKernelGGL((k_solve_lds<1, WV>), grid, block, lds_need, c->stream, a);
-            else if (nreg <= 2) hipLaunchKernelGGL((k_solve_lds<2, WV>), grid, block, lds_need, c->stream, a);
-            else hipLaunchKernelGGL((k_solve_lds<3, WV>), grid, block, lds_need, c->stream, a);
+            constexpr int WV = SOLVE_WAVES;
+            const dim3 grid((d + WV * SOLVE_ROWS - 1) / (WV * SOLVE_ROWS)), block(64 * WV);
+#define SOLVE_LAUNCH(NR, UN) hipLaunchKernelGGL((k_solve_lds<NR, WV, SOLVE_ROWS, UN>), grid, block, lds_need, c->stream, a)
+            if (packed_L) {
+                if (nreg <= 1) SOLVE_LAUNCH(1, true); else if (nreg <= 2) SOLVE_LAUNCH(2, true); else SOLVE_LAUNCH(3, true);
+            } else {
+                if (nreg <= 1) SOLVE_LAUNCH(1, false); else if (nreg <= 2) SOLVE_LAUNCH(2, false); else SOLVE_LAUNCH(3, false);
+            }
+#undef SOLVE_LAUNCH
         } else if (nreg <= 4) hipLaunchKernelGGL(k_solve<4>, dim3(d), dim3(64), 0, c->stream, a);
         else hipLaunchKernelGGL(k_solve<5>, dim3(d), dim3(64), 0, c->stream, a);
     }
@@ -457,12 +473,12 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold_g<FOLDG_T, 6, 10>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<1, 4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<2, 4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_solve_lds<3, 4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+    {
+#define SK(NR, UN) reinterpret_cast<const void*>(&k_solve_lds<NR, SOLVE_WAVES, SOLVE_ROWS, UN>)
+        const void* sk[] = {SK(1, true), SK(2, true), SK(3, true), SK(1, false), SK(2, false), SK(3, false)};
+#undef SK
+        for (const void* f : sk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_blk<512>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
