@@ -205,127 +205,6 @@ __global__ __launch_bounds__(64) void k_solve(SolveArgs s) {
     if (lane == 0) s.dx[row] = dot;
 }
 
-// Blocked Cholesky, block = 6 columns (one clone block; n = 6N is always a multiple of 6).
-// The packed lower triangle lives in LDS.  Per block: every thread reads the 6x6 diagonal
-// block and factors it redundantly in registers (the six dependent rsqrt steps cost no
-// barrier and no LDS round trip), one thread per row solves the panel, then the trailing
-// matrix takes a rank-6 update in 4x4 register tiles.  Two barriers per SIX columns instead
-// of one per column: the per-column latency chain (tools/ubench/step_latency.hip) is what
-// bounds an unblocked factorisation at ~1 us per column.  (Variants measured and dropped: an
-// unblocked register-resident factorisation, 290 us at n = 180, and MFMA accumulator tiles for
-// the trailing update, 131 us; this kernel: 126 us, of which the 30 in-register diagonal
-// factorisations are 45 us.)
-template <int T, int DBG = 0>
-__global__ __launch_bounds__(T) void k_chol_blk(CholArgs c) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int NB = 6;
-    const int t = threadIdx.x, n = c.n;
-    double* A = smem;                            // packed lower by rows: (i, j) at i(i+1)/2 + j
-    if (t == 0) c.status[0] = 0;
-    for (int i = t >> 6; i < n; i += T / 64)
-        for (int j = (t & 63); j <= i; j += 64) A[i * (i + 1) / 2 + j] = c.S[(size_t)i * c.lds_ + j];
-    __syncthreads();
-    int bad = 0;
-    for (int c0 = 0; c0 < n; c0 += NB) {
-        // 1. diagonal block, factored redundantly by every thread
-        double Ld[NB][NB], dinv[NB];
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) Ld[a][b] = A[(c0 + a) * (c0 + a + 1) / 2 + c0 + b];
-#pragma unroll
-        for (int a = 0; a < NB; ++a) {
-            double piv = Ld[a][a];
-#pragma unroll
-            for (int k = 0; k < a; ++k) piv = fma(-Ld[a][k], Ld[a][k], piv);
-            if (!(piv > 0.0)) bad = 1;
-            const double di = (piv > 1e-200 && piv < 1e200) ? fast_rsqrt(piv) : 1.0 / sqrt(piv);
-            dinv[a] = di;
-            Ld[a][a] = fast_norm(piv, di);
-#pragma unroll
-            for (int b = a + 1; b < NB; ++b) {
-                double x = Ld[b][a];
-#pragma unroll
-                for (int k = 0; k < a; ++k) x = fma(-Ld[b][k], Ld[a][k], x);
-                Ld[b][a] = x * di;
-            }
-        }
-        if (bad) break;                                  // uniform: every thread factors the same block
-        const int c1 = c0 + NB;
-        // 2. panel rows: x L11^T = a  (forward substitution), one thread per row
-        if (DBG < 2)
-        for (int i = c1 + t; i < n; i += T) {
-            double* row = A + i * (i + 1) / 2 + c0;
-            double x[NB];
-#pragma unroll
-            for (int a = 0; a < NB; ++a) x[a] = row[a];
-#pragma unroll
-            for (int a = 0; a < NB; ++a) {
-#pragma unroll
-                for (int k = 0; k < a; ++k) x[a] = fma(-x[k], Ld[a][k], x[a]);
-                x[a] *= dinv[a];
-            }
-#pragma unroll
-            for (int a = 0; a < NB; ++a) row[a] = x[a];
-        }
-        if (t == 0) {
-#pragma unroll
-            for (int a = 0; a < NB; ++a)
-#pragma unroll
-                for (int b = 0; b <= a; ++b) A[(c0 + a) * (c0 + a + 1) / 2 + c0 + b] = Ld[a][b];
-        }
-        __syncthreads();
-        // 3. trailing update in 4x4 register tiles: A[i][j] -= sum_a L[i][c0+a] L[j][c0+a], j <= i.
-        //    The nt(nt+1)/2 lower tiles are dealt round-robin over the threads (balanced).
-        const int nt = (n - c1 + 3) >> 2;                // tiles per side
-        const int ntile = nt * (nt + 1) / 2;
-        if (DBG < 1)
-        for (int e = t; e < ntile; e += T) {
-            int ti = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-            while (ti * (ti + 1) / 2 > e) --ti;
-            while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
-            const int tj = e - ti * (ti + 1) / 2;
-            const int i0 = c1 + 4 * ti, j0 = c1 + 4 * tj;
-            double Li[4][NB], Lj[4][NB];
-            int bi[4], bj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = min(i0 + u, n - 1), j = min(j0 + u, n - 1);
-                bi[u] = i * (i + 1) / 2;
-                bj[u] = j * (j + 1) / 2;
-#pragma unroll
-                for (int a = 0; a < NB; ++a) {
-                    Li[u][a] = A[bi[u] + c0 + a];
-                    Lj[u][a] = A[bj[u] + c0 + a];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int j = j0 + v;
-                    if (i < n && j <= i) {
-                        double x = A[bi[u] + j];
-#pragma unroll
-                        for (int a = 0; a < NB; ++a) x = fma(-Li[u][a], Lj[v][a], x);
-                        A[bi[u] + j] = x;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (bad) { if (t == 0) c.status[0] = 1; return; }
-    for (int i = t >> 6; i < n; i += T / 64)
-        for (int j = (t & 63); j <= i; j += 64) {
-            const double x = A[i * (i + 1) / 2 + j];
-            c.L[(size_t)i * n + j] = x;
-            c.U[(size_t)j * n + i] = x;
-            if (i == j) c.invd[j] = 1.0 / x;
-        }
-}
-
 // Register-resident tiled Cholesky for n <= 4 * CHOL_TILE_MAX_NT.  The whole lower triangle lives
 // in registers as 4x4 tiles (tile e = t + T*s of the row-major enumeration of the lower tiles, up
 // to three per thread), so the trailing update reads only the current 4-column panel from LDS

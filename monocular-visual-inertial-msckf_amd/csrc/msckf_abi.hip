@@ -336,9 +336,6 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         if (dc <= 4 * CHOL_TILE_MAX_NT) {
             packed_L = true;
             hipLaunchKernelGGL((k_chol_tile<512>), dim3(1), dim3(512), 0, c->stream, a);   // matrix in registers
-        } else if ((size_t)dc * (dc + 1) / 2 * 8 <= (size_t)(LDS_MAX_BYTES - 1024)) {
-            const size_t lds_chol = (size_t)dc * (dc + 1) / 2 * 8;
-            hipLaunchKernelGGL((k_chol_blk<512>), dim3(1), dim3(512), lds_chol, c->stream, a);
         } else {
             const size_t need = (size_t)dc * (dc + 1) / 2 * 8;
             a.use_lds = need <= (size_t)(LDS_MAX_BYTES - 1024) ? 1 : 0;
@@ -479,8 +476,6 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
 #undef SK
         for (const void* f : sk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_blk<512>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<24>), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -5,15 +5,6 @@
 #include <algorithm>
 #include "../../monocular-visual-inertial-msckf_amd/csrc/k_gain.h"
 using namespace msckf;
-template <int DBG> float run(CholArgs a, size_t lds) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol_blk<512, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_chol_blk<512, DBG>), dim3(1), dim3(512), lds, 0, a);
-    hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k_chol_blk<512, DBG>), dim3(1), dim3(512), lds, 0, a);
-    hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); return ms * 100.0f;
-}
 template <int TT = 512>
 float run_tile(CholArgs a) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -42,16 +33,7 @@ int main() {
     hipMalloc(&dS, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dU, n * n * 8); hipMalloc(&dI, n * 8); hipMalloc(&st, 64);
     hipMemcpy(dS, S.data(), n * n * 8, hipMemcpyHostToDevice); hipMemset(st, 0, 64);
     a.S = dS; a.lds_ = n; a.L = dL; a.U = dU; a.invd = dI; a.n = n; a.status = st;
-    const size_t lds = (size_t)n * (n + 1) / 2 * 8;
-    printf("full        : %.1f us\n", run<0>(a, lds));
-    printf("no trailing : %.1f us\n", run<1>(a, lds));
-    printf("diag only   : %.1f us\n", run<2>(a, lds));
-    run<0>(a, lds); hipDeviceSynchronize();
-    printf("blk  max |L L^T - S| = %.2e\n", check(S, dL, n));
-    hipMemset(dL, 0, n * n * 8);
     printf("tile        : %.1f us\n", run_tile(a));
-    printf("tile T=256  : %.1f us\n", run_tile<256>(a));
-    printf("tile T=1024 : %.1f us\n", run_tile<1024>(a));
     hipDeviceSynchronize();
     printf("tile max |L L^T - S| = %.2e\n", check(S, dL, n));
     for (int nn : {60, 186, 6}) {
