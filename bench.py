@@ -239,12 +239,20 @@ def main():
             eng.sync()
             ms_masked, _ = eng.run_timed(50)                       # K1-K7 over the valid subset, HIP events
             us_fused = us_sel + ms_masked / 50 * 1e3
+            t2 = time.perf_counter()
+            eng.replan()                                           # tree over the valid features only (syncs)
+            us_replan = (time.perf_counter() - t2) * 1e6
+            eng.run()
+            eng.sync()
+            ms_replanned, _ = eng.run_timed(50)
             n_views = int(prob.view_ptr[-1])
             sel_bytes = n_views * (7 * 8 + 4) + prob.F * (3 * 4 + 1 + 7 * 8)
             line["select_f1"] = {"kernel": "k_select (get_valid_features)", "us_per_launch": us_sel,
                                  "candidates": prob.F, "valid": int(eng.selection().valid.sum()),
                                  "bytes_algorithmic": sel_bytes, "hbm_gbs_algorithmic": sel_bytes / (us_sel * 1e-6) / 1e9,
-                                 "fused_select_update_us": us_fused}
+                                 "fused_select_update_us": us_fused,
+                                 "replan_host_us": us_replan,
+                                 "fused_replanned_us": us_sel + us_replan + ms_replanned / 50 * 1e3}
             # f2 / f3: the covariance steps either side of the update on the resident P (host clock
             # around async launches + one sync; augment / remove include their pose upload and sync)
             rng = np.random.default_rng(0)

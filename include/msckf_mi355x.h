@@ -176,6 +176,10 @@ int msckf_set_tracks(msckf_ctx* ctx, const double* line_base, const double* line
  * features of the batch (the others report accepted = 0 and are not counted as rejected),
  * until the next msckf_set_features or msckf_clear_selection. */
 int msckf_run_select(msckf_ctx* ctx, const msckf_select_params* params);
+/* Optional, between msckf_run_select and msckf_run: wait for the flags and plan the QR tree
+ * over the valid features only (the plan of msckf_set_features covers every candidate).  Costs
+ * one stream sync and the host-side plan; pays off when few candidates are valid. */
+int msckf_replan(msckf_ctx* ctx);
 int msckf_clear_selection(msckf_ctx* ctx);
 /* Download the selection (any pointer may be NULL), input order: flags[F], idp_m[F*3] and
  * idp_rho[F] as they stand after the refresh, world[F*3] = triangulated point (NaN when the

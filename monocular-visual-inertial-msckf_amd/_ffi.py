@@ -23,7 +23,7 @@ SYMBOLS = [
     "msckf_export_block", "msckf_run_merge_gain", "msckf_export_result", "msckf_import_covariance", "msckf_debug_gate", "msckf_debug_compressed", "msckf_debug_fold_stamps",
     "msckf_device_pointer", "msckf_stream",
     "msckf_set_tracks", "msckf_run_select", "msckf_clear_selection", "msckf_get_selection",
-    "msckf_debug_time_select",
+    "msckf_debug_time_select", "msckf_replan",
     "msckf_propagate", "msckf_augment", "msckf_remove_clones", "msckf_set_poses", "msckf_get_covariance",
 ]
 
@@ -88,7 +88,7 @@ def load():
     lib.msckf_set_state.restype = C.c_int
     lib.msckf_set_features.argtypes = [vp, C.c_int32, _ip, _dp, _ip, _dp, _dp, _dp]
     lib.msckf_set_features.restype = C.c_int
-    for name in ("msckf_run", "msckf_sync", "msckf_run_compress", "msckf_commit_covariance"):
+    for name in ("msckf_run", "msckf_sync", "msckf_run_compress", "msckf_commit_covariance", "msckf_replan"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = C.c_int
     lib.msckf_run_timed.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float)]

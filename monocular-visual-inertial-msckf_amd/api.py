@@ -212,6 +212,10 @@ class UpdateEngine:
         sp.K = (C.c_double * 9)(*np.asarray(K, dtype=np.float64).reshape(9))
         self._check(self._lib.msckf_run_select(self._h, C.byref(sp)), allow_noop=False)
 
+    def replan(self):
+        """Plan the QR tree over the valid features only (syncs; optional after `run_select`)."""
+        self._check(self._lib.msckf_replan(self._h), allow_noop=False)
+
     def clear_selection(self):
         self._check(self._lib.msckf_clear_selection(self._h), allow_noop=False)
 
@@ -390,8 +394,10 @@ class UpdateEngine:
         self.load(prob)
         self.set_tracks(tracks_from_reference(feats))
         self.run_select(select_params_from_reference(filt), prob.K)
-        self.run()
         sel = self.selection()
+        if 0 < int(sel.valid.sum()) < 0.15 * len(feats):
+            self.replan()                      # few valid candidates: a shallower QR tree pays for the sync
+        self.run()
         res = self.result()
         items = list(feats.items())
         for j, (_, ft) in enumerate(items):

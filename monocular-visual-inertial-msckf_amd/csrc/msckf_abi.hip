@@ -105,6 +105,7 @@ struct msckf_ctx {
     float us_total = 0;
     std::vector<int> h_view_sorted;
     std::vector<int> h_view_in;           // view_ptr as the caller gave it (set_tracks permutes with it)
+    std::vector<int> h_fmin, h_fmax;      // first / last slot per sorted feature (msckf_replan)
     bool have_tracks = false, use_select = false;
     msckf_select_params sel_params{};     // of the last msckf_run_select
     std::vector<double> h_cam[4];         // host mirror of cam_R / cam_t / cam_R0 / cam_t0 (clone bookkeeping, f2)
@@ -161,7 +162,7 @@ void invalidate_batch(msckf_ctx* c) {
 // leaf_rows.  Merge levels: consecutive nodes, up to `arity` children as long
 // as the rows to fold fit one LDS batch of the parent window, else two.
 void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
-                const std::vector<int>& view_sorted) {
+                const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     const int F = c->F, N = c->N;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 160;
     const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 6;
@@ -175,21 +176,28 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
         off += (size_t)n.w * (n.w + 1);
         c->nodes.push_back(n);
     };
-    // leaves
+    // leaves (with `valid`, the features k_select masked out carry no rows: they neither count
+    // towards a leaf nor widen its window, and stretches without a valid feature get no leaf)
+    auto live = [&](int i) { return !valid || ((*valid)[i] & 1); };
     int f = 0;
     while (f < F) {
+        while (f < F && !live(f)) ++f;
+        if (f >= F) break;
         int lo = fmin[f], hi = fmax[f];
-        int rows = 0, e = f;
+        int rows = 0, e = f, last = f;
         while (e < F && (e - f) < FOLD_MAX_SRC) {
-            const int r = 2 * (view_sorted[e + 1] - view_sorted[e]);
-            if (e > f && rows + r > leaf_rows) break;
-            rows += r;
-            lo = std::min(lo, fmin[e]);
-            hi = std::max(hi, fmax[e]);
+            if (live(e)) {
+                const int r = 2 * (view_sorted[e + 1] - view_sorted[e]);
+                if (e > f && rows + r > leaf_rows) break;
+                rows += r;
+                lo = std::min(lo, fmin[e]);
+                hi = std::max(hi, fmax[e]);
+                last = e;
+            }
             ++e;
         }
-        push(0, f, e, lo, hi);
-        f = e;
+        push(0, f, last + 1, lo, hi);
+        f = last + 1;
     }
     c->n_leaves = (int)c->nodes.size();
     if (c->n_leaves > 0) c->levels.push_back({0, c->n_leaves});
@@ -406,7 +414,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
     if (c->F > 0 && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
-    if (with_gain && c->F > 0) {
+    if (with_gain && c->F > 0 && c->root >= 0) {
         if ((rc = launch_gain(c, root_block(c))) != MSCKF_OK) return rc;
     }
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[3], c->stream));
@@ -623,6 +631,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
     build_plan(c, h_fmin, h_fmax, h_view);
+    c->h_fmin = h_fmin; c->h_fmax = h_fmax;
     // room for gathered shard blocks behind the plan's blocks
     c->gather_off = c->rbuf_doubles;
     const double t1 = now_us();
@@ -856,6 +865,38 @@ int msckf_run_select(msckf_ctx* c, const msckf_select_params* sp) {
     a.world = ptr<double>(c->dWorld);
     hipLaunchKernelGGL(k_select, dim3((c->F * 8 + 255) / 256), dim3(256), 0, c->stream, a);
     HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+int msckf_replan(msckf_ctx* c) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (!c->use_select || !c->have_features) return MSCKF_ERR_STATE;
+    if (c->F == 0) return MSCKF_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const double t0 = now_us();
+    std::vector<unsigned char> flags(c->F);
+    HIPCHK(c, hipMemcpyAsync(flags.data(), c->dSelFlags.p, c->F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    build_plan(c, c->h_fmin, c->h_fmax, c->h_view_sorted, &flags);
+    c->gather_off = c->rbuf_doubles;
+    if (int rc = ensure(c, c->dNodes, std::max<size_t>(c->nodes.size(), 1) * sizeof(FoldNode))) return rc;
+    // the blocks moved inside the R workspace: entries below their diagonals must read as zero again
+    {
+        const size_t need = (c->rbuf_doubles + 16) * 8;
+        if (c->dRbuf.bytes < need) {
+            if (c->dRbuf.p) HIPCHK(c, hipFree(c->dRbuf.p));
+            c->dRbuf.p = nullptr; c->dRbuf.bytes = 0;
+            HIPCHK(c, hipMalloc(&c->dRbuf.p, need + need / 2));
+            c->dRbuf.bytes = need + need / 2;
+        }
+        HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
+    }
+    if (!c->nodes.empty())
+        HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
+                                 c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->us_host_prep = (float)(now_us() - t0);
+    c->ran = false;
     return MSCKF_OK;
 }
 

@@ -29,6 +29,8 @@ def test_struct_sizes_match_header():
     from msckf_amd import _ffi
     assert C.sizeof(_ffi.Config) == 8 * 4
     assert C.sizeof(_ffi.Stats) == 8 * 4 + 8 * 4
+    assert C.sizeof(_ffi.SelectParamsC) == 6 * 4 + 8 + 9 * 8
+    assert _ffi.SelectParamsC.min_parallax_deg.offset == 24 and _ffi.SelectParamsC.K.offset == 32
 
 
 def test_no_cpu_fallback(engine_lib):

@@ -110,6 +110,33 @@ def test_fused_pass_equals_two_calls(eng):
     assert rel_err(fused.dx, sep.dx) < 1e-11 and rel_err(fused.P_new, sep.P_new) < 1e-12
 
 
+@pytest.mark.parametrize("lost_fraction", [0.5, 0.03, 0.0])
+def test_replan_over_valid_features_only(eng, lost_fraction):
+    """msckf_replan shrinks the QR tree to the valid features; same update, fewer levels."""
+    from msckf_amd import synth
+    prob = synth.make_problem(30, 1500, 10, seed=51)
+    tracks = synth.make_tracks(prob, 51, lost_fraction=lost_fraction)
+    params = synth.SelectParams(use_parallax=False)
+    sel = eng.select_problem(prob, tracks, params)
+    eng.run()
+    full = eng.result()
+    eng.replan()
+    eng.run()
+    again = eng.result()
+    assert again.status == full.status and np.array_equal(again.accepted, full.accepted)
+    assert again.stats["n_leaves"] <= full.stats["n_leaves"]
+    if full.status == 0:
+        assert rel_err(again.dx, full.dx) < 1e-10 and rel_err(again.P_new, full.P_new) < 1e-11
+        if lost_fraction < 0.1:
+            assert again.stats["n_levels"] < full.stats["n_levels"]
+    else:
+        assert not sel.valid.any() and again.stats["n_leaves"] == 0
+    # sharded export after a replan (also the empty tree) stays consistent
+    eng.run_compress()
+    blk, n = eng.export_block()
+    assert n == int(full.accepted.sum()) and np.allclose(np.tril(blk[:, :-1], -1), 0.0)
+
+
 def test_clear_selection_and_call_order(eng):
     from msckf_amd import _ffi
     prob, tracks, params, _ = load_golden_select("sel_default")
