@@ -64,7 +64,7 @@ def pmc_traffic(kernel_prefix):
     return tot / calls if calls else None
 
 
-def cpu_baseline(prob, reps=2):
+def cpu_baseline(prob, reps=10):
     """The oracle (NumPy restatement of the reference path) on this box's host
     cores: reference-faithful per-feature Python loop, SVD nullspace, np.linalg.qr,
     explicit inverses, Joseph form -- minus the dense sigma^2*eye(m) allocation
@@ -77,8 +77,15 @@ def cpu_baseline(prob, reps=2):
         out = oracle.update(prob, dense_noise=False)
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
-    return out, dict(value=1.0 / t, unit="updates/s", cores=os.cpu_count(), kind="port",
-                     sample=f"{reps} full updates of the same workload (median {t:.2f} s each); oracle with "
+    try:                                                    # threads the BLAS / LAPACK calls of the oracle may use
+        from threadpoolctl import threadpool_info
+        cores = max([int(p.get("num_threads", 1)) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    return out, dict(value=1.0 / t, unit="updates/s", cores=cores, kind="port",
+                     sample=f"{reps} full updates of the same workload (median {t:.2f} s each, {sum(ts):.0f} s in all); "
+                            "per-feature stage is a single-threaded Python loop, QR / products use the BLAS "
+                            f"thread pool ({cores} threads, {os.cpu_count()} logical CPUs); oracle with "
                             "R_n = sigma^2 I analytic instead of the reference's dense sigma^2*eye(m)")
 
 

@@ -61,7 +61,12 @@ inline int fold_bmax(int w) {
 struct Buf {
     void* p = nullptr;
     size_t bytes = 0;
+    bool view = false;      // points into an arena: never freed or re-allocated on its own
 };
+
+inline void set_view(Buf& b, void* base, size_t off, size_t bytes) {
+    b.p = static_cast<char*>(base) + off; b.bytes = bytes; b.view = true;
+}
 
 double now_us() {
     using namespace std::chrono;
@@ -109,6 +114,13 @@ struct msckf_ctx {
     bool have_tracks = false, use_select = false;
     msckf_select_params sel_params{};     // of the last msckf_run_select
     std::vector<double> h_cam[4];         // host mirror of cam_R / cam_t / cam_R0 / cam_t0 (clone bookkeeping, f2)
+    // arenas: what travels together lives together, so each direction is ONE copy through pinned memory
+    // (a pageable hipMemcpyAsync costs ~9 us apiece; the 15 + 6 of them were 270 us of the host-inclusive call)
+    Buf dPoseArena, dFeatArena, dResArena, dGateArena;
+    void *hPose = nullptr, *hFeat = nullptr, *hRes = nullptr, *hGate = nullptr, *hP = nullptr;   // pinned staging
+    size_t hFeatCap = 0, res_dx_off = 0, res_p_off = 0;
+    std::vector<double> chi2_cache;
+    bool defer_state_sync = false;        // msckf_update: the feature upload's sync covers the state upload
 };
 
 namespace {
@@ -137,14 +149,16 @@ int ensure(msckf_ctx* c, Buf& b, size_t bytes, bool zero = false) {
 template <typename Tp>
 Tp* ptr(const Buf& b) { return reinterpret_cast<Tp*>(b.p); }
 
-// clone poses: host mirror -> HBM
+// clone poses: host mirror -> pinned arena image -> HBM, one copy
 int upload_poses(msckf_ctx* c) {
-    const size_t N = c->h_cam[1].size() / 3;
+    const size_t N = c->h_cam[1].size() / 3, mN = c->maxN;
     if (N == 0) return MSCKF_OK;
-    HIPCHK(c, hipMemcpyAsync(c->dCamR.p, c->h_cam[0].data(), N * 72, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dCamT.p, c->h_cam[1].data(), N * 24, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dCamR0.p, c->h_cam[2].data(), N * 72, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dCamT0.p, c->h_cam[3].data(), N * 24, hipMemcpyHostToDevice, c->stream));
+    double* h = static_cast<double*>(c->hPose);
+    std::memcpy(h, c->h_cam[0].data(), N * 72);
+    std::memcpy(h + 9 * mN, c->h_cam[1].data(), N * 24);
+    std::memcpy(h + 12 * mN, c->h_cam[2].data(), N * 72);
+    std::memcpy(h + 21 * mN, c->h_cam[3].data(), N * 24);
+    HIPCHK(c, hipMemcpyAsync(c->dPoseArena.p, h, 24 * mN * 8, hipMemcpyHostToDevice, c->stream));
     return MSCKF_OK;
 }
 
@@ -387,20 +401,22 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
 
 // Gate results of the last run, summed on the host:
 // {accepted, stacked rows, not-SPD gate matrices, not selected by k_select}.
-int gate_counts(msckf_ctx* c, int out[4], std::vector<unsigned char>* acc_sorted) {
+int gate_counts(msckf_ctx* c, int out[4], std::vector<unsigned char>* acc_sorted, bool copied = false) {
     out[0] = out[1] = out[2] = out[3] = 0;
     if (c->F == 0) return MSCKF_OK;
-    std::vector<unsigned char> acc(c->F);
-    std::vector<int> rk(c->F);
-    HIPCHK(c, hipMemcpyAsync(acc.data(), c->dAcc.p, c->F, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(rk.data(), c->dRank.p, (size_t)c->F * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t F = c->F;
+    if (!copied) {
+        HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, F * 5, hipMemcpyDeviceToHost, c->stream));   // rank | accepted
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    const int* rk = static_cast<const int*>(c->hGate);
+    const unsigned char* acc = static_cast<const unsigned char*>(c->hGate) + F * 4;
     for (int s = 0; s < c->F; ++s) {
         if (acc[s] == 1) { out[0]++; out[1] += 2 * (c->h_view_sorted[s + 1] - c->h_view_sorted[s]) - rk[s]; }
         else if (acc[s] == 2) out[2]++;
         else if (acc[s] == 3) out[3]++;
     }
-    if (acc_sorted) acc_sorted->swap(acc);
+    if (acc_sorted) acc_sorted->assign(acc, acc + F);
     return MSCKF_OK;
 }
 
@@ -495,15 +511,31 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     const int N = c->maxN, d = 15 + 6 * N, dc = 6 * N;
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
-    E(c->dP, (size_t)d * d * 8); E(c->dPout, (size_t)d * d * 8);
-    E(c->dCamR, (size_t)N * 9 * 8); E(c->dCamT, (size_t)N * 3 * 8);
-    E(c->dCamR0, (size_t)N * 9 * 8); E(c->dCamT0, (size_t)N * 3 * 8);
+    E(c->dP, (size_t)d * d * 8);
+    E(c->dPoseArena, (size_t)24 * N * 8);
+    c->res_dx_off = 64; c->res_p_off = 64 + (size_t)d * 8;
+    E(c->dResArena, c->res_p_off + (size_t)d * d * 8, true);
+    E(c->dGateArena, (size_t)5 * std::max(c->maxF, 1));
+    if (rc == MSCKF_OK) {
+        set_view(c->dCamR, c->dPoseArena.p, 0, (size_t)N * 72);
+        set_view(c->dCamT, c->dPoseArena.p, (size_t)9 * N * 8, (size_t)N * 24);
+        set_view(c->dCamR0, c->dPoseArena.p, (size_t)12 * N * 8, (size_t)N * 72);
+        set_view(c->dCamT0, c->dPoseArena.p, (size_t)21 * N * 8, (size_t)N * 24);
+        set_view(c->dStatus, c->dResArena.p, 0, 64);
+        set_view(c->dDx, c->dResArena.p, c->res_dx_off, (size_t)d * 8);
+        set_view(c->dPout, c->dResArena.p, c->res_p_off, (size_t)d * d * 8);
+        bool ok = hipHostMalloc(&c->hPose, (size_t)24 * N * 8) == hipSuccess &&
+                  hipHostMalloc(&c->hRes, c->res_p_off + (size_t)d * d * 8) == hipSuccess &&
+                  hipHostMalloc(&c->hGate, (size_t)5 * std::max(c->maxF, 1)) == hipSuccess &&
+                  hipHostMalloc(&c->hP, (size_t)d * d * 8) == hipSuccess;
+        if (!ok) rc = MSCKF_ERR_HIP;
+    }
     E(c->dChi2, 1024 * 8);
-    E(c->dKeep, (size_t)d * 4); E(c->dStatus, 64, true);                   // dKeep: index map of msckf_remove_clones
+    E(c->dKeep, (size_t)d * 4);                                            // index map of msckf_remove_clones
     E(c->dY, (size_t)d * dc * 8); E(c->dS, (size_t)dc * dc * 8); E(c->dL, (size_t)dc * dc * 8);
     E(c->dU, (size_t)dc * dc * 8); E(c->dInvd, (size_t)dc * 8); E(c->dK, (size_t)d * dc * 8);
     E(c->dB2, (size_t)d * d * 8); E(c->dD, (size_t)d * dc * 8); E(c->dPn, (size_t)d * d * 8);
-    E(c->dDx, (size_t)d * 8, true); E(c->dCholWork, (size_t)dc * (dc + 1) / 2 * 8);
+    E(c->dCholWork, (size_t)dc * (dc + 1) / 2 * 8);
     if (rc != MSCKF_OK) { msckf_destroy(c); return rc; }
     *out = c;
     return MSCKF_OK;
@@ -518,7 +550,9 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld};
-    for (Buf* b : all) if (b->p) (void)hipFree(b->p);
+    for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
+    for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
+    for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -538,7 +572,8 @@ int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_
     std::memcpy(c->g, gravity, 24);
     std::memcpy(c->Kinv, Kinv, 72);
     const size_t d = c->d;
-    HIPCHK(c, hipMemcpyAsync(c->dP.p, P, d * d * 8, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(c->hP, P, d * d * 8);
+    HIPCHK(c, hipMemcpyAsync(c->dP.p, c->hP, d * d * 8, hipMemcpyHostToDevice, c->stream));
     if (N > 0) {
         c->h_cam[0].assign(cam_R, cam_R + (size_t)N * 9); c->h_cam[1].assign(cam_t, cam_t + (size_t)N * 3);
         c->h_cam[2].assign(cam_R0, cam_R0 + (size_t)N * 9); c->h_cam[3].assign(cam_t0, cam_t0 + (size_t)N * 3);
@@ -546,8 +581,11 @@ int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_
     } else {
         for (auto& v : c->h_cam) v.clear();
     }
-    HIPCHK(c, hipMemcpyAsync(c->dChi2.p, chi2_crit, (size_t)n_crit * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((int)c->chi2_cache.size() != n_crit || std::memcmp(c->chi2_cache.data(), chi2_crit, (size_t)n_crit * 8) != 0) {
+        c->chi2_cache.assign(chi2_crit, chi2_crit + n_crit);           // the table rarely changes between calls
+        HIPCHK(c, hipMemcpyAsync(c->dChi2.p, c->chi2_cache.data(), (size_t)n_crit * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    if (!c->defer_state_sync) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->us_h2d = (float)(now_us() - t0);
     c->have_state = true;
     c->ran = false;
@@ -607,10 +645,29 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
         for (int f = 0; f < F; ++f) c->perm[cnt[(size_t)fmin_in[f] * N + fmax_in[f]]++] = f;
     }
-    // gather into sorted order
-    std::vector<int> h_view(F + 1), h_slot(sumM), h_fmin(F), h_fmax(F);
-    std::vector<double> h_uv((size_t)sumM * 2), h_base((size_t)F * 3), h_m((size_t)F * 3), h_rho(F);
-    std::vector<long long> h_blk(F);
+    // arena layout (8-byte aligned pieces): doubles first, then the 64-bit offsets, then the ints
+    const size_t o_uv = 0, o_base = o_uv + (size_t)sumM * 16, o_m = o_base + (size_t)F * 24, o_rho = o_m + (size_t)F * 24;
+    const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
+    const size_t o_slot = o_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7), o_fmin = o_slot + (((size_t)sumM * 4 + 7) & ~(size_t)7);
+    const size_t feat_bytes = o_fmin + (((size_t)F * 4 + 7) & ~(size_t)7);
+    if (c->hFeatCap < feat_bytes) {
+        if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
+        c->hFeat = nullptr; c->hFeatCap = 0;
+        HIPCHK(c, hipHostMalloc(&c->hFeat, feat_bytes + feat_bytes / 2));
+        c->hFeatCap = feat_bytes + feat_bytes / 2;
+    }
+    if (int rca = ensure(c, c->dFeatArena, feat_bytes)) return rca;
+    char* hb = static_cast<char*>(c->hFeat);
+    double* h_uv = reinterpret_cast<double*>(hb + o_uv);
+    double* h_base = reinterpret_cast<double*>(hb + o_base);
+    double* h_m = reinterpret_cast<double*>(hb + o_m);
+    double* h_rho = reinterpret_cast<double*>(hb + o_rho);
+    long long* h_blk = reinterpret_cast<long long*>(hb + o_blk);
+    int* h_viewp = reinterpret_cast<int*>(hb + o_view);
+    int* h_slot = reinterpret_cast<int*>(hb + o_slot);
+    int* h_fminp = reinterpret_cast<int*>(hb + o_fmin);
+    // gather into sorted order, straight into the pinned image
+    std::vector<int> h_view(F + 1), h_fmin(F), h_fmax(F);
     long long blk = 0;
     int pos = 0;
     for (int sidx = 0; sidx < F; ++sidx) {
@@ -623,11 +680,13 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         std::memcpy(&h_m[(size_t)sidx * 3], &idp_m[(size_t)f * 3], 24);
         h_rho[sidx] = idp_rho[f];
         h_fmin[sidx] = fmin_in[f]; h_fmax[sidx] = fmax_in[f];
+        h_fminp[sidx] = fmin_in[f];
         h_blk[sidx] = blk;
         blk += (long long)(6 * M + 1) * (2 * M);
         pos += M;
     }
     h_view[F] = pos;
+    std::memcpy(h_viewp, h_view.data(), (size_t)(F + 1) * 4);
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
     build_plan(c, h_fmin, h_fmax, h_view);
@@ -637,12 +696,20 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const double t1 = now_us();
     c->us_host_prep = (float)(t1 - t0);
 
+    set_view(c->dObsUV, c->dFeatArena.p, o_uv, (size_t)sumM * 16);
+    set_view(c->dBase, c->dFeatArena.p, o_base, (size_t)F * 24);
+    set_view(c->dMvec, c->dFeatArena.p, o_m, (size_t)F * 24);
+    set_view(c->dRho, c->dFeatArena.p, o_rho, (size_t)F * 8);
+    set_view(c->dBlkOff, c->dFeatArena.p, o_blk, (size_t)F * 8);
+    set_view(c->dViewPtr, c->dFeatArena.p, o_view, (size_t)(F + 1) * 4);
+    set_view(c->dObsSlot, c->dFeatArena.p, o_slot, (size_t)sumM * 4);
+    set_view(c->dFmin, c->dFeatArena.p, o_fmin, (size_t)F * 4);
+    // gate results: rank[F] (int) then accepted[F] (byte), contiguous so they come back in one copy
+    set_view(c->dRank, c->dGateArena.p, 0, (size_t)F * 4);
+    set_view(c->dAcc, c->dGateArena.p, (size_t)F * 4, (size_t)F);
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
-    E(c->dViewPtr, (size_t)(F + 1) * 4); E(c->dObsUV, (size_t)sumM * 16); E(c->dObsSlot, (size_t)sumM * 4);
-    E(c->dBase, (size_t)F * 24); E(c->dMvec, (size_t)F * 24); E(c->dRho, (size_t)F * 8); E(c->dFmin, (size_t)F * 4);
-    E(c->dBlkOff, (size_t)F * 8); E(c->dStack, (size_t)blk * 8); E(c->dRank, (size_t)F * 4);
-    E(c->dAcc, (size_t)F); E(c->dGamma, (size_t)F * 8);
+    E(c->dStack, (size_t)blk * 8); E(c->dGamma, (size_t)F * 8);
     E(c->dNodes, c->nodes.size() * sizeof(FoldNode));
     if (rc != MSCKF_OK) return rc;
     {
@@ -657,14 +724,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         }
         HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->dViewPtr.p, h_view.data(), (size_t)(F + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dObsUV.p, h_uv.data(), (size_t)sumM * 16, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dObsSlot.p, h_slot.data(), (size_t)sumM * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dBase.p, h_base.data(), (size_t)F * 24, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dMvec.p, h_m.data(), (size_t)F * 24, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dRho.p, h_rho.data(), (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dFmin.p, h_fmin.data(), (size_t)F * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dBlkOff.p, h_blk.data(), (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -728,27 +788,34 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     if (!c->ran) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_us();
+    const size_t d = c->d;
+    // gate results and (when the gain stage ran) status | dx | P_out: two copies behind the pipeline, one sync
+    if (c->F > 0) HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, (size_t)c->F * 5, hipMemcpyDeviceToHost, c->stream));
+    if (c->ran_gain) {
+        const size_t bytes = P_out ? c->res_p_off + d * d * 8 : c->res_dx_off + d * 8;
+        HIPCHK(c, hipMemcpyAsync(c->hRes, c->dResArena.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     int counters[4] = {0, 0, 0, 0};
     int status[4] = {0};
     std::vector<unsigned char> acc_sorted;
-    if (int rc0 = gate_counts(c, counters, &acc_sorted)) return rc0;
-    HIPCHK(c, hipMemcpy(status, c->dStatus.p, 16, hipMemcpyDeviceToHost));
+    if (int rc0 = gate_counts(c, counters, &acc_sorted, true)) return rc0;
     const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
-    const size_t d = c->d;
+    if (c->ran_gain && n_acc > 0) std::memcpy(status, c->hRes, 16);
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && status[0] != 0) rc = MSCKF_ERR_NOT_SPD;
     if (accepted && c->F > 0) {
         for (int s = 0; s < c->F; ++s) accepted[c->perm[s]] = (acc_sorted[s] == 1) ? 1 : 0;
     }
+    const char* hres = static_cast<const char*>(c->hRes);
     if (dx) {
-        if (rc == MSCKF_OK && c->ran_gain) HIPCHK(c, hipMemcpy(dx, c->dDx.p, d * 8, hipMemcpyDeviceToHost));
+        if (rc == MSCKF_OK && c->ran_gain) std::memcpy(dx, hres + c->res_dx_off, d * 8);
         else std::memset(dx, 0, d * 8);
     }
     if (P_out) {
         // no-op leaves the covariance untouched (reference early returns MSCKF.py:584-585)
-        const void* src = (rc == MSCKF_OK && c->ran_gain) ? c->dPout.p : c->dP.p;
-        HIPCHK(c, hipMemcpy(P_out, src, d * d * 8, hipMemcpyDeviceToHost));
+        if (rc == MSCKF_OK && c->ran_gain) std::memcpy(P_out, hres + c->res_p_off, d * d * 8);
+        else HIPCHK(c, hipMemcpy(P_out, c->dP.p, d * d * 8, hipMemcpyDeviceToHost));
     }
     c->us_d2h = (float)(now_us() - t0);
     if (st) {
@@ -781,10 +848,12 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
                  const double* idp_base, const double* idp_m, const double* idp_rho, const double* chi2_crit,
                  int32_t n_crit, double* dx, double* P_out, uint8_t* accepted, msckf_stats* stats) {
     if (!c) return MSCKF_ERR_ARG;
+    c->defer_state_sync = F > 0;
     int rc = msckf_set_state(c, N, P, cam_R, cam_t, cam_R0, cam_t0, gravity, Kinv, sigma, chi2_crit, n_crit);
+    c->defer_state_sync = false;
     if (rc != MSCKF_OK) return rc;
     rc = msckf_set_features(c, F, view_ptr, obs_uv, obs_slot, idp_base, idp_m, idp_rho);
-    if (rc != MSCKF_OK) return rc;
+    if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); return rc; }   // the state upload may still be in flight
     if (F == 0) {
         // empty feature dict: the reference returns at MSCKF.py:584-585
         const size_t d = c->d;
