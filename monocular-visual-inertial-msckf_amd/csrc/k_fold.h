@@ -330,7 +330,7 @@ __global__ __launch_bounds__(T) void k_fold_g(FoldArgs p) {
             }
             const double x0 = vb[BMAX];
             sg = row16_sum(sg);
-            if (sg > 0.0) {
+            if (sg > 1e-290) {
                 const double nrm = sqrt(x0 * x0 + sg);
                 const double alpha = (x0 > 0.0) ? -nrm : nrm;
                 const double v0 = x0 - alpha;
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                 }
                 // ---- math -------------------------------------------------------------------
                 double alpha = x0;
-                const bool live = sg > 0.0;                           // uniform: same sigma everywhere
+                const bool live = sg > 1e-290;                        // uniform: same sigma everywhere (below: nrm^2 underflows)
                 if (live) {
                     const double ss = fma(x0, x0, sg);
                     double nrm, beta;

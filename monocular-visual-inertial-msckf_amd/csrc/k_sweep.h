@@ -1,0 +1,301 @@
+// K5, upper part: merging upper-triangular blocks whose clone windows overlap
+// (reference MSCKF.py:594-598, the same QR as k_fold.h, restricted to what is
+// left once every group of equal-first-slot features has been reduced to
+// triangles).  The stacked triangles form a BAND matrix (a track spans at most
+// Mmax consecutive-ish clones), so the final R has band width <= 6 Mmax and a
+// tree of ever wider dense merges (k_fold) wastes a chain of w column steps per
+// level on it.  Here ONE workgroup keeps the band R in LDS and folds the source
+// triangles into it as a systolic pipeline:
+//
+//   * a "fold" eliminates one source triangle (w rows, columns [off, off+w))
+//     against R with one Householder reflector per column, rows held in the
+//     REGISTERS of one wavefront (64 x 64 tile: lane (rq, cq) = (lane & 3, lane >> 2)
+//     owns rows {rq + 4 rr} and local columns {cq + 16 k}; the rhs sits at local
+//     column 63), so the dots reduce over a DPP quad only;
+//   * step i of a fold touches R row off+i and nothing else of R, so fold g+1
+//     may run its step for column c one macro step after fold g ran its own:
+//     NW wavefronts work on NW different folds at NW different columns, one
+//     workgroup barrier per macro step.  The arithmetic is exactly that of
+//     folding the triangles one after the other.
+//   * row r of a triangle comes alive at local column r and the columns left of
+//     the pivot are retired: with the step index cut into chunks of 8 (KK = i / 8)
+//     the live row slots (rr <= 2 KK + 1) and column slots (k >= KK / 2) are
+//     compile-time loop bounds; each wavefront runs its own straight-line
+//     sequence  [idle barriers] [chunk 0 .. chunk 7] [idle barriers] ...  and all
+//     wavefronts execute the same number of barriers (nsteps).
+//   * the rows of the source triangle are fetched two row slots per chunk, one
+//     chunk ahead of their first use; the first two row slots of the NEXT fold are
+//     fetched during the last chunks of the current one.
+//
+// The host (build_plan_band) orders the folds by first column and assigns
+//   t0[g] = max(t0[g-1] + off[g] - off[g-1] + 1,  t0[g-NW] + w[g-NW])
+// (pipeline lag / wavefront reuse).  A fold's tile must cover the envelope of
+// the R rows it meets (ew >= w: columns [off, off+ew) can fill in).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wave_ops.h"
+
+namespace msckf {
+
+struct SweepFold {
+    long long src_off;   // offset (doubles) of the source block in rbuf: row-major w x (w+1), upper triangular
+    int off;             // first column of the source window, local to the node
+    int w;               // rows / columns of the source triangle (<= SWEEP_MAX_W)
+    int ew;              // tile width: columns [off, off+ew) may fill in (w <= ew <= SWEEP_MAX_W)
+    int t0;              // macro step of the fold's first column
+    int pad0, pad1;
+};
+
+struct SweepNode {
+    int fold_begin, fold_end;   // folds [begin, end): fold i runs on wavefront (i - begin) % NW
+    int wtot;                   // columns of the node's R
+    int nsteps;                 // macro steps
+    long long out_off;          // output block in rbuf: row-major wtot x (wtot+1)
+};
+
+struct SweepArgs {
+    const SweepNode* nodes;
+    const SweepFold* folds;
+    int node_base;
+    double* rbuf;
+    long long* stamps;          // optional: 8 ticks per node, may be null
+    int stamp_base;
+    const double* zero;         // a double that reads 0.0 (tail of the workspace)
+};
+
+constexpr int SWEEP_MAX_W = 60;        // widest source / envelope (local column 63 holds the rhs)
+constexpr int SWEEP_RS = 64;           // doubles per R row in LDS: entry (c, col) at [c][col - c], rhs at [c][63]
+constexpr double SWEEP_TINY = 1e-290;  // |column|^2 under this is treated as an exact zero column
+constexpr int SWEEP_VB = 72;           // per-wavefront published column: [rq][16] rows + |column|^2 at [64]
+
+__host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nw) {
+    return ((size_t)wtot * SWEEP_RS + (size_t)nw * (SWEEP_VB + 64)) * 8;
+}
+
+// Sum over the 4 lanes of a DPP quad; every lane of the quad gets the sum.
+__device__ __forceinline__ double quad_sum(double x) {
+    x += dpp_move<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_move<0x4E>(x);    // quad_perm [2,3,0,1]
+    return x;
+}
+
+template <int KK> struct STag { static constexpr int value = KK; };
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SweepNode nd = p.nodes[p.node_base + blockIdx.x];
+    const int t = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+    const int rq = lane & 3;            // row lane: the 4 lanes of a DPP quad
+    const int cq = lane >> 2;           // column lane 0..15
+    double* Rb = smem;                                              // [wtot][SWEEP_RS]
+    double* vb = smem + (size_t)nd.wtot * SWEEP_RS + wv * SWEEP_VB; // published column of this wavefront
+    double* dump = smem + (size_t)nd.wtot * SWEEP_RS + NW * SWEEP_VB + wv * 64 + lane;   // sink of masked writes
+    const int nsteps = __builtin_amdgcn_readfirstlane(nd.nsteps);
+    const int fold_end = __builtin_amdgcn_readfirstlane(nd.fold_end);
+    long long tk0 = 0;
+    if (p.stamps) tk0 = wall_clock64();
+
+    for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
+
+    double a[16][4];
+    double nxt[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[rr][k] = 0.0;
+
+    int tcur = 0;                       // macro steps (= barriers) this wavefront has done
+    int f_off = 0, f_w = 0, f_ew = 0, f_t0 = 0;
+    const double* f_src = p.rbuf;
+    int n_off = 0, n_w = 0, n_ew = 0, n_t0 = 0;
+    const double* n_src = p.rbuf;
+
+    auto read_desc = [&](int fi, int& o_off, int& o_w, int& o_ew, int& o_t0, const double*& o_src) {
+        const SweepFold f = p.folds[fi];
+        o_off = __builtin_amdgcn_readfirstlane(f.off);
+        o_w = __builtin_amdgcn_readfirstlane(f.w);
+        o_ew = __builtin_amdgcn_readfirstlane(f.ew);
+        o_t0 = __builtin_amdgcn_readfirstlane(f.t0);
+        o_src = p.rbuf + f.src_off;
+    };
+    // element (row slot rr, column slot k) of a source triangle; unconditional load from a clamped address
+    // (structural zeros are read from p.zero, a zero double of the workspace: no select after the load, so the
+    //  wait for the data sits at its first use, chunks later)
+    auto load_elem = [&](const double* src, int w, int rr, int k) -> double {
+        const int r = rq + 4 * rr, lc = cq + 16 * k;
+        const bool isr = (k == 3) && (cq == 15);
+        const bool ok = (r < w) && (isr || (lc >= r && lc < w));
+        const int col = isr ? w : lc;
+        const double* q = ok ? src + (r * (w + 1) + col) : p.zero;
+        return *q;
+    };
+    auto fetch_next_head = [&]() {      // row slots 0, 1 of the next fold
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
+    };
+
+    // the owners of local column slot KN publish their column (row slots rr <= RP) with its squared norm
+    auto publish = [&](auto tagk, auto tagr) {
+        constexpr int KN = decltype(tagk)::value;
+        constexpr int RP = decltype(tagr)::value < 15 ? decltype(tagr)::value : 15;
+        if constexpr (KN < 4) {
+            double q0 = 0.0, q1 = 0.0;
+            double* dst = vb + rq * 16;
+#pragma unroll
+            for (int rr = 0; rr <= RP; ++rr) {
+                const double x = a[rr][KN];
+                if (rr & 1) q1 = fma(x, x, q1); else q0 = fma(x, x, q0);
+                dst[rr] = x;
+            }
+            vb[64] = quad_sum(q0 + q1);
+        }
+    };
+
+    auto step = [&](auto tagk, int i) {
+        constexpr int KK = decltype(tagk)::value;
+        constexpr int RMAX = 2 * KK + 1;                  // live row slots (rows <= 8 KK + 7)
+        constexpr int K0 = KK / 2;                        // first live column slot
+        double* Rrow = Rb + (size_t)(f_off + i) * SWEEP_RS;
+        // ---- reads ------------------------------------------------------------------
+        double v[RMAX + 1];
+        {
+            const double* src = vb + rq * 16;
+#pragma unroll
+            for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
+        }
+        const double sg = vb[64];
+        const double x0 = Rrow[0];
+        double rck[4];
+        bool on[4];
+        int idx[4];
+#pragma unroll
+        for (int k = K0; k < 4; ++k) {
+            const int lc = cq + 16 * k;
+            const bool isr = (k == 3) && (cq == 15);      // rhs column
+            on[k] = isr || (lc > i && lc < f_ew);
+            const int dl = lc - i;
+            idx[k] = isr ? 63 : (dl < 0 ? 0 : dl);
+            rck[k] = Rrow[idx[k]];
+        }
+        // ---- reflector scalars (every lane, uniform values) ---------------------------
+        const bool live = sg > SWEEP_TINY;                 // below: nothing to eliminate (nrm^2 would underflow)
+        const double ss = live ? fma(x0, x0, sg) : 1.0;
+        double nrm, beta;
+        if (ss > 1e-200 && ss < 1e200) {
+            const double y = fast_rsqrt(ss);
+            nrm = fast_norm(ss, y);
+            beta = y * fast_rcp(nrm + fabs(x0));
+        } else {
+            nrm = sqrt(ss);
+            beta = 1.0 / (nrm * (nrm + fabs(x0)));
+        }
+        beta = live ? beta : 0.0;
+        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
+        const double v0 = x0 - alpha;
+        // ---- dots, rank-1 update, R row ---------------------------------------------
+#pragma unroll
+        for (int k = K0; k < 4; ++k) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int rr = 0; rr <= RMAX; ++rr) {
+                if (rr & 1) s1 = fma(v[rr], a[rr][k], s1); else s0 = fma(v[rr], a[rr][k], s0);
+            }
+            const double sd = quad_sum(s0 + s1);
+            const double tau = on[k] ? beta * fma(v0, rck[k], sd) : 0.0;
+            const double rnew = fma(-tau, v0, rck[k]);
+#pragma unroll
+            for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
+            double* dst = (on[k] && rq == 0) ? (Rrow + idx[k]) : dump;
+            *dst = rnew;
+        }
+        {
+            double* dst = (lane == 0) ? Rrow : dump;
+            *dst = alpha;
+        }
+        // ---- the owners of the next pivot column publish it ---------------------------
+        const int in = i + 1;
+        if (in < f_w) {
+            if ((in & 7) != 0) {
+                if (cq == (in & 15)) publish(STag<K0>{}, STag<RMAX>{});     // same chunk: (in >> 4) == K0
+            } else {
+                // first column of the next chunk: slot (KK + 1) / 2, column lane 0 or 8, two more row slots
+                constexpr int KN = (KK + 1) / 2;
+                if (cq == ((KK & 1) ? 0 : 8)) publish(STag<KN>{}, STag<RMAX + 2>{});
+            }
+        }
+    };
+
+    // one chunk of 8 columns: fetch the two row slots the chunk's LAST publish needs, then the steps
+    auto chunk = [&](auto tagk, bool have_next) {
+        constexpr int KK = decltype(tagk)::value;
+        if (8 * KK >= f_w) return;
+#pragma unroll
+        for (int rr = 2 * KK + 2; rr <= 2 * KK + 3 && rr < 16; ++rr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (16 * k + 15 >= 4 * rr) a[rr][k] = load_elem(f_src, f_w, rr, k);   // else structurally zero, never read
+            }
+        }
+        if (have_next && KK == max((f_w - 1) / 8 - 1, 0)) fetch_next_head();
+        const int ihi = min(8 * KK + 8, f_w);
+        for (int i = 8 * KK; i < ihi; ++i) {
+            step(tagk, i);
+            __syncthreads();
+            ++tcur;
+        }
+    };
+
+    __syncthreads();                                       // R zeroed
+    int fi = nd.fold_begin + wv;
+    bool have = fi < fold_end;
+    if (have) {
+        read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
+        fetch_next_head();
+    }
+    while (have) {
+        f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
+        while (tcur < f_t0) { __syncthreads(); ++tcur; }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[rr][k] = nxt[rr][k];
+        if (cq == 0) publish(STag<0>{}, STag<1>{});
+        fi += NW;
+        const bool have_next = fi < fold_end;
+        if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
+        chunk(STag<0>{}, have_next);
+        chunk(STag<1>{}, have_next);
+        chunk(STag<2>{}, have_next);
+        chunk(STag<3>{}, have_next);
+        chunk(STag<4>{}, have_next);
+        chunk(STag<5>{}, have_next);
+        chunk(STag<6>{}, have_next);
+        chunk(STag<7>{}, have_next);
+        have = have_next;
+    }
+    while (tcur < nsteps) { __syncthreads(); ++tcur; }
+
+    // ---- flush R: row-major wtot x (wtot+1), entries at and right of the diagonal ----
+    __syncthreads();
+    double* out = p.rbuf + nd.out_off;
+    const int ldo = nd.wtot + 1;
+    for (int c = wv; c < nd.wtot; c += NW) {
+        const double* Rrow = Rb + (size_t)c * SWEEP_RS;
+        for (int col = c + lane; col < nd.wtot; col += 64) {
+            const int dlt = col - c;
+            out[(size_t)c * ldo + col] = (dlt < 63) ? Rrow[dlt] : 0.0;
+        }
+        if (lane == 0) out[(size_t)c * ldo + nd.wtot] = Rrow[63];
+    }
+    if (p.stamps && t == 0) {
+        long long* o = p.stamps + 8 * (p.stamp_base + blockIdx.x);
+        o[0] = 0; o[1] = 0; o[2] = 0; o[3] = wall_clock64() - tk0; o[4] = nd.wtot; o[5] = nd.nsteps;
+    }
+}
+
+}  // namespace msckf

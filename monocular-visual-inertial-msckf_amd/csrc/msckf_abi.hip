@@ -17,6 +17,7 @@
 #include "k_fold.h"
 #include "k_gain.h"
 #include "k_select.h"
+#include "k_sweep.h"
 #include "k_state.h"
 
 using namespace msckf;
@@ -49,6 +50,10 @@ constexpr int SOLVE_WAVES = MSCKF_SOLVE_WAVES;   // wavefronts per workgroup of 
 constexpr int SOLVE_ROWS = MSCKF_SOLVE_ROWS;     // rows of Y per wavefront
 constexpr int FOLDG_T = 512;                     // fallback kernel (R streamed through HBM)
 constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgroup
+#ifndef MSCKF_SWEEP_NW
+#define MSCKF_SWEEP_NW 8
+#endif
+constexpr int SWEEP_NW = MSCKF_SWEEP_NW;         // wavefronts (= concurrent folds) of k_sweep
 constexpr int FOLD_LDS_BYTES = 160 * 1024 - 512;
 
 inline int fold_class(int w) { return (w + 1 <= 64) ? 1 : (w + 1 <= 128) ? 2 : 3; }
@@ -92,7 +97,7 @@ struct msckf_ctx {
     // device buffers
     Buf dP, dPout, dCamR, dCamT, dCamR0, dCamT0, dChi2;
     Buf dViewPtr, dObsUV, dObsSlot, dBase, dMvec, dRho, dFmin, dBlkOff, dStack, dRank, dAcc, dGamma, dKeep;
-    Buf dNodes, dRbuf, dStamps;
+    Buf dNodes, dRbuf, dStamps, dSweepNodes, dSweepFolds;
     Buf dLineBase, dLineDir, dLineConf, dLostFor, dTrackedFor, dSelFlags, dWorld;   // f1 (k_select)
     Buf dY, dS, dL, dU, dInvd, dK, dB2, dD, dPn, dDx, dCholWork, dStatus;
     // host-side plan
@@ -100,6 +105,13 @@ struct msckf_ctx {
     std::vector<FoldNode> nodes;
     std::vector<std::pair<int, int>> levels;   // (node_base, count) per fold launch
     int root = -1;
+    // band plan: leaves per first-slot group (k_fold), group merges and the root as k_sweep pipelines
+    bool band_plan = false;
+    std::vector<SweepNode> snodes;        // [0, n_group_merges) group merges, last = root
+    std::vector<SweepFold> sfolds;
+    int n_group_merges = 0;
+    size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
+    size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
     size_t rbuf_doubles = 0;              // used by the plan
     size_t gather_off = 0;                // region for gathered shard blocks
     int gather_cap = 0;
@@ -246,8 +258,129 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
         c->levels.push_back({lvl_base, lvl_cnt});
     }
     c->root = c->nodes.empty() ? -1 : (int)c->nodes.size() - 1;
+    c->root_off = c->nodes.empty() ? 0 : (size_t)c->nodes.back().out_off;
     c->rbuf_doubles = off;
 }
+
+// ---- band plan ----------------------------------------------------------------
+// Tracks span at most SWEEP_MAX_W / 6 clone slots: the stacked system is a band matrix.
+//   level 0 : leaves never cross a first-slot group (k_fold; every leaf window starts at the group's slot);
+//   level 1 : one k_sweep workgroup per group with several leaves folds the leaf triangles (same first
+//             column -> pipeline lag 1) into the group's triangle;
+//   level 2 : ONE k_sweep workgroup folds the group triangles (first columns 6 slots apart -> lag 7)
+//             into the band R = the root block [T | r_n].
+// Returns false when the batch does not qualify (wide tracks, R band over the LDS budget): tree plan then.
+void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps) {
+    int last = 0;
+    for (int g = begin; g < end; ++g) {
+        int t0 = 0;
+        if (g > begin) t0 = folds[g - 1].t0 + (folds[g].off - folds[g - 1].off) + 1;
+        if (g - begin >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].w);
+        folds[g].t0 = t0;
+        last = std::max(last, t0 + folds[g].w);
+    }
+    *nsteps = last;
+}
+
+bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
+                     const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
+    const int F = c->F, N = c->N, dc = 6 * N;
+    if (c->cfg.flags & 1) return false;                                   // tree plan forced
+    if (sweep_lds_bytes(dc, SWEEP_NW) > (size_t)FOLD_LDS_BYTES) return false;
+    auto live = [&](int i) { return !valid || ((*valid)[i] & 1); };
+    for (int f = 0; f < F; ++f)
+        if (live(f) && 6 * (fmax[f] - fmin[f] + 1) > SWEEP_MAX_W) return false;
+    const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 250;
+    c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear();
+    size_t off = 0;
+    struct Tri { long long src; int lo, w; };
+    std::vector<Tri> group_tri;                                           // one triangle per group, by first slot
+    std::vector<SweepNode> merges;
+    int f = 0;
+    while (f < F) {
+        while (f < F && !live(f)) ++f;
+        if (f >= F) break;
+        const int s = fmin[f];
+        // leaves of this group
+        std::vector<Tri> leaves;
+        while (f < F && (!live(f) || fmin[f] == s)) {
+            if (!live(f)) { ++f; continue; }
+            int hi = fmax[f], rows = 0, e = f, last = f;
+            while (e < F && (e - f) < FOLD_MAX_SRC && (!live(e) || fmin[e] == s)) {
+                if (live(e)) {
+                    const int r = std::max(2 * (view_sorted[e + 1] - view_sorted[e]) - 3, 1);
+                    if (e > f && rows + r > leaf_rows) break;
+                    rows += r;
+                    hi = std::max(hi, fmax[e]);
+                    last = e;
+                }
+                ++e;
+            }
+            FoldNode n{};
+            n.kind = 0; n.src_begin = f; n.src_end = last + 1; n.win_lo = s; n.w = 6 * (hi - s + 1); n.pad = 0;
+            n.out_off = (long long)off;
+            off += (size_t)n.w * (n.w + 1);
+            c->nodes.push_back(n);
+            leaves.push_back({n.out_off, s, n.w});
+            f = last + 1;
+        }
+        if (leaves.size() == 1) { group_tri.push_back(leaves[0]); continue; }
+        SweepNode m{};
+        m.fold_begin = (int)c->sfolds.size();
+        int wtot = 0, env = 0;
+        for (const Tri& l : leaves) {
+            env = std::max(env, l.w);
+            SweepFold sf{}; sf.src_off = l.src; sf.off = 0; sf.w = l.w; sf.ew = env;
+            c->sfolds.push_back(sf);
+            wtot = std::max(wtot, l.w);
+        }
+        m.fold_end = (int)c->sfolds.size();
+        m.wtot = wtot;
+        sweep_schedule(c->sfolds, m.fold_begin, m.fold_end, &m.nsteps);
+        m.out_off = (long long)off;
+        off += (size_t)wtot * (wtot + 1);
+        merges.push_back(m);
+        group_tri.push_back({m.out_off, s, wtot});
+    }
+    c->n_leaves = (int)c->nodes.size();
+    if (c->n_leaves > 0) c->levels.push_back({0, c->n_leaves});
+    c->n_group_merges = (int)merges.size();
+    c->snodes = merges;
+    if (!group_tri.empty()) {
+        SweepNode r{};
+        r.fold_begin = (int)c->sfolds.size();
+        int env = 0;
+        for (const Tri& g : group_tri) {
+            env = std::max(env, 6 * g.lo + g.w);
+            SweepFold sf{}; sf.src_off = g.src; sf.off = 6 * g.lo; sf.w = g.w; sf.ew = env - 6 * g.lo;
+            c->sfolds.push_back(sf);
+        }
+        r.fold_end = (int)c->sfolds.size();
+        r.wtot = dc;
+        sweep_schedule(c->sfolds, r.fold_begin, r.fold_end, &r.nsteps);
+        r.out_off = (long long)off;
+        c->root_off = off;
+        off += (size_t)dc * (dc + 1);
+        c->snodes.push_back(r);
+        c->root = 0;
+    } else {
+        c->root = -1;
+        c->root_off = 0;
+    }
+    c->zero_off = off;
+    off += 16;
+    c->rbuf_doubles = off;
+    return true;
+}
+
+// plan for the current batch: band pipeline when it qualifies, else the tree
+void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
+                const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
+    c->band_plan = build_plan_band(c, fmin, fmax, view_sorted, valid);
+    if (!c->band_plan) { c->snodes.clear(); c->sfolds.clear(); c->n_group_merges = 0; build_plan(c, fmin, fmax, view_sorted, valid); }
+}
+
+int upload_plan(msckf_ctx* c);
 
 int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& levels,
                        const std::vector<FoldNode>& all_nodes) {
@@ -301,6 +434,47 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
         }
     }
     HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+// band plan, levels 1-2: group merges (one workgroup each), then the root sweep
+int launch_sweeps(msckf_ctx* c) {
+    if (c->snodes.empty()) return MSCKF_OK;
+    SweepArgs a{};
+    a.nodes = ptr<SweepNode>(c->dSweepNodes);
+    a.folds = ptr<SweepFold>(c->dSweepFolds);
+    a.rbuf = ptr<double>(c->dRbuf);
+    a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) : nullptr;
+    a.zero = ptr<double>(c->dRbuf) + c->zero_off;          // inside the plan's (zero-initialised, never written) region
+    const dim3 block(64 * SWEEP_NW);
+    if (c->n_group_merges > 0) {
+        int wmax = 0;
+        for (int i = 0; i < c->n_group_merges; ++i) wmax = std::max(wmax, c->snodes[i].wtot);
+        a.node_base = 0;
+        a.stamp_base = (int)c->nodes.size();
+        hipLaunchKernelGGL((k_sweep<SWEEP_NW>), dim3(c->n_group_merges), block, sweep_lds_bytes(wmax, SWEEP_NW), c->stream, a);
+    }
+    a.node_base = c->n_group_merges;
+    a.stamp_base = (int)c->nodes.size() + c->n_group_merges;
+    hipLaunchKernelGGL((k_sweep<SWEEP_NW>), dim3(1), block, sweep_lds_bytes(c->snodes.back().wtot, SWEEP_NW), c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+// node / fold tables of the current plan -> HBM (async on the context's stream)
+int upload_plan(msckf_ctx* c) {
+    if (int rc = ensure(c, c->dNodes, std::max<size_t>(c->nodes.size(), 1) * sizeof(FoldNode))) return rc;
+    if (!c->nodes.empty())
+        HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
+                                 c->stream));
+    if (!c->snodes.empty()) {
+        if (int rc = ensure(c, c->dSweepNodes, c->snodes.size() * sizeof(SweepNode))) return rc;
+        if (int rc = ensure(c, c->dSweepFolds, c->sfolds.size() * sizeof(SweepFold))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dSweepNodes.p, c->snodes.data(), c->snodes.size() * sizeof(SweepNode),
+                                 hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, c->sfolds.data(), c->sfolds.size() * sizeof(SweepFold),
+                                 hipMemcpyHostToDevice, c->stream));
+    }
     return MSCKF_OK;
 }
 
@@ -420,7 +594,7 @@ int gate_counts(msckf_ctx* c, int out[4], std::vector<unsigned char>* acc_sorted
     return MSCKF_OK;
 }
 
-const double* root_block(msckf_ctx* c) { return ptr<double>(c->dRbuf) + c->nodes[c->root].out_off; }
+const double* root_block(msckf_ctx* c) { return ptr<double>(c->dRbuf) + c->root_off; }
 
 int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (!c->have_state || !c->have_features) return MSCKF_ERR_STATE;
@@ -429,6 +603,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if ((rc = launch_feature(c)) != MSCKF_OK) return rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
     if (c->F > 0 && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
+    if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c)) != MSCKF_OK) return rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     if (with_gain && c->F > 0 && c->root >= 0) {
         if ((rc = launch_gain(c, root_block(c))) != MSCKF_OK) return rc;
@@ -500,6 +675,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
 #undef SK
         for (const void* f : sk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              FOLD_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         LDS_MAX_BYTES - 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<24>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -547,7 +724,7 @@ void msckf_destroy(msckf_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
-                  &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dY, &c->dS, &c->dL,
+                  &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dSweepNodes, &c->dSweepFolds, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
@@ -606,7 +783,8 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     c->have_tracks = false;
     c->use_select = false;
     if (F == 0) {
-        c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->root = -1; c->perm.clear();
+        c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->n_group_merges = 0;
+        c->band_plan = false; c->root = -1; c->perm.clear();
         c->have_features = true;
         c->us_host_prep = (float)(now_us() - t0);
         return MSCKF_OK;
@@ -689,7 +867,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     std::memcpy(h_viewp, h_view.data(), (size_t)(F + 1) * 4);
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
-    build_plan(c, h_fmin, h_fmax, h_view);
+    plan_batch(c, h_fmin, h_fmax, h_view);
     c->h_fmin = h_fmin; c->h_fmax = h_fmax;
     // room for gathered shard blocks behind the plan's blocks
     c->gather_off = c->rbuf_doubles;
@@ -710,7 +888,6 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
     E(c->dStack, (size_t)blk * 8); E(c->dGamma, (size_t)F * 8);
-    E(c->dNodes, c->nodes.size() * sizeof(FoldNode));
     if (rc != MSCKF_OK) return rc;
     {
         // the R workspace is zero-initialised once: entries below a block's diagonal are never written
@@ -725,8 +902,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
     }
     HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
-                             c->stream));
+    if (int rcp = upload_plan(c)) return rcp;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->us_h2d += (float)(now_us() - t1);
     c->have_features = true;
@@ -822,7 +998,8 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
         std::memset(st, 0, sizeof(*st));
         st->n_features = c->F - counters[3]; st->n_accepted = n_acc; st->n_rejected = c->F - counters[3] - n_acc;
         st->stacked_rows = counters[1]; st->not_spd = counters[2];
-        st->n_leaves = c->n_leaves; st->n_levels = (int)c->levels.size();
+        st->n_leaves = c->n_leaves;
+        st->n_levels = (int)c->levels.size() + (c->band_plan ? (c->n_group_merges > 0 ? 2 : 1) : 0);
         st->us_total = c->us_total; st->us_feature = c->us_stage[0]; st->us_qr = c->us_stage[1];
         st->us_gain = c->us_stage[2];
         st->us_host_prep = c->us_host_prep; st->us_h2d = c->us_h2d; st->us_d2h = c->us_d2h;
@@ -946,9 +1123,8 @@ int msckf_replan(msckf_ctx* c) {
     std::vector<unsigned char> flags(c->F);
     HIPCHK(c, hipMemcpyAsync(flags.data(), c->dSelFlags.p, c->F, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    build_plan(c, c->h_fmin, c->h_fmax, c->h_view_sorted, &flags);
+    plan_batch(c, c->h_fmin, c->h_fmax, c->h_view_sorted, &flags);
     c->gather_off = c->rbuf_doubles;
-    if (int rc = ensure(c, c->dNodes, std::max<size_t>(c->nodes.size(), 1) * sizeof(FoldNode))) return rc;
     // the blocks moved inside the R workspace: entries below their diagonals must read as zero again
     {
         const size_t need = (c->rbuf_doubles + 16) * 8;
@@ -960,9 +1136,7 @@ int msckf_replan(msckf_ctx* c) {
         }
         HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
     }
-    if (!c->nodes.empty())
-        HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
-                                 c->stream));
+    if (int rcp = upload_plan(c)) return rcp;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->us_host_prep = (float)(now_us() - t0);
     c->ran = false;
@@ -1275,7 +1449,7 @@ int msckf_debug_fold_stamps(msckf_ctx* c, long long* out, int32_t max_nodes) {
         HIPCHK(c, hipMemcpy(out, ptr<long long>(c->dStamps) + 8 * 8192, nf * 64, hipMemcpyDeviceToHost));
         return (int)nf;
     }
-    const size_t n = std::min<size_t>((size_t)max_nodes, c->nodes.size());
+    const size_t n = std::min<size_t>((size_t)max_nodes, c->nodes.size() + c->snodes.size());
     HIPCHK(c, hipMemcpy(out, c->dStamps.p, n * 64, hipMemcpyDeviceToHost));
     return (int)n;
 }
