@@ -69,13 +69,19 @@ constexpr double SWEEP_TINY = 1e-290;  // |column|^2 under this is treated as an
 constexpr int SWEEP_VB = 72;           // per-wavefront published column: [rq][16] rows + |column|^2 at [64]
 
 __host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nw) {
-    return ((size_t)wtot * SWEEP_RS + (size_t)nw * (SWEEP_VB + 64)) * 8;
+    return ((size_t)wtot * SWEEP_RS + (size_t)nw * (SWEEP_VB + 64) + 2) * 8;    // R | published columns | dumps | zero
 }
 
 // Sum over the 4 lanes of a DPP quad; every lane of the quad gets the sum.
+template <int CTRL>
+__device__ __forceinline__ double quad_move(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double quad_sum(double x) {
-    x += dpp_move<0xB1>(x);    // quad_perm [1,0,3,2]
-    x += dpp_move<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += quad_move<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += quad_move<0x4E>(x);    // quad_perm [2,3,0,1]
     return x;
 }
 
@@ -92,13 +98,13 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
     const int cq = lane >> 2;           // column lane 0..15
     double* Rb = smem;                                              // [wtot][SWEEP_RS]
     double* vb = smem + (size_t)nd.wtot * SWEEP_RS + wv * SWEEP_VB; // published column of this wavefront
-    double* dump = smem + (size_t)nd.wtot * SWEEP_RS + NW * SWEEP_VB + wv * 64 + lane;   // sink of masked writes
     const int nsteps = __builtin_amdgcn_readfirstlane(nd.nsteps);
     const int fold_end = __builtin_amdgcn_readfirstlane(nd.fold_end);
     long long tk0 = 0;
     if (p.stamps) tk0 = wall_clock64();
 
     for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
+    if (t < 2) smem[nd.wtot * SWEEP_RS + NW * (SWEEP_VB + 64) + t] = 0.0;
 
     double a[16][4];
     double nxt[2][4];
@@ -156,11 +162,32 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
         }
     };
 
+    // per-lane LDS indices (doubles) of this lane's R entries of the current pivot row, one per column slot:
+    //   ra[k]: where R(c, off + lc) is read  (a word that reads 0.0, stride 0, for columns outside the tile)
+    //   wa[k]: where it is written back      (row lane 0 only; everybody else writes into its dump word)
+    // Both advance by (SWEEP_RS - 1) per step (next row, one column less to the left); the rhs by SWEEP_RS.
+    int ra[4], wa[4], rs[4], ws[4];
+    const int dump_i = nd.wtot * SWEEP_RS + NW * SWEEP_VB + wv * 64 + lane;
+    const int zero_i = nd.wtot * SWEEP_RS + NW * (SWEEP_VB + 64);
+    auto init_addr = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lc = cq + 16 * k;
+            const bool isr = (k == 3) && (cq == 15);
+            const bool valid = isr || lc < f_ew;
+            ra[k] = valid ? f_off * SWEEP_RS + (isr ? 63 : lc) : zero_i;
+            rs[k] = valid ? (isr ? SWEEP_RS : SWEEP_RS - 1) : 0;
+            const bool wr = valid && rq == 0;
+            wa[k] = wr ? ra[k] : dump_i;
+            ws[k] = wr ? rs[k] : 0;
+        }
+    };
+
     auto step = [&](auto tagk, int i) {
         constexpr int KK = decltype(tagk)::value;
         constexpr int RMAX = 2 * KK + 1;                  // live row slots (rows <= 8 KK + 7)
         constexpr int K0 = KK / 2;                        // first live column slot
-        double* Rrow = Rb + (size_t)(f_off + i) * SWEEP_RS;
+        const int rrow = (f_off + i) * SWEEP_RS;          // pivot row of R (uniform)
         // ---- reads ------------------------------------------------------------------
         double v[RMAX + 1];
         {
@@ -169,54 +196,44 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
             for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
         }
         const double sg = vb[64];
-        const double x0 = Rrow[0];
+        const double x0 = smem[rrow];
         double rck[4];
-        bool on[4];
-        int idx[4];
 #pragma unroll
-        for (int k = K0; k < 4; ++k) {
-            const int lc = cq + 16 * k;
-            const bool isr = (k == 3) && (cq == 15);      // rhs column
-            on[k] = isr || (lc > i && lc < f_ew);
-            const int dl = lc - i;
-            idx[k] = isr ? 63 : (dl < 0 ? 0 : dl);
-            rck[k] = Rrow[idx[k]];
-        }
-        // ---- reflector scalars (every lane, uniform values) ---------------------------
-        const bool live = sg > SWEEP_TINY;                 // below: nothing to eliminate (nrm^2 would underflow)
-        const double ss = live ? fma(x0, x0, sg) : 1.0;
-        double nrm, beta;
-        if (ss > 1e-200 && ss < 1e200) {
-            const double y = fast_rsqrt(ss);
-            nrm = fast_norm(ss, y);
-            beta = y * fast_rcp(nrm + fabs(x0));
-        } else {
-            nrm = sqrt(ss);
-            beta = 1.0 / (nrm * (nrm + fabs(x0)));
-        }
-        beta = live ? beta : 0.0;
-        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
-        const double v0 = x0 - alpha;
-        // ---- dots, rank-1 update, R row ---------------------------------------------
-#pragma unroll
-        for (int k = K0; k < 4; ++k) {
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int rr = 0; rr <= RMAX; ++rr) {
-                if (rr & 1) s1 = fma(v[rr], a[rr][k], s1); else s0 = fma(v[rr], a[rr][k], s0);
+        for (int k = K0; k < 4; ++k) rck[k] = smem[ra[k]];
+        const bool act0 = (cq + 16 * K0) > i;             // slot K0: columns left of / at the pivot are retired
+        if (sg > SWEEP_TINY) {                            // wave-uniform; below: nothing to eliminate
+            const double ss = fma(x0, x0, sg);
+            double nrm, beta;
+            if (ss > 1e-200 && ss < 1e200) {
+                const double y = fast_rsqrt(ss);
+                nrm = ss * y;                             // a few 1e-16 relative: the reflector stays orthogonal to that level
+                beta = y * fast_rcp(nrm + fabs(x0));
+            } else {
+                nrm = sqrt(ss);
+                beta = 1.0 / (nrm * (nrm + fabs(x0)));
             }
-            const double sd = quad_sum(s0 + s1);
-            const double tau = on[k] ? beta * fma(v0, rck[k], sd) : 0.0;
-            const double rnew = fma(-tau, v0, rck[k]);
+            const double alpha = (x0 > 0.0) ? -nrm : nrm;
+            const double v0 = x0 - alpha;
+            const double beta0 = act0 ? beta : 0.0;
 #pragma unroll
-            for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
-            double* dst = (on[k] && rq == 0) ? (Rrow + idx[k]) : dump;
-            *dst = rnew;
+            for (int k = K0; k < 4; ++k) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int rr = 0; rr <= RMAX; ++rr) {
+                    if (rr & 1) s1 = fma(v[rr], a[rr][k], s1); else s0 = fma(v[rr], a[rr][k], s0);
+                }
+                const double sd = quad_sum(s0 + s1);
+                const double tau = ((k == K0) ? beta0 : beta) * fma(v0, rck[k], sd);
+                const double rnew = fma(-tau, v0, rck[k]);
+#pragma unroll
+                for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
+                const int dst = (k == K0) ? (act0 ? wa[k] : dump_i) : wa[k];
+                smem[dst] = rnew;
+            }
+            smem[(lane == 0) ? rrow : dump_i] = alpha;
         }
-        {
-            double* dst = (lane == 0) ? Rrow : dump;
-            *dst = alpha;
-        }
+#pragma unroll
+        for (int k = K0; k < 4; ++k) { ra[k] += rs[k]; wa[k] += ws[k]; }
         // ---- the owners of the next pivot column publish it ---------------------------
         const int in = i + 1;
         if (in < f_w) {
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
     while (have) {
         f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
         while (tcur < f_t0) { __syncthreads(); ++tcur; }
+        init_addr();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
