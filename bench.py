@@ -47,7 +47,7 @@ def algorithmic_costs(N, F, M):
                 bytes_A=bytes_inputs + bytes_stack, t_roof_s=t_roof, rows=m)
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_prefixes):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
     same command; raw counters, see the note in profiles/*_summary.md).  None if absent."""
@@ -58,7 +58,7 @@ def pmc_traffic(kernel_prefix):
     d = json.load(open(files[-1]))
     tot, calls = 0.0, 0
     for name, k in d["kernels"].items():
-        if kernel_prefix in name and k["fetch_kb"] is not None and k["write_kb"] is not None:
+        if any(pfx in name for pfx in kernel_prefixes) and k["fetch_kb"] is not None and k["write_kb"] is not None:
             tot += (k["fetch_kb"] + k["write_kb"]) * 1024.0 * k["calls"]
             calls += k["calls"]
     return tot / calls if calls else None
@@ -216,12 +216,13 @@ def main():
             us_qr = stages[1]
             n_lv = max(1, stats.get("n_levels", 1))
             line["roofline"] = {
-                "kernel": "k_fold (K5 QR compression tree, %d launches per update)" % n_lv,
+                "kernel": "K5 QR compression: k_fold leaves + k_sweep group merges and root sweep "
+                          "(%d launches per update)" % n_lv,
                 "bound": "mfma", "unit": "TFLOP/s",
                 "achieved": costs["flops_B"] / (us_qr * 1e-6) / 1e12,
                 "peak": FP64_PEAK_TFLOPS,
                 "frac": costs["flops_B"] / (us_qr * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic("k_fold<"),
+                "traffic": pmc_traffic(("k_fold<", "k_sweep<")),
                 "flops_per_launch": costs["flops_B"] / n_lv,
                 "avg_launch_us": us_qr / n_lv,
             }

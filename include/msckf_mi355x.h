@@ -50,6 +50,9 @@ extern "C" {
 #define MSCKF_ERR_STATE (-5)        /* call order (e.g. run before set_state/set_features)  */
 #define MSCKF_ERR_DUP_SLOT (-6)     /* a track observes the same clone slot twice           */
 
+#define MSCKF_FLAG_TREE_PLAN 1      /* K5: always the merge tree (default: the band pipeline
+                                       whenever every track spans <= 10 clone slots)        */
+
 #define MSCKF_MAX_TRACK 31          /* views per feature (2M+1 rows fit one wavefront)      */
 
 typedef struct msckf_ctx msckf_ctx;
@@ -62,7 +65,7 @@ typedef struct msckf_config {
     int32_t max_track;              /* capacity: M  (<= MSCKF_MAX_TRACK)                    */
     int32_t leaf_rows;              /* 0 = default; target stacked rows per QR leaf         */
     int32_t merge_arity;            /* 0 = default; max children per QR tree node           */
-    int32_t flags;                  /* reserved, 0                                          */
+    int32_t flags;                  /* MSCKF_FLAG_*; 0 = defaults                           */
 } msckf_config;
 
 /* Filled by msckf_get_stats / msckf_update (nullable there). Times are device
@@ -73,7 +76,7 @@ typedef struct msckf_stats {
     int32_t n_rejected;             /* reference counter number_of_residuals_discarded_for_gasting_test, MSCKF.py:578 */
     int32_t stacked_rows;           /* m = sum of q_j over accepted features                */
     int32_t n_leaves;
-    int32_t n_levels;               /* QR tree depth (launches of the fold kernel)          */
+    int32_t n_levels;               /* K5 launches (tree levels, or leaves + group merges + root sweep) */
     int32_t not_spd;                /* per-feature gate matrices that were not SPD          */
     int32_t reserved;
     float us_total;                 /* whole device pipeline                                */

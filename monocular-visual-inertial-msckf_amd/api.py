@@ -72,11 +72,16 @@ class UpdateEngine:
     """One context on one MI355X.  Not thread-safe (one engine per host thread)."""
 
     def __init__(self, max_clones: int = 30, max_features: int = 4096, max_track: int = 30,
-                 device: int = 0, leaf_rows: int = 0, merge_arity: int = 0):
+                 device: int = 0, leaf_rows: int = 0, merge_arity: int = 0, plan: str = "auto"):
+        """plan: "auto" = band pipeline (k_sweep) whenever every track spans <= 10 clone slots and
+        the band R fits LDS, else the merge tree; "tree" = always the merge tree (A/B, tests)."""
         self._lib = _ffi.load()
         if max_track > _ffi.MAX_TRACK:
             raise ValueError(f"max_track {max_track} > {_ffi.MAX_TRACK}")
-        cfg = _ffi.Config(_ffi.ABI_VERSION, device, max_clones, max_features, max_track, leaf_rows, merge_arity, 0)
+        if plan not in ("auto", "tree"):
+            raise ValueError("plan must be 'auto' or 'tree'")
+        cfg = _ffi.Config(_ffi.ABI_VERSION, device, max_clones, max_features, max_track, leaf_rows, merge_arity,
+                          _ffi.FLAG_TREE_PLAN if plan == "tree" else 0)
         h = C.c_void_p()
         rc = self._lib.msckf_create(C.byref(h), C.byref(cfg))
         if rc != 0:

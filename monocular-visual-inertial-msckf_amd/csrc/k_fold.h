@@ -669,7 +669,7 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                     double nrm, beta;
                     if (ss > 1e-200 && ss < 1e200) {
                         const double y = fast_rsqrt(ss);
-                        nrm = fast_norm(ss, y);
+                        nrm = ss * y;                                  // a few 1e-16 relative: the reflector stays orthogonal to that level
                         beta = y * fast_rcp(nrm + fabs(x0));
                     } else {
                         nrm = sqrt(ss);

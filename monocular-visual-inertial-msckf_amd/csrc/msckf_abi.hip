@@ -285,7 +285,7 @@ void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nste
 bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                      const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     const int F = c->F, N = c->N, dc = 6 * N;
-    if (c->cfg.flags & 1) return false;                                   // tree plan forced
+    if (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) return false;                // tree plan forced
     if (sweep_lds_bytes(dc, SWEEP_NW) > (size_t)FOLD_LDS_BYTES) return false;
     auto live = [&](int i) { return !valid || ((*valid)[i] & 1); };
     for (int f = 0; f < F; ++f)

@@ -262,3 +262,50 @@ print('TORCH_INTEROP_OK')
 """ % (ROOT, ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "TORCH_INTEROP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("N,F,M,seed,kw", [
+    (30, 2000, 10, 31, {}),                                        # headline shape: 21 groups, 7 leaves each
+    (20, 500, 8, 32, {"outlier_fraction": 0.1, "outlier_px": 500.0}),
+    (12, 300, 10, 33, {"variable_tracks": True}),                  # ragged windows: envelopes wider than the sources
+    (10, 7, 3, 34, {}),                                            # fewer features than groups, single-row leaves
+    (37, 600, 10, 35, {}),                                         # widest band R that still fits LDS next to the tiles
+])
+def test_band_pipeline_equals_merge_tree(N, F, M, seed, kw):
+    """K5 through the band pipeline (per-group leaves, k_sweep group merges and root sweep) gives the
+    update of the merge tree (k_fold levels) and of the oracle; T differs only by row signs / order."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=seed, **kw)
+    ref = oracle.update(prob, dense_noise=False)
+    out = {}
+    for plan in ("auto", "tree"):
+        with UpdateEngine(max_clones=N, max_features=F, max_track=max(M, 2), plan=plan) as e:
+            res = e.update_problem(prob)
+            T, rn = e.debug_compressed()
+            out[plan] = (res, T, rn)
+    band, tree = out["auto"][0], out["tree"][0]
+    assert band.status == tree.status == ref["status"] == 0
+    assert np.array_equal(band.accepted, tree.accepted)
+    assert rel_err(band.dx, tree.dx) < 1e-10 and rel_err(band.P_new, tree.P_new) < 1e-11
+    assert rel_err(band.dx, ref["dx"]) < TOL and rel_err(band.P_new, ref["P_new"]) < TOL
+    Tb, rb = out["auto"][1:]
+    Tt, rt = out["tree"][1:]
+    assert np.allclose(np.tril(Tb, -1), 0.0)
+    assert rel_err(Tb.T @ Tb, Tt.T @ Tt) < 1e-11 and rel_err(Tb.T @ rb, Tt.T @ rt) < 1e-10
+    # the band plan was taken: its R has no entry further than 6 * span columns right of the diagonal
+    span = int((prob.obs_slot.reshape(-1)[np.asarray(prob.view_ptr[1:]) - 1]
+                - prob.obs_slot.reshape(-1)[np.asarray(prob.view_ptr[:-1])]).max()) + 1
+    assert not np.triu(Tb, 6 * span).any()
+
+
+def test_wide_tracks_fall_back_to_the_tree(eng):
+    """Tracks spanning more than 10 clone slots do not fit the sweep tiles: the merge tree runs."""
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(16, 120, 14, seed=36)
+    ref = oracle.update(prob, dense_noise=False)
+    res = eng.update_problem(prob)
+    assert res.status == 0
+    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
