@@ -28,7 +28,7 @@
 //     fetched during the last chunks of the current one.
 //
 // The host (build_plan_band) orders the folds by first column and assigns
-//   t0[g] = max(t0[g-1] + off[g] - off[g-1] + 1,  t0[g-NW] + w[g-NW])
+//   t0[0] = 1,  t0[g] = max(t0[g-1] + off[g] - off[g-1] + 1,  t0[g-NF] + w[g-NF] + 1)
 // (pipeline lag / wavefront reuse).  A fold's tile must cover the envelope of
 // the R rows it meets (ew >= w: columns [off, off+ew) can fill in).
 #pragma once
@@ -68,8 +68,8 @@ constexpr int SWEEP_RS = 64;           // doubles per R row in LDS: entry (c, co
 constexpr double SWEEP_TINY = 1e-290;  // |column|^2 under this is treated as an exact zero column
 constexpr int SWEEP_VB = 72;           // per-wavefront published column: [rq][16] rows + |column|^2 at [64]
 
-__host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nw) {
-    return ((size_t)wtot * SWEEP_RS + (size_t)nw * (SWEEP_VB + 64) + 2) * 8;    // R | published columns | dumps | zero
+__host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nf, int wpf) {
+    return ((size_t)wtot * SWEEP_RS + (size_t)nf * SWEEP_VB + (size_t)nf * wpf * 64 + 2) * 8;   // R | published columns | dumps | zero
 }
 
 // Sum over the 4 lanes of a DPP quad; every lane of the quad gets the sum.
@@ -87,31 +87,39 @@ __device__ __forceinline__ double quad_sum(double x) {
 
 template <int KK> struct STag { static constexpr int value = KK; };
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
+// NF concurrent folds, WPF wavefronts per fold (only 1 is enabled: splitting a fold's columns over two wavefronts
+// -- 16 per workgroup, half the FMAs each -- measured the same 0.83 us per step: the step is a dependent chain
+// barrier -> LDS -> reflector scalars / dots -> tau -> update -> column norm -> LDS, not an issue-rate limit).
+template <int NF, int WPF>
+__global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
+    static_assert(WPF == 1, "with two wavefronts per fold the pivot R(c,c) is rewritten by one while the other may still read it");
+    constexpr int NW = NF * WPF;        // wavefronts
+    constexpr int CL = 16 * WPF;        // column lanes of a fold
+    constexpr int CS = 64 / CL;         // column slots of a lane
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SweepNode nd = p.nodes[p.node_base + blockIdx.x];
     const int t = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
     const int rq = lane & 3;            // row lane: the 4 lanes of a DPP quad
-    const int cq = lane >> 2;           // column lane 0..15
+    const int fs = wv / WPF;            // fold slot
+    const int cq = (lane >> 2) + 16 * (wv % WPF);   // column lane 0..CL-1
     double* Rb = smem;                                              // [wtot][SWEEP_RS]
-    double* vb = smem + (size_t)nd.wtot * SWEEP_RS + wv * SWEEP_VB; // published column of this wavefront
+    double* vb = smem + (size_t)nd.wtot * SWEEP_RS + fs * SWEEP_VB; // published column of this fold slot
     const int nsteps = __builtin_amdgcn_readfirstlane(nd.nsteps);
     const int fold_end = __builtin_amdgcn_readfirstlane(nd.fold_end);
     long long tk0 = 0;
     if (p.stamps) tk0 = wall_clock64();
 
     for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
-    if (t < 2) smem[nd.wtot * SWEEP_RS + NW * (SWEEP_VB + 64) + t] = 0.0;
+    if (t < 2) smem[nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + t] = 0.0;
 
-    double a[16][4];
-    double nxt[2][4];
+    double a[16][CS];
+    double nxt[2][CS];
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[rr][k] = 0.0;
+        for (int k = 0; k < CS; ++k) a[rr][k] = 0.0;
 
     int tcur = 0;                       // macro steps (= barriers) this wavefront has done
     int f_off = 0, f_w = 0, f_ew = 0, f_t0 = 0;
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
     // (structural zeros are read from p.zero, a zero double of the workspace: no select after the load, so the
     //  wait for the data sits at its first use, chunks later)
     auto load_elem = [&](const double* src, int w, int rr, int k) -> double {
-        const int r = rq + 4 * rr, lc = cq + 16 * k;
-        const bool isr = (k == 3) && (cq == 15);
+        const int r = rq + 4 * rr, lc = cq + CL * k;
+        const bool isr = (k == CS - 1) && (cq == CL - 1);
         const bool ok = (r < w) && (isr || (lc >= r && lc < w));
         const int col = isr ? w : lc;
         const double* q = ok ? src + (r * (w + 1) + col) : p.zero;
@@ -142,23 +150,23 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
+            for (int k = 0; k < CS; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
     };
 
     // the owners of local column slot KN publish their column (row slots rr <= RP) with its squared norm
     auto publish = [&](auto tagk, auto tagr) {
         constexpr int KN = decltype(tagk)::value;
         constexpr int RP = decltype(tagr)::value < 15 ? decltype(tagr)::value : 15;
-        if constexpr (KN < 4) {
-            double q0 = 0.0, q1 = 0.0;
+        if constexpr (KN < CS) {
+            double q4[4] = {0.0, 0.0, 0.0, 0.0};
             double* dst = vb + rq * 16;
 #pragma unroll
             for (int rr = 0; rr <= RP; ++rr) {
                 const double x = a[rr][KN];
-                if (rr & 1) q1 = fma(x, x, q1); else q0 = fma(x, x, q0);
+                q4[rr & 3] = fma(x, x, q4[rr & 3]);
                 dst[rr] = x;
             }
-            vb[64] = quad_sum(q0 + q1);
+            vb[64] = quad_sum((q4[0] + q4[1]) + (q4[2] + q4[3]));
         }
     };
 
@@ -166,14 +174,14 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
     //   ra[k]: where R(c, off + lc) is read  (a word that reads 0.0, stride 0, for columns outside the tile)
     //   wa[k]: where it is written back      (row lane 0 only; everybody else writes into its dump word)
     // Both advance by (SWEEP_RS - 1) per step (next row, one column less to the left); the rhs by SWEEP_RS.
-    int ra[4], wa[4], rs[4], ws[4];
-    const int dump_i = nd.wtot * SWEEP_RS + NW * SWEEP_VB + wv * 64 + lane;
-    const int zero_i = nd.wtot * SWEEP_RS + NW * (SWEEP_VB + 64);
+    int ra[CS], wa[CS], rs[CS], ws[CS];
+    const int dump_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + wv * 64 + lane;
+    const int zero_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64;
     auto init_addr = [&]() {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lc = cq + 16 * k;
-            const bool isr = (k == 3) && (cq == 15);
+        for (int k = 0; k < CS; ++k) {
+            const int lc = cq + CL * k;
+            const bool isr = (k == CS - 1) && (cq == CL - 1);
             const bool valid = isr || lc < f_ew;
             ra[k] = valid ? f_off * SWEEP_RS + (isr ? 63 : lc) : zero_i;
             rs[k] = valid ? (isr ? SWEEP_RS : SWEEP_RS - 1) : 0;
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
     auto step = [&](auto tagk, int i) {
         constexpr int KK = decltype(tagk)::value;
         constexpr int RMAX = 2 * KK + 1;                  // live row slots (rows <= 8 KK + 7)
-        constexpr int K0 = KK / 2;                        // first live column slot
+        constexpr int K0 = (8 * KK) / CL;                 // first live column slot
         const int rrow = (f_off + i) * SWEEP_RS;          // pivot row of R (uniform)
         // ---- reads ------------------------------------------------------------------
         double v[RMAX + 1];
@@ -197,13 +205,24 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
         }
         const double sg = vb[64];
         const double x0 = smem[rrow];
-        double rck[4];
+        double rck[CS], sd[CS];
 #pragma unroll
-        for (int k = K0; k < 4; ++k) rck[k] = smem[ra[k]];
-        const bool act0 = (cq + 16 * K0) > i;             // slot K0: columns left of / at the pivot are retired
-        if (sg > SWEEP_TINY) {                            // wave-uniform; below: nothing to eliminate
+        for (int k = K0; k < CS; ++k) rck[k] = smem[ra[k]];
+        const bool act0 = (cq + CL * K0) > i;             // slot K0: columns left of / at the pivot are retired
+        const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
+        // ---- dots first: they do not depend on the reflector scalars (four partial sums: short chains)
+#pragma unroll
+        for (int k = K0; k < CS; ++k) {
+            double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int rr = 0; rr <= RMAX; ++rr) s4[rr & 3] = fma(v[rr], a[rr][k], s4[rr & 3]);
+            sd[k] = quad_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+        }
+        // ---- reflector scalars (every lane, uniform values) ---------------------------
+        double alpha = x0, beta = 0.0;
+        if (live) {
             const double ss = fma(x0, x0, sg);
-            double nrm, beta;
+            double nrm;
             if (ss > 1e-200 && ss < 1e200) {
                 const double y = fast_rsqrt(ss);
                 nrm = ss * y;                             // a few 1e-16 relative: the reflector stays orthogonal to that level
@@ -212,38 +231,37 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
                 nrm = sqrt(ss);
                 beta = 1.0 / (nrm * (nrm + fabs(x0)));
             }
-            const double alpha = (x0 > 0.0) ? -nrm : nrm;
-            const double v0 = x0 - alpha;
-            const double beta0 = act0 ? beta : 0.0;
-#pragma unroll
-            for (int k = K0; k < 4; ++k) {
-                double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-                for (int rr = 0; rr <= RMAX; ++rr) {
-                    if (rr & 1) s1 = fma(v[rr], a[rr][k], s1); else s0 = fma(v[rr], a[rr][k], s0);
-                }
-                const double sd = quad_sum(s0 + s1);
-                const double tau = ((k == K0) ? beta0 : beta) * fma(v0, rck[k], sd);
+            alpha = (x0 > 0.0) ? -nrm : nrm;
+        }
+        const double v0 = x0 - alpha;
+        const double beta0 = act0 ? beta : 0.0;
+        auto slot = [&](auto tags) {
+            constexpr int k = decltype(tags)::value;
+            if constexpr (k < CS) {
+                const double tau = ((k == K0) ? beta0 : beta) * fma(v0, rck[k], sd[k]);
                 const double rnew = fma(-tau, v0, rck[k]);
 #pragma unroll
                 for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
                 const int dst = (k == K0) ? (act0 ? wa[k] : dump_i) : wa[k];
                 smem[dst] = rnew;
             }
-            smem[(lane == 0) ? rrow : dump_i] = alpha;
-        }
-#pragma unroll
-        for (int k = K0; k < 4; ++k) { ra[k] += rs[k]; wa[k] += ws[k]; }
-        // ---- the owners of the next pivot column publish it ---------------------------
+        };
+        // the slot of the next pivot column first, then its owners publish it while the other slots update
         const int in = i + 1;
-        if (in < f_w) {
-            if ((in & 7) != 0) {
-                if (cq == (in & 15)) publish(STag<K0>{}, STag<RMAX>{});     // same chunk: (in >> 4) == K0
-            } else {
-                // first column of the next chunk: slot (KK + 1) / 2, column lane 0 or 8, two more row slots
-                constexpr int KN = (KK + 1) / 2;
-                if (cq == ((KK & 1) ? 0 : 8)) publish(STag<KN>{}, STag<RMAX + 2>{});
-            }
+        slot(STag<K0>{});
+        if (in < f_w && (in & 7) != 0) {
+            if (cq == (in & (CL - 1))) publish(STag<K0>{}, STag<RMAX>{});         // same chunk: in / CL == K0
+        }
+        slot(STag<K0 + 1>{});
+        slot(STag<K0 + 2>{});
+        slot(STag<K0 + 3>{});
+        smem[(rq == 0 && cq == 0) ? rrow : dump_i] = alpha;
+#pragma unroll
+        for (int k = K0; k < CS; ++k) { ra[k] += rs[k]; wa[k] += ws[k]; }
+        if (in < f_w && (in & 7) == 0) {
+            // first column of the next chunk: slot 8 (KK + 1) / CL, column lane 8 (KK + 1) % CL, two more row slots
+            constexpr int KN = (8 * (KK + 1)) / CL;
+            if (cq == (8 * (KK + 1)) % CL) publish(STag<KN>{}, STag<RMAX + 2>{});
         }
     };
 
@@ -254,8 +272,8 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
 #pragma unroll
         for (int rr = 2 * KK + 2; rr <= 2 * KK + 3 && rr < 16; ++rr) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (16 * k + 15 >= 4 * rr) a[rr][k] = load_elem(f_src, f_w, rr, k);   // else structurally zero, never read
+            for (int k = 0; k < CS; ++k) {
+                if (CL * k + CL - 1 >= 4 * rr) a[rr][k] = load_elem(f_src, f_w, rr, k);   // else structurally zero, never read
             }
         }
         if (have_next && KK == max((f_w - 1) / 8 - 1, 0)) fetch_next_head();
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
     };
 
     __syncthreads();                                       // R zeroed
-    int fi = nd.fold_begin + wv;
+    int fi = nd.fold_begin + fs;
     bool have = fi < fold_end;
     if (have) {
         read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
@@ -276,14 +294,16 @@ __global__ __launch_bounds__(64 * NW) void k_sweep(SweepArgs p) {
     }
     while (have) {
         f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
-        while (tcur < f_t0) { __syncthreads(); ++tcur; }
+        while (tcur < f_t0 - 1) { __syncthreads(); ++tcur; }
         init_addr();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[rr][k] = nxt[rr][k];
+            for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
         if (cq == 0) publish(STag<0>{}, STag<1>{});
-        fi += NW;
+        __syncthreads();                                   // column 0 is visible to the fold's other wavefront
+        ++tcur;                                            // (the host schedules t0 >= 1 and one spare step per slot reuse)
+        fi += NF;
         const bool have_next = fi < fold_end;
         if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
         chunk(STag<0>{}, have_next);

@@ -53,7 +53,11 @@ constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgrou
 #ifndef MSCKF_SWEEP_NW
 #define MSCKF_SWEEP_NW 8
 #endif
-constexpr int SWEEP_NW = MSCKF_SWEEP_NW;         // wavefronts (= concurrent folds) of k_sweep
+#ifndef MSCKF_SWEEP_WPF
+#define MSCKF_SWEEP_WPF 1
+#endif
+constexpr int SWEEP_NW = MSCKF_SWEEP_NW;         // concurrent folds of k_sweep
+constexpr int SWEEP_WPF = MSCKF_SWEEP_WPF;       // wavefronts per fold (1 or 2)
 constexpr int FOLD_LDS_BYTES = 160 * 1024 - 512;
 
 inline int fold_class(int w) { return (w + 1 <= 64) ? 1 : (w + 1 <= 128) ? 2 : 3; }
@@ -273,9 +277,9 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
 void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps) {
     int last = 0;
     for (int g = begin; g < end; ++g) {
-        int t0 = 0;
+        int t0 = 1;                                        // step t0 - 1 publishes the fold's first column
         if (g > begin) t0 = folds[g - 1].t0 + (folds[g].off - folds[g - 1].off) + 1;
-        if (g - begin >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].w);
+        if (g - begin >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].w + 1);
         folds[g].t0 = t0;
         last = std::max(last, t0 + folds[g].w);
     }
@@ -286,7 +290,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
                      const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     const int F = c->F, N = c->N, dc = 6 * N;
     if (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) return false;                // tree plan forced
-    if (sweep_lds_bytes(dc, SWEEP_NW) > (size_t)FOLD_LDS_BYTES) return false;
+    if (sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF) > (size_t)FOLD_LDS_BYTES) return false;
     auto live = [&](int i) { return !valid || ((*valid)[i] & 1); };
     for (int f = 0; f < F; ++f)
         if (live(f) && 6 * (fmax[f] - fmin[f] + 1) > SWEEP_MAX_W) return false;
@@ -446,17 +450,17 @@ int launch_sweeps(msckf_ctx* c) {
     a.rbuf = ptr<double>(c->dRbuf);
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) : nullptr;
     a.zero = ptr<double>(c->dRbuf) + c->zero_off;          // inside the plan's (zero-initialised, never written) region
-    const dim3 block(64 * SWEEP_NW);
+    const dim3 block(64 * SWEEP_NW * SWEEP_WPF);
     if (c->n_group_merges > 0) {
         int wmax = 0;
         for (int i = 0; i < c->n_group_merges; ++i) wmax = std::max(wmax, c->snodes[i].wtot);
         a.node_base = 0;
         a.stamp_base = (int)c->nodes.size();
-        hipLaunchKernelGGL((k_sweep<SWEEP_NW>), dim3(c->n_group_merges), block, sweep_lds_bytes(wmax, SWEEP_NW), c->stream, a);
+        hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(c->n_group_merges), block, sweep_lds_bytes(wmax, SWEEP_NW, SWEEP_WPF), c->stream, a);
     }
     a.node_base = c->n_group_merges;
     a.stamp_base = (int)c->nodes.size() + c->n_group_merges;
-    hipLaunchKernelGGL((k_sweep<SWEEP_NW>), dim3(1), block, sweep_lds_bytes(c->snodes.back().wtot, SWEEP_NW), c->stream, a);
+    hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(1), block, sweep_lds_bytes(c->snodes.back().wtot, SWEEP_NW, SWEEP_WPF), c->stream, a);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -675,7 +679,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
 #undef SK
         for (const void* f : sk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               FOLD_LDS_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         LDS_MAX_BYTES - 1024);
