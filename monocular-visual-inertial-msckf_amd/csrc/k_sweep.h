@@ -87,6 +87,12 @@ __device__ __forceinline__ double quad_sum(double x) {
 
 template <int KK> struct STag { static constexpr int value = KK; };
 
+#ifdef SWEEP_PROF
+#define SWEEP_TICK(slot) do { const long long tn_ = __builtin_readcyclecounter(); prof[slot] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define SWEEP_TICK(slot) do { } while (0)
+#endif
+
 // NF concurrent folds, WPF wavefronts per fold (only 1 is enabled: splitting a fold's columns over two wavefronts
 // -- 16 per workgroup, half the FMAs each -- measured the same 0.83 us per step: the step is a dependent chain
 // barrier -> LDS -> reflector scalars / dots -> tau -> update -> column norm -> LDS, not an issue-rate limit).
@@ -122,6 +128,10 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         for (int k = 0; k < CS; ++k) a[rr][k] = 0.0;
 
     int tcur = 0;                       // macro steps (= barriers) this wavefront has done
+#ifdef SWEEP_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = __builtin_readcyclecounter();
+#endif
     int f_off = 0, f_w = 0, f_ew = 0, f_t0 = 0;
     const double* f_src = p.rbuf;
     int n_off = 0, n_w = 0, n_ew = 0, n_t0 = 0;
@@ -210,6 +220,9 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         for (int k = K0; k < CS; ++k) rck[k] = smem[ra[k]];
         const bool act0 = (cq + CL * K0) > i;             // slot K0: columns left of / at the pivot are retired
         const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
+#ifdef SWEEP_PROF
+        if (live) SWEEP_TICK(1);                            // LDS data arrived (the branch forces the wait)
+#endif
         // ---- dots first: they do not depend on the reflector scalars (four partial sums: short chains)
 #pragma unroll
         for (int k = K0; k < CS; ++k) {
@@ -218,6 +231,9 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             for (int rr = 0; rr <= RMAX; ++rr) s4[rr & 3] = fma(v[rr], a[rr][k], s4[rr & 3]);
             sd[k] = quad_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
         }
+#ifdef SWEEP_PROF
+        if (sd[CS - 1] != 1.2345e300) SWEEP_TICK(2);        // dots + quad sums done
+#endif
         // ---- reflector scalars (every lane, uniform values) ---------------------------
         double alpha = x0, beta = 0.0;
         if (live) {
@@ -234,6 +250,9 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             alpha = (x0 > 0.0) ? -nrm : nrm;
         }
         const double v0 = x0 - alpha;
+#ifdef SWEEP_PROF
+        if (beta != 1.2345e300) SWEEP_TICK(3);              // scalar chain done
+#endif
         const double beta0 = act0 ? beta : 0.0;
         auto slot = [&](auto tags) {
             constexpr int k = decltype(tags)::value;
@@ -279,8 +298,14 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         if (have_next && KK == max((f_w - 1) / 8 - 1, 0)) fetch_next_head();
         const int ihi = min(8 * KK + 8, f_w);
         for (int i = 8 * KK; i < ihi; ++i) {
+            SWEEP_TICK(0);                                 // left the barrier
             step(tagk, i);
+#ifdef SWEEP_PROF
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the tick sees the LDS writes out
+#endif
+            SWEEP_TICK(4);                                 // updates, R writes, publish issued
             __syncthreads();
+            SWEEP_TICK(5);                                 // barrier wait
             ++tcur;
         }
     };
@@ -334,6 +359,12 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         long long* o = p.stamps + 8 * (p.stamp_base + blockIdx.x);
         o[0] = 0; o[1] = 0; o[2] = 0; o[3] = wall_clock64() - tk0; o[4] = nd.wtot; o[5] = nd.nsteps;
     }
+#ifdef SWEEP_PROF
+    if (p.stamps && lane == 0 && blockIdx.x == 0) {
+        long long* o = p.stamps + 16 * 8192 + 8 * wv;
+        for (int q = 0; q < 8; ++q) o[q] = prof[q];
+    }
+#endif
 }
 
 }  // namespace msckf

@@ -114,6 +114,7 @@ struct msckf_ctx {
     std::vector<SweepNode> snodes;        // [0, n_group_merges) group merges, last = root
     std::vector<SweepFold> sfolds;
     int n_group_merges = 0;
+    std::vector<std::pair<int, int>> sweep_levels;   // (node_base, count) per group-merge launch
     size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
     size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
     size_t rbuf_doubles = 0;              // used by the plan
@@ -299,7 +300,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     size_t off = 0;
     struct Tri { long long src; int lo, w; };
     std::vector<Tri> group_tri;                                           // one triangle per group, by first slot
-    std::vector<SweepNode> merges;
+    std::vector<std::vector<SweepNode>> merge_levels;                     // [level] -> nodes of every group at that depth
     int f = 0;
     while (f < F) {
         while (f < F && !live(f)) ++f;
@@ -328,28 +329,49 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             leaves.push_back({n.out_off, s, n.w});
             f = last + 1;
         }
-        if (leaves.size() == 1) { group_tri.push_back(leaves[0]); continue; }
-        SweepNode m{};
-        m.fold_begin = (int)c->sfolds.size();
-        int wtot = 0, env = 0;
-        for (const Tri& l : leaves) {
-            env = std::max(env, l.w);
-            SweepFold sf{}; sf.src_off = l.src; sf.off = 0; sf.w = l.w; sf.ew = env;
-            c->sfolds.push_back(sf);
-            wtot = std::max(wtot, l.w);
+        // merge levels of this group: one k_sweep node folds up to 2 * SWEEP_NW triangles (two rounds of the
+        // fold slots); larger groups first reduce chunks of SWEEP_NW triangles in parallel workgroups
+        std::vector<Tri> cur = leaves;
+        auto merge_node = [&](size_t b, size_t e, int level) -> Tri {
+            SweepNode m{};
+            m.fold_begin = (int)c->sfolds.size();
+            int wtot = 0, env = 0;
+            for (size_t i = b; i < e; ++i) {
+                env = std::max(env, cur[i].w);
+                SweepFold sf{}; sf.src_off = cur[i].src; sf.off = 0; sf.w = cur[i].w; sf.ew = env;
+                c->sfolds.push_back(sf);
+                wtot = std::max(wtot, cur[i].w);
+            }
+            m.fold_end = (int)c->sfolds.size();
+            m.wtot = wtot;
+            sweep_schedule(c->sfolds, m.fold_begin, m.fold_end, &m.nsteps);
+            m.out_off = (long long)off;
+            off += (size_t)wtot * (wtot + 1);
+            if ((int)merge_levels.size() <= level) merge_levels.resize(level + 1);
+            merge_levels[level].push_back(m);
+            return Tri{m.out_off, s, wtot};
+        };
+        int level = 0;
+        while (cur.size() > (size_t)(2 * SWEEP_NW)) {
+            std::vector<Tri> nxt;
+            for (size_t b = 0; b < cur.size(); b += SWEEP_NW) {
+                const size_t e = std::min(cur.size(), b + SWEEP_NW);
+                nxt.push_back(e - b == 1 ? cur[b] : merge_node(b, e, level));
+            }
+            cur.swap(nxt);
+            ++level;
         }
-        m.fold_end = (int)c->sfolds.size();
-        m.wtot = wtot;
-        sweep_schedule(c->sfolds, m.fold_begin, m.fold_end, &m.nsteps);
-        m.out_off = (long long)off;
-        off += (size_t)wtot * (wtot + 1);
-        merges.push_back(m);
-        group_tri.push_back({m.out_off, s, wtot});
+        if (cur.size() > 1) { const Tri tmerged = merge_node(0, cur.size(), level); cur.assign(1, tmerged); }
+        group_tri.push_back(cur[0]);
     }
     c->n_leaves = (int)c->nodes.size();
     if (c->n_leaves > 0) c->levels.push_back({0, c->n_leaves});
-    c->n_group_merges = (int)merges.size();
-    c->snodes = merges;
+    c->sweep_levels.clear();
+    for (const auto& lv : merge_levels) {
+        c->sweep_levels.push_back({(int)c->snodes.size(), (int)lv.size()});
+        c->snodes.insert(c->snodes.end(), lv.begin(), lv.end());
+    }
+    c->n_group_merges = (int)c->snodes.size();
     if (!group_tri.empty()) {
         SweepNode r{};
         r.fold_begin = (int)c->sfolds.size();
@@ -381,7 +403,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
 void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     c->band_plan = build_plan_band(c, fmin, fmax, view_sorted, valid);
-    if (!c->band_plan) { c->snodes.clear(); c->sfolds.clear(); c->n_group_merges = 0; build_plan(c, fmin, fmax, view_sorted, valid); }
+    if (!c->band_plan) { c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0; build_plan(c, fmin, fmax, view_sorted, valid); }
 }
 
 int upload_plan(msckf_ctx* c);
@@ -451,12 +473,12 @@ int launch_sweeps(msckf_ctx* c) {
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) : nullptr;
     a.zero = ptr<double>(c->dRbuf) + c->zero_off;          // inside the plan's (zero-initialised, never written) region
     const dim3 block(64 * SWEEP_NW * SWEEP_WPF);
-    if (c->n_group_merges > 0) {
+    for (const auto& lv : c->sweep_levels) {
         int wmax = 0;
-        for (int i = 0; i < c->n_group_merges; ++i) wmax = std::max(wmax, c->snodes[i].wtot);
-        a.node_base = 0;
-        a.stamp_base = (int)c->nodes.size();
-        hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(c->n_group_merges), block, sweep_lds_bytes(wmax, SWEEP_NW, SWEEP_WPF), c->stream, a);
+        for (int i = lv.first; i < lv.first + lv.second; ++i) wmax = std::max(wmax, c->snodes[i].wtot);
+        a.node_base = lv.first;
+        a.stamp_base = (int)c->nodes.size() + lv.first;
+        hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(lv.second), block, sweep_lds_bytes(wmax, SWEEP_NW, SWEEP_WPF), c->stream, a);
     }
     a.node_base = c->n_group_merges;
     a.stamp_base = (int)c->nodes.size() + c->n_group_merges;
@@ -787,7 +809,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     c->have_tracks = false;
     c->use_select = false;
     if (F == 0) {
-        c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->n_group_merges = 0;
+        c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->band_plan = false; c->root = -1; c->perm.clear();
         c->have_features = true;
         c->us_host_prep = (float)(now_us() - t0);
@@ -1003,7 +1025,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
         st->n_features = c->F - counters[3]; st->n_accepted = n_acc; st->n_rejected = c->F - counters[3] - n_acc;
         st->stacked_rows = counters[1]; st->not_spd = counters[2];
         st->n_leaves = c->n_leaves;
-        st->n_levels = (int)c->levels.size() + (c->band_plan ? (c->n_group_merges > 0 ? 2 : 1) : 0);
+        st->n_levels = (int)c->levels.size() + (c->band_plan ? (int)c->sweep_levels.size() + 1 : 0);
         st->us_total = c->us_total; st->us_feature = c->us_stage[0]; st->us_qr = c->us_stage[1];
         st->us_gain = c->us_stage[2];
         st->us_host_prep = c->us_host_prep; st->us_h2d = c->us_h2d; st->us_d2h = c->us_d2h;
