@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_solve(SolveArgs s) {
 }
 
 // Register-resident tiled Cholesky for n <= 4 * CHOL_TILE_MAX_NT.  The whole lower triangle lives
-// in registers as 4x4 tiles (tile e = t + T*s of the row-major enumeration of the lower tiles, up
+// in registers as 4x4 tiles (tile e = t + T*s of a column-wise enumeration of the lower tiles, last column first, up
 // to three per thread), so the trailing update reads only the current 4-column panel from LDS
 // (32 doubles per tile and step) and never re-reads or re-writes the matrix itself -- the LDS
 // traffic of the packed-triangle version (k_chol_blk: 80 LDS operations per tile and step, 79 of
@@ -237,10 +237,15 @@ __global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
         const int e = t + T * s;
         ti[s] = -1; tj[s] = -1;
         if (e < ntile) {
-            int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-            while (r * (r + 1) / 2 > e) --r;
-            while ((r + 1) * (r + 2) / 2 <= e) ++r;
-            ti[s] = r; tj[s] = e - r * (r + 1) / 2;
+            // Tiles are enumerated column by column from the LAST column backwards (column nt-1-m starts at
+            // m (m + 1) / 2): a tile (i, j) is live while k < j, so at every step the live tiles are exactly the
+            // first A_k = (nt-k-1)(nt-k)/2 of the enumeration -- packed into the lowest register slots of all
+            // threads (61 slot-steps per wavefront instead of 121 with a row-major order) -- and the panel of
+            // step k is one run of consecutive threads (one or two wavefronts execute the panel solve, not all).
+            int m = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+            while (m * (m + 1) / 2 > e) --m;
+            while ((m + 1) * (m + 2) / 2 <= e) ++m;
+            tj[s] = nt - 1 - m; ti[s] = tj[s] + (e - m * (m + 1) / 2);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -314,8 +319,17 @@ __global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
                 d[u][v] = x;
             }
     };
-    if (t == 0) factor_diag(a[0], 0);              // tile (0, 0) is e = 0
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (ti[s] == 0 && tj[s] == 0) factor_diag(a[s], 0);
     __syncthreads();
+#ifdef CHOL_PROF
+    long long pc[6] = {0, 0, 0, 0, 0, 0};
+    long long tp = __builtin_readcyclecounter();
+#define CHOL_TICK(q) do { const long long tn_ = __builtin_readcyclecounter(); pc[q] += tn_ - tp; tp = tn_; } while (0)
+#else
+#define CHOL_TICK(q) do { } while (0)
+#endif
     for (int k = 0; k < nt; ++k) {
         if (sBad) break;                           // uniform: read after a barrier
         // ---- P(k): the panel below the diagonal tile -------------------------------------
@@ -336,7 +350,9 @@ __global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
                 }
             }
         }
+        CHOL_TICK(0);
         __syncthreads();
+        CHOL_TICK(1);
         // ---- T(k): trailing update, next diagonal tile first ----------------------------------
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -345,12 +361,19 @@ __global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
                 factor_diag(a[s], k + 1);
             }
         }
+        CHOL_TICK(2);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (tj[s] > k && !(ti[s] == k + 1 && tj[s] == k + 1)) update_tile(a[s], ti[s], tj[s]);
         }
+        CHOL_TICK(3);
         __syncthreads();
+        CHOL_TICK(4);
     }
+#ifdef CHOL_PROF
+    if ((t & 63) == 0) printf("chol wave %d: panel %lld  bar1 %lld  diag %lld  trailing %lld  bar2 %lld (cycles, %d steps)\n", t >> 6,
+                              pc[0], pc[1], pc[2], pc[3], pc[4], nt);
+#endif
     if (sBad) { if (t == 0) c.status[0] = 1; return; }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {

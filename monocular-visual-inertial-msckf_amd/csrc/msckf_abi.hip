@@ -40,6 +40,10 @@ constexpr int FOLD_CPT3 = (192 + FOLD_NCG - 1) / FOLD_NCG;
 constexpr int FOLD_RPT_LEAF = ((160 / FOLD_RL + 3) / 4) * 4;   // <= 160-row leaves
 constexpr int FOLD_RPT_BIG = 256 / FOLD_RL;                     // 256-row batches (W1, W2)
 constexpr int FOLD_RPT_W3 = 192 / FOLD_RL;                      // 192-row batches (W3)
+#ifndef MSCKF_CHOL_T
+#define MSCKF_CHOL_T 768
+#endif
+constexpr int CHOL_T = MSCKF_CHOL_T;             // threads of the register-tiled Cholesky
 #ifndef MSCKF_SOLVE_WAVES
 #define MSCKF_SOLVE_WAVES 8
 #endif
@@ -557,7 +561,7 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         a.n = dc; a.work = ptr<double>(c->dCholWork); a.status = ptr<int>(c->dStatus);
         if (dc <= 4 * CHOL_TILE_MAX_NT) {
             packed_L = true;
-            hipLaunchKernelGGL((k_chol_tile<512>), dim3(1), dim3(512), 0, c->stream, a);   // matrix in registers
+            hipLaunchKernelGGL((k_chol_tile<CHOL_T>), dim3(1), dim3(CHOL_T), 0, c->stream, a);   // matrix in registers
         } else {
             const size_t need = (size_t)dc * (dc + 1) / 2 * 8;
             a.use_lds = need <= (size_t)(LDS_MAX_BYTES - 1024) ? 1 : 0;
