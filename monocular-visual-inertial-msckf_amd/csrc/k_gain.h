@@ -357,8 +357,13 @@ __global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (ti[s] == k + 1 && tj[s] == k + 1) {
+                // the chain every other wavefront ends up waiting for: issue it ahead of the co-resident
+                // wavefronts' trailing updates (without the priority its ~90 dependent FP64 instructions
+                // took 4000 cycles per step, most of them waiting for an issue slot)
+                __builtin_amdgcn_s_setprio(3);
                 update_diag_tile(a[s], k + 1);
                 factor_diag(a[s], k + 1);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
         CHOL_TICK(2);
