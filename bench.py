@@ -154,21 +154,30 @@ def main():
         eng.load(local)
         nblk = eng.block_doubles()
         d = prob.d
-        mine = torch.zeros(nblk, dtype=torch.float64, device="cuda")
-        gathered = torch.zeros(world * nblk, dtype=torch.float64, device="cuda") if rank == 0 else None
-        glist = list(gathered.view(world, nblk).unbind(0)) if rank == 0 else None
-        nacc = torch.zeros(1, dtype=torch.int64, device="cuda")
+        # send buffer: the block [R | Q^T r] plus one trailing double, the shard's accepted count (it rides
+        # with the gather instead of a second collective); rank 0 receives `world` such records
+        rec = nblk + 1
+        mine = torch.zeros(rec, dtype=torch.float64, device="cuda")
+        gathered = torch.zeros(world * rec, dtype=torch.float64, device="cuda") if rank == 0 else None
+        glist = list(gathered.view(world, rec).unbind(0)) if rank == 0 else None
+        packed = torch.zeros(world * nblk, dtype=torch.float64, device="cuda") if rank == 0 and world > 1 else None
         out = torch.zeros(d + d * d, dtype=torch.float64, device="cuda")
 
         def step():
             eng.run_compress()                                   # K1-K5 on the local shard
             _, n = eng.export_block(dst_ptr=mine.data_ptr())     # D2D into the torch-owned send buffer (syncs)
-            nacc[0] = n
+            mine[nblk] = float(n)
             dist.gather(mine, gather_list=glist, dst=0)          # ONE RCCL gather of the R blocks
-            dist.all_reduce(nacc)
-            torch.cuda.synchronize()
             if rank == 0:
-                eng.merge_gain(int(gathered.data_ptr()), int(nacc.item()), n_blocks=world)
+                g2 = gathered.view(world, rec)
+                total = int(g2[:, nblk].sum().item())            # syncs: the gather has landed
+                if world > 1:
+                    packed.view(world, nblk).copy_(g2[:, :nblk])   # contiguous blocks for the merge
+                    torch.cuda.current_stream().synchronize()      # the engine works on its own stream
+                    src = packed
+                else:
+                    src = gathered
+                eng.merge_gain(int(src.data_ptr()), total, n_blocks=world)
                 eng.sync()
                 eng.export_result(out.data_ptr(), out.data_ptr() + d * 8)   # dx | P+ -> broadcast buffer (D2D)
             dist.broadcast(out, src=0)                           # state for the next update on every rank
