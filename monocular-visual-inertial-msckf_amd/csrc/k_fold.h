@@ -58,6 +58,7 @@ struct FoldArgs {
 };
 
 constexpr int FOLD_MAX_SRC = 1024;   // sources per node the LDS bookkeeping can hold
+constexpr int STAGE_U = 4;           // loads in flight per lane while a leaf stages one K4 block
 
 // LDS carve-up of k_fold (offsets in doubles); shared by the kernel and the host planner.
 struct FoldLayout {
@@ -188,22 +189,25 @@ __global__ __launch_bounds__(T) void k_fold_g(FoldArgs p) {
                     const int vbeg = p.view_ptr[f];
                     const int M = p.view_ptr[f + 1] - vbeg;
                     const int R2 = 2 * M, rk = p.rank[f];
+                    const float inv_r2 = 1.0f / (float)R2;
                     const double* blk = p.stack + p.blk_off[f];
                     const int lead = 6 * (p.fmin[f] - nd.win_lo);
                     if (ln < M) smap[ln] = 6 * (p.obs_slot[vbeg + ln] - nd.win_lo);
                     const int nel = (6 * M + 1) * R2;
-                    for (int e0 = 0; e0 < nel; e0 += 256) {
-                        double x[4];
+                    // (all loads of a block issued before the first use: the staging is bound by the HBM round trip;
+                    //  a track of 10 views is 1220 doubles = one trip of 20 loads per lane)
+                    for (int e0 = 0; e0 < nel; e0 += 64 * STAGE_U) {
+                        double x[STAGE_U];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
                             x[u] = (e < nel) ? blk[e] : 0.0;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
                             if (e < nel) {
-                                const int c = e / R2, L = e - c * R2;
+                                const int c = (int)(((float)e + 0.5f) * inv_r2), L = e - c * R2;   // e / R2, exact for e < 2^20
                                 const int gr = r0 + (L - rk);           // node-global sorted row
                                 if (L >= rk && gr >= sub_lo && gr < sub_lo + np) {
                                     const int col = (c == 6 * M) ? w : smap[c / 6] + (c % 6);
@@ -516,22 +520,25 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                     const int vbeg = p.view_ptr[f];
                     const int M = p.view_ptr[f + 1] - vbeg;
                     const int R2 = 2 * M, rk = p.rank[f];
+                    const float inv_r2 = 1.0f / (float)R2;
                     const double* blk = p.stack + p.blk_off[f];
                     const int lead = 6 * (p.fmin[f] - nd.win_lo);
                     if (ln < M) smap[ln] = 6 * (p.obs_slot[vbeg + ln] - nd.win_lo);
                     const int nel = (6 * M + 1) * R2;
-                    for (int e0 = 0; e0 < nel; e0 += 256) {
-                        double x[4];
+                    // (all loads of a block issued before the first use: the staging is bound by the HBM round trip;
+                    //  a track of 10 views is 1220 doubles = one trip of 20 loads per lane)
+                    for (int e0 = 0; e0 < nel; e0 += 64 * STAGE_U) {
+                        double x[STAGE_U];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
                             x[u] = (e < nel) ? blk[e] : 0.0;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
                             if (e < nel) {
-                                const int c = e / R2, L = e - c * R2;
+                                const int c = (int)(((float)e + 0.5f) * inv_r2), L = e - c * R2;   // e / R2, exact for e < 2^20
                                 const int gr = r0 + (L - rk);           // node-global sorted row
                                 if (L >= rk && gr >= sub_lo && gr < sub_lo + np) {
                                     const int col = (c == 6 * M) ? w : smap[c / 6] + (c % 6);
