@@ -309,3 +309,45 @@ def test_wide_tracks_fall_back_to_the_tree(eng):
     res = eng.update_problem(prob)
     assert res.status == 0
     assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+
+
+def _drop_views(prob, rng, keep_first=True, p_drop=0.35, only_first_slots=None):
+    """Remove interior observations (tracks that skip clones) and, optionally, whole features so that only
+    some first slots carry tracks (groups with gaps between them)."""
+    from msckf_amd import synth
+    vp = np.asarray(prob.view_ptr)
+    keep_feat, new_vp, keep_obs = [], [0], []
+    for f in range(prob.F):
+        a, b = int(vp[f]), int(vp[f + 1])
+        if only_first_slots is not None and int(prob.obs_slot[a]) not in only_first_slots:
+            continue
+        idx = [a] + [i for i in range(a + 1, b - 1) if rng.random() > p_drop] + [b - 1]
+        idx = sorted(set(idx))
+        if len(idx) < 2:
+            continue
+        keep_feat.append(f)
+        keep_obs.extend(idx)
+        new_vp.append(new_vp[-1] + len(idx))
+    kf, ko = np.asarray(keep_feat), np.asarray(keep_obs)
+    return synth.UpdateProblem(P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
+                               gravity=prob.gravity, K=prob.K, sigma=prob.sigma,
+                               view_ptr=np.asarray(new_vp, dtype=np.int32), obs_uv=prob.obs_uv[ko],
+                               obs_slot=prob.obs_slot[ko], idp_base=prob.idp_base[kf], idp_m=prob.idp_m[kf],
+                               idp_rho=prob.idp_rho[kf])
+
+
+@pytest.mark.parametrize("seed,first_slots", [(41, None), (42, {0, 1, 9, 10, 17}), (43, {5})])
+def test_band_pipeline_tracks_with_holes_and_group_gaps(eng, seed, first_slots):
+    """Tracks that skip clones (zero column blocks inside a window) and batches whose tracks start at a few
+    slots only (R rows no fold ever touches, folds whose envelopes do not overlap)."""
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    rng = np.random.default_rng(seed)
+    prob = _drop_views(synth.make_problem(28, 400, 10, seed=seed), rng, only_first_slots=first_slots)
+    ref = oracle.update(prob, dense_noise=False)
+    res = eng.update_problem(prob)
+    assert res.status == ref["status"] == 0
+    assert np.array_equal(res.accepted, ref["accepted"])
+    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+    T, rn = eng.debug_compressed()
+    assert not np.triu(T, 60).any()                  # band plan taken (every track spans <= 10 slots)
