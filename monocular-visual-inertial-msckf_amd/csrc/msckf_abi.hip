@@ -142,6 +142,8 @@ struct msckf_ctx {
     size_t hFeatCap = 0, res_dx_off = 0, res_p_off = 0;
     std::vector<double> chi2_cache;
     bool defer_state_sync = false;        // msckf_update: the feature upload's sync covers the state upload
+    bool oneshot = false;                 // msckf_update: set_features uploads, launches K1-K4 and plans K5 meanwhile, no sync
+    bool feature_launched = false;        // K1-K4 of the current batch is already in the stream (oneshot)
 };
 
 namespace {
@@ -630,7 +632,8 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (!c->have_state || !c->have_features) return MSCKF_ERR_STATE;
     int rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[0], c->stream));
-    if ((rc = launch_feature(c)) != MSCKF_OK) return rc;
+    if (!c->feature_launched && (rc = launch_feature(c)) != MSCKF_OK) return rc;
+    c->feature_launched = false;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
     if (c->F > 0 && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c)) != MSCKF_OK) return rc;
@@ -897,12 +900,8 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     std::memcpy(h_viewp, h_view.data(), (size_t)(F + 1) * 4);
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
-    plan_batch(c, h_fmin, h_fmax, h_view);
     c->h_fmin = h_fmin; c->h_fmax = h_fmax;
-    // room for gathered shard blocks behind the plan's blocks
-    c->gather_off = c->rbuf_doubles;
     const double t1 = now_us();
-    c->us_host_prep = (float)(t1 - t0);
 
     set_view(c->dObsUV, c->dFeatArena.p, o_uv, (size_t)sumM * 16);
     set_view(c->dBase, c->dFeatArena.p, o_base, (size_t)F * 24);
@@ -919,6 +918,20 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
     E(c->dStack, (size_t)blk * 8); E(c->dGamma, (size_t)F * 8);
     if (rc != MSCKF_OK) return rc;
+    // the tracks go first; in the one-shot call K1-K4 starts behind them while the host plans K5
+    HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
+    c->feature_launched = false;
+    if (c->oneshot) {
+        HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+        if (int rcf = launch_feature(c)) return rcf;
+        c->feature_launched = true;
+    }
+    const double t2 = now_us();
+    plan_batch(c, h_fmin, h_fmax, h_view);
+    // room for gathered shard blocks behind the plan's blocks
+    c->gather_off = c->rbuf_doubles;
+    const double t3 = now_us();
+    c->us_host_prep = (float)((t1 - t0) + (t3 - t2));
     {
         // the R workspace is zero-initialised once: entries below a block's diagonal are never written
         const size_t need = (c->rbuf_doubles + 16) * 8;
@@ -931,10 +944,9 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         }
         HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
     if (int rcp = upload_plan(c)) return rcp;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->us_h2d += (float)(now_us() - t1);
+    if (!c->oneshot) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->us_h2d += (float)((t2 - t1) + (now_us() - t3));
     c->have_features = true;
     return MSCKF_OK;
 }
@@ -1059,8 +1071,10 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
     int rc = msckf_set_state(c, N, P, cam_R, cam_t, cam_R0, cam_t0, gravity, Kinv, sigma, chi2_crit, n_crit);
     c->defer_state_sync = false;
     if (rc != MSCKF_OK) return rc;
+    c->oneshot = F > 0;
     rc = msckf_set_features(c, F, view_ptr, obs_uv, obs_slot, idp_base, idp_m, idp_rho);
-    if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); return rc; }   // the state upload may still be in flight
+    c->oneshot = false;
+    if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); c->feature_launched = false; return rc; }   // uploads / K1-K4 may be in flight
     if (F == 0) {
         // empty feature dict: the reference returns at MSCKF.py:584-585
         const size_t d = c->d;
@@ -1069,8 +1083,7 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
         if (stats) { std::memset(stats, 0, sizeof(*stats)); }
         return MSCKF_NOOP;
     }
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    rc = run_pipeline(c, true, nullptr);
+    rc = run_pipeline(c, true, nullptr);               // K1-K4 is already in the stream (ev[6] sits in front of it)
     if (rc != MSCKF_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev[7]));
