@@ -151,8 +151,13 @@ def main():
         from msckf_amd.shard import partition_features
         lo, hi = partition_features(prob.view_ptr, world)[rank]
         local = prob.subset(lo, hi)
+        # exchange format (every rank sees the whole batch, so all agree): group triangles when the batch
+        # runs the band pipeline -- each rank stops in front of its root sweep, rank 0 folds the shards' groups
+        # and runs ONE root sweep -- else the root blocks [R | Q^T r] and the fold-tree merge
+        groups = UpdateEngine.band_ok(prob)
+        eng.set_group_exchange(groups)
         eng.load(local)
-        nblk = eng.block_doubles()
+        nblk = eng.group_record_doubles() if groups else eng.block_doubles()
         d = prob.d
         # send buffer: the block [R | Q^T r] plus one trailing double, the shard's accepted count (it rides
         # with the gather instead of a second collective); rank 0 receives `world` such records
@@ -165,7 +170,10 @@ def main():
 
         def step():
             eng.run_compress()                                   # K1-K5 on the local shard
-            _, n = eng.export_block(dst_ptr=mine.data_ptr())     # D2D into the torch-owned send buffer (syncs)
+            if groups:
+                _, n = eng.export_groups(dst_ptr=mine.data_ptr())    # D2D into the torch-owned send buffer (syncs)
+            else:
+                _, n = eng.export_block(dst_ptr=mine.data_ptr())
             mine[nblk] = float(n)
             dist.gather(mine, gather_list=glist, dst=0)          # ONE RCCL gather of the R blocks
             if rank == 0:
@@ -177,7 +185,10 @@ def main():
                     src = packed
                 else:
                     src = gathered
-                eng.merge_gain(int(src.data_ptr()), total, n_blocks=world)
+                if groups:
+                    eng.merge_groups(int(src.data_ptr()), total, n_records=world)
+                else:
+                    eng.merge_gain(int(src.data_ptr()), total, n_blocks=world)
                 eng.sync()
                 eng.export_result(out.data_ptr(), out.data_ptr() + d * 8)   # dx | P+ -> broadcast buffer (D2D)
             dist.broadcast(out, src=0)                           # state for the next update on every rank
@@ -218,6 +229,7 @@ def main():
             "config": {"workload": f"N={N} clones, F={Fg} features per GPU, track={M}, fp64"
                                    + ("" if world == 1 else f", feature-sharded over {world} GPUs "
                                       f"({Fg * world} features per update), 1 RCCL gather + broadcast per update"),
+                       **({"exchange": "group triangles" if groups else "root blocks"} if use_dist else {}),
                        "unit_definition": "one 2000-feature measurement update (K1-K7)", "seed": 0},
         }
         if not use_dist:

@@ -337,6 +337,51 @@ class UpdateEngine:
             self._check(self._lib.msckf_run_merge_gain(self._h, b.ctypes.data_as(C.c_void_p), int(b.shape[0]), 0,
                                                        int(total_accepted)), allow_noop=False)
 
+    # -- group exchange: the sharded band pipeline ------------------------------
+    BAND_MAX_SPAN = 10        # clone slots a track may span (k_sweep tiles are 60 columns wide)
+    BAND_MAX_CLONES = 37      # the band R of 6 N rows x 64 doubles has to fit LDS
+
+    @classmethod
+    def band_ok(cls, prob: UpdateProblem) -> bool:
+        """True when every shard of `prob` is planned as the band pipeline (the rule of `build_plan_band`):
+        then the ranks may exchange group triangles (`export_groups` / `merge_groups`) instead of root blocks."""
+        if prob.N > cls.BAND_MAX_CLONES or prob.F == 0:
+            return False
+        vp = np.asarray(prob.view_ptr)
+        slots = np.asarray(prob.obs_slot).reshape(-1)
+        lo = np.minimum.reduceat(slots, vp[:-1])
+        hi = np.maximum.reduceat(slots, vp[:-1])
+        return bool((hi - lo + 1).max() <= cls.BAND_MAX_SPAN)
+
+    def set_group_exchange(self, on: bool = True):
+        """Plan the following batches with the group-record layout (call before `load`)."""
+        self._check(self._lib.msckf_set_group_exchange(self._h, 1 if on else 0), allow_noop=False)
+
+    def group_record_doubles(self) -> int:
+        return int(self._lib.msckf_group_record_doubles(self._h))
+
+    def export_groups(self, dst_ptr: Optional[int] = None):
+        """The shard's group triangles (one record) after `run_compress`; host array or HBM address."""
+        n_acc = C.c_int32(0)
+        if dst_ptr is not None:
+            self._check(self._lib.msckf_export_groups(self._h, C.c_void_p(dst_ptr), 1, C.byref(n_acc)), allow_noop=False)
+            return None, int(n_acc.value)
+        rec = np.zeros(self.group_record_doubles())
+        self._check(self._lib.msckf_export_groups(self._h, rec.ctypes.data_as(C.c_void_p), 0, C.byref(n_acc)),
+                    allow_noop=False)
+        return rec, int(n_acc.value)
+
+    def merge_groups(self, records, total_accepted: int, n_records: Optional[int] = None):
+        """Root side: fold the shards' group triangles, one root sweep, K6-K7.  `records` is a host array
+        (G, record_doubles) or an int device address (then pass n_records)."""
+        if isinstance(records, (int, np.integer)):
+            self._check(self._lib.msckf_run_merge_groups(self._h, C.c_void_p(int(records)), int(n_records), 1,
+                                                         int(total_accepted)), allow_noop=False)
+        else:
+            b = _ffi.f64(records)
+            self._check(self._lib.msckf_run_merge_groups(self._h, b.ctypes.data_as(C.c_void_p), int(b.shape[0]), 0,
+                                                         int(total_accepted)), allow_noop=False)
+
     def export_result(self, dx_ptr: int, P_ptr: int):
         """dx and P+ of the last run into HBM buffers owned by the caller."""
         self._check(self._lib.msckf_export_result(self._h, C.c_void_p(dx_ptr), C.c_void_p(P_ptr), 1), allow_noop=False)

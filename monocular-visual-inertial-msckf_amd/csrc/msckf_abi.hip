@@ -62,6 +62,7 @@ constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgrou
 #endif
 constexpr int SWEEP_NW = MSCKF_SWEEP_NW;         // concurrent folds of k_sweep
 constexpr int SWEEP_WPF = MSCKF_SWEEP_WPF;       // wavefronts per fold (1 or 2)
+constexpr size_t XCHG_SLOT = (size_t)SWEEP_MAX_W * (SWEEP_MAX_W + 1);   // doubles per group triangle in an export record
 constexpr int FOLD_LDS_BYTES = 160 * 1024 - 512;
 
 inline int fold_class(int w) { return (w + 1 <= 64) ? 1 : (w + 1 <= 128) ? 2 : 3; }
@@ -121,6 +122,17 @@ struct msckf_ctx {
     std::vector<std::pair<int, int>> sweep_levels;   // (node_base, count) per group-merge launch
     size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
     size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
+    // group exchange (sharded band pipeline): the group triangles live in one export record at the head of rbuf
+    bool xchg = false;                    // requested by msckf_set_group_exchange
+    bool xchg_planned = false;            // the current plan has the record layout
+    std::vector<double> h_xflags;         // [N] 1.0 where this shard has tracks starting at the slot
+    std::vector<double> x_key;            // flags of the last merged records (plan cache of msckf_run_merge_groups)
+    int x_nrec = 0;
+    bool x_plan_valid = false;
+    std::vector<SweepNode> x_snodes;      // rank-0 merge plan: cross-rank group merges, last = root
+    std::vector<SweepFold> x_sfolds;
+    int x_n_merges = 0;
+    size_t x_root_off = 0, x_zero_off = 0;
     size_t rbuf_doubles = 0;              // used by the plan
     size_t gather_off = 0;                // region for gathered shard blocks
     int gather_cap = 0;
@@ -303,7 +315,11 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         if (live(f) && 6 * (fmax[f] - fmin[f] + 1) > SWEEP_MAX_W) return false;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 250;
     c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear();
-    size_t off = 0;
+    // group exchange: the record [N flags | N slots of XCHG_SLOT doubles] heads the workspace; the triangle of
+    // group s (fixed window of min(10, N - s) slots, so its shape depends on (N, s) only) is produced in slot s
+    const bool xchg = c->xchg;
+    size_t off = xchg ? (size_t)N + (size_t)N * XCHG_SLOT : 0;
+    if (xchg) c->h_xflags.assign(N, 0.0);
     struct Tri { long long src; int lo, w; };
     std::vector<Tri> group_tri;                                           // one triangle per group, by first slot
     std::vector<std::vector<SweepNode>> merge_levels;                     // [level] -> nodes of every group at that depth
@@ -328,6 +344,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
                 ++e;
             }
             FoldNode n{};
+            if (xchg) hi = std::min(s + SWEEP_MAX_W / 6, N) - 1;
             n.kind = 0; n.src_begin = f; n.src_end = last + 1; n.win_lo = s; n.w = 6 * (hi - s + 1); n.pad = 0;
             n.out_off = (long long)off;
             off += (size_t)n.w * (n.w + 1);
@@ -338,7 +355,8 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         // merge levels of this group: one k_sweep node folds up to 2 * SWEEP_NW triangles (two rounds of the
         // fold slots); larger groups first reduce chunks of SWEEP_NW triangles in parallel workgroups
         std::vector<Tri> cur = leaves;
-        auto merge_node = [&](size_t b, size_t e, int level) -> Tri {
+        const long long xdest = xchg ? (long long)((size_t)N + (size_t)s * XCHG_SLOT) : -1;
+        auto merge_node = [&](size_t b, size_t e, int level, long long dest = -1) -> Tri {
             SweepNode m{};
             m.fold_begin = (int)c->sfolds.size();
             int wtot = 0, env = 0;
@@ -351,8 +369,8 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             m.fold_end = (int)c->sfolds.size();
             m.wtot = wtot;
             sweep_schedule(c->sfolds, m.fold_begin, m.fold_end, &m.nsteps);
-            m.out_off = (long long)off;
-            off += (size_t)wtot * (wtot + 1);
+            if (dest >= 0) m.out_off = dest;
+            else { m.out_off = (long long)off; off += (size_t)wtot * (wtot + 1); }
             if ((int)merge_levels.size() <= level) merge_levels.resize(level + 1);
             merge_levels[level].push_back(m);
             return Tri{m.out_off, s, wtot};
@@ -367,7 +385,13 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             cur.swap(nxt);
             ++level;
         }
-        if (cur.size() > 1) { const Tri tmerged = merge_node(0, cur.size(), level); cur.assign(1, tmerged); }
+        if (cur.size() > 1) { const Tri tmerged = merge_node(0, cur.size(), level, xdest); cur.assign(1, tmerged); }
+        else if (xchg) {
+            // a single leaf: it writes straight into the record slot
+            for (FoldNode& nd : c->nodes) if (nd.out_off == cur[0].src) { nd.out_off = xdest; break; }
+            cur[0].src = xdest;
+        }
+        if (xchg) c->h_xflags[s] = 1.0;
         group_tri.push_back(cur[0]);
     }
     c->n_leaves = (int)c->nodes.size();
@@ -402,12 +426,14 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     c->zero_off = off;
     off += 16;
     c->rbuf_doubles = off;
+    c->xchg_planned = xchg;
     return true;
 }
 
 // plan for the current batch: band pipeline when it qualifies, else the tree
 void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
+    c->xchg_planned = false;
     c->band_plan = build_plan_band(c, fmin, fmax, view_sorted, valid);
     if (!c->band_plan) { c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0; build_plan(c, fmin, fmax, view_sorted, valid); }
 }
@@ -470,7 +496,7 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
 }
 
 // band plan, levels 1-2: group merges (one workgroup each), then the root sweep
-int launch_sweeps(msckf_ctx* c) {
+int launch_sweeps(msckf_ctx* c, bool with_root = true) {
     if (c->snodes.empty()) return MSCKF_OK;
     SweepArgs a{};
     a.nodes = ptr<SweepNode>(c->dSweepNodes);
@@ -486,9 +512,11 @@ int launch_sweeps(msckf_ctx* c) {
         a.stamp_base = (int)c->nodes.size() + lv.first;
         hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(lv.second), block, sweep_lds_bytes(wmax, SWEEP_NW, SWEEP_WPF), c->stream, a);
     }
-    a.node_base = c->n_group_merges;
-    a.stamp_base = (int)c->nodes.size() + c->n_group_merges;
-    hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(1), block, sweep_lds_bytes(c->snodes.back().wtot, SWEEP_NW, SWEEP_WPF), c->stream, a);
+    if (with_root) {
+        a.node_base = c->n_group_merges;
+        a.stamp_base = (int)c->nodes.size() + c->n_group_merges;
+        hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(1), block, sweep_lds_bytes(c->snodes.back().wtot, SWEEP_NW, SWEEP_WPF), c->stream, a);
+    }
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -499,6 +527,9 @@ int upload_plan(msckf_ctx* c) {
     if (!c->nodes.empty())
         HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
                                  c->stream));
+    c->x_plan_valid = false;               // the sweep tables are rewritten: a cached merge plan behind them is gone
+    if (c->xchg_planned)                   // (behind the workspace memset of set_features / replan, same stream)
+        HIPCHK(c, hipMemcpyAsync(c->dRbuf.p, c->h_xflags.data(), c->h_xflags.size() * 8, hipMemcpyHostToDevice, c->stream));
     if (!c->snodes.empty()) {
         if (int rc = ensure(c, c->dSweepNodes, c->snodes.size() * sizeof(SweepNode))) return rc;
         if (int rc = ensure(c, c->dSweepFolds, c->sfolds.size() * sizeof(SweepFold))) return rc;
@@ -636,7 +667,8 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     c->feature_launched = false;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
     if (c->F > 0 && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
-    if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c)) != MSCKF_OK) return rc;
+    // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
+    if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, with_gain || !c->xchg_planned)) != MSCKF_OK) return rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     if (with_gain && c->F > 0 && c->root >= 0) {
         if ((rc = launch_gain(c, root_block(c))) != MSCKF_OK) return rc;
@@ -1351,6 +1383,7 @@ int msckf_export_block(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accep
         if (n_accepted) *n_accepted = 0;
         return MSCKF_OK;
     }
+    if (c->xchg_planned && !c->ran_gain) return MSCKF_ERR_STATE;   // the root sweep was left to the merging rank: msckf_export_groups
     HIPCHK(c, hipMemcpyAsync(dst, root_block(c), bytes, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                              c->stream));
     int counters[4] = {0, 0, 0, 0};
@@ -1416,6 +1449,150 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     // counters[0] decides OK / NOOP in get_result: mark "accepted" when any block is non-empty
     (void)N;
     int rc = launch_gain(c, root);
+    if (rc != MSCKF_OK) return rc;
+    c->ran = true; c->ran_gain = true;
+    c->acc_override = total_accepted;
+    return MSCKF_OK;
+}
+
+// ---- group exchange: the sharded band pipeline --------------------------------------
+int msckf_set_group_exchange(msckf_ctx* c, int on) {
+    if (!c) return MSCKF_ERR_ARG;
+    c->xchg = on != 0;
+    c->have_features = false;             // the next msckf_set_features plans with the new layout
+    c->ran = false;
+    return MSCKF_OK;
+}
+
+size_t msckf_group_record_doubles(const msckf_ctx* c) {
+    return c ? (size_t)c->N + (size_t)c->N * XCHG_SLOT : 0;
+}
+
+int msckf_export_groups(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accepted) {
+    if (!c || !dst) return MSCKF_ERR_ARG;
+    if (!c->ran) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = msckf_group_record_doubles(c) * 8;
+    if (c->F == 0 || c->root < 0) {       // no tracks in this shard: all flags 0
+        if (device_ptr) HIPCHK(c, hipMemsetAsync(dst, 0, bytes, c->stream));
+        else std::memset(dst, 0, bytes);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_accepted) *n_accepted = 0;
+        return MSCKF_OK;
+    }
+    if (!c->xchg_planned) return MSCKF_ERR_STATE;     // tree plan (wide tracks, N > 37): use msckf_export_block
+    HIPCHK(c, hipMemcpyAsync(dst, c->dRbuf.p, bytes, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    int counters[4] = {0, 0, 0, 0};
+    if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
+    if (n_accepted) *n_accepted = counters[0];
+    return MSCKF_OK;
+}
+
+int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int device_ptr, int32_t total_accepted) {
+    if (!c || !records || n_rec < 1) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int N = c->N, dc = c->dc;
+    if (N < 1 || sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF) > (size_t)FOLD_LDS_BYTES) return MSCKF_ERR_ARG;
+    const size_t rec = msckf_group_record_doubles(c);
+    // workspace behind the local plan: records | merged group triangles | root block | zero words
+    const size_t o_rec = c->gather_off, o_mrg = o_rec + (size_t)n_rec * rec, o_root = o_mrg + (size_t)N * XCHG_SLOT;
+    const size_t o_zero = o_root + (size_t)dc * (dc + 1), o_end = o_zero + 16;
+    const size_t need = (o_end + 16) * 8;
+    if (c->dRbuf.bytes < need) {          // grow, keeping the local plan's blocks
+        void* np = nullptr;
+        HIPCHK(c, hipMalloc(&np, need));
+        HIPCHK(c, hipMemset(np, 0, need));
+        if (c->dRbuf.p) {
+            HIPCHK(c, hipMemcpy(np, c->dRbuf.p, std::min(c->dRbuf.bytes, c->gather_off * 8), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipFree(c->dRbuf.p));
+        }
+        c->dRbuf.p = np; c->dRbuf.bytes = need;
+        c->x_plan_valid = false;
+    }
+    double* rb = ptr<double>(c->dRbuf);
+    HIPCHK(c, hipMemcpyAsync(rb + o_rec, records, (size_t)n_rec * rec * 8,
+                             device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    // which groups does each record carry?  (N flags at the head of every record)
+    std::vector<double> key((size_t)n_rec * N);
+    HIPCHK(c, hipMemcpy2DAsync(key.data(), (size_t)N * 8, rb + o_rec, rec * 8, (size_t)N * 8, n_rec, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const bool reuse = c->x_plan_valid && c->x_nrec == n_rec && c->x_root_off == o_root && c->x_key == key;
+    if (!reuse) {
+        c->x_snodes.clear(); c->x_sfolds.clear();
+        const int fold_base = (int)c->sfolds.size();      // the tables sit behind the local plan's
+        struct Tri { long long src; int lo, w; };
+        std::vector<Tri> groups;
+        std::vector<SweepFold>& fl = c->x_sfolds;
+        for (int s0 = 0; s0 < N; ++s0) {
+            const int w = 6 * (std::min(s0 + SWEEP_MAX_W / 6, N) - s0);
+            std::vector<long long> src;
+            for (int r = 0; r < n_rec; ++r)
+                if (key[(size_t)r * N + s0] != 0.0) src.push_back((long long)(o_rec + (size_t)r * rec + N + (size_t)s0 * XCHG_SLOT));
+            if (src.empty()) continue;
+            if (src.size() == 1) { groups.push_back({src[0], s0, w}); continue; }
+            SweepNode m{};
+            m.fold_begin = fold_base + (int)fl.size();
+            const int b = (int)fl.size();
+            for (long long so : src) { SweepFold sf{}; sf.src_off = so; sf.off = 0; sf.w = w; sf.ew = w; fl.push_back(sf); }
+            m.fold_end = fold_base + (int)fl.size();
+            m.wtot = w;
+            sweep_schedule(fl, b, (int)fl.size(), &m.nsteps);
+            m.out_off = (long long)(o_mrg + (size_t)s0 * XCHG_SLOT);
+            c->x_snodes.push_back(m);
+            groups.push_back({m.out_off, s0, w});
+        }
+        c->x_n_merges = (int)c->x_snodes.size();
+        if (!groups.empty()) {
+            SweepNode r{};
+            r.fold_begin = fold_base + (int)fl.size();
+            const int b = (int)fl.size();
+            int env = 0;
+            for (const Tri& g : groups) {
+                env = std::max(env, 6 * g.lo + g.w);
+                SweepFold sf{}; sf.src_off = g.src; sf.off = 6 * g.lo; sf.w = g.w; sf.ew = env - 6 * g.lo;
+                fl.push_back(sf);
+            }
+            r.fold_end = fold_base + (int)fl.size();
+            r.wtot = dc;
+            sweep_schedule(fl, b, (int)fl.size(), &r.nsteps);
+            r.out_off = (long long)o_root;
+            c->x_snodes.push_back(r);
+        }
+        // tables: local plan first (its launches may follow this call), the merge plan behind it
+        std::vector<SweepNode> all_n(c->snodes);
+        all_n.insert(all_n.end(), c->x_snodes.begin(), c->x_snodes.end());
+        std::vector<SweepFold> all_f(c->sfolds);
+        all_f.insert(all_f.end(), fl.begin(), fl.end());
+        if (int rc = ensure(c, c->dSweepNodes, std::max<size_t>(all_n.size(), 1) * sizeof(SweepNode))) return rc;
+        if (int rc = ensure(c, c->dSweepFolds, std::max<size_t>(all_f.size(), 1) * sizeof(SweepFold))) return rc;
+        if (!all_n.empty()) HIPCHK(c, hipMemcpyAsync(c->dSweepNodes.p, all_n.data(), all_n.size() * sizeof(SweepNode), hipMemcpyHostToDevice, c->stream));
+        if (!all_f.empty()) HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, all_f.data(), all_f.size() * sizeof(SweepFold), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(rb + o_mrg, 0, (o_end - o_mrg) * 8, c->stream));   // merged triangles, root block, zero words
+        HIPCHK(c, hipStreamSynchronize(c->stream));                                  // all_n / all_f are locals
+        c->x_key = key; c->x_nrec = n_rec; c->x_root_off = o_root; c->x_zero_off = o_zero; c->x_plan_valid = true;
+    }
+    if (c->x_snodes.empty()) {            // no shard has a track: nothing to update
+        c->ran = true; c->ran_gain = false; c->acc_override = 0;
+        return MSCKF_OK;
+    }
+    SweepArgs a{};
+    a.nodes = ptr<SweepNode>(c->dSweepNodes);
+    a.folds = ptr<SweepFold>(c->dSweepFolds);
+    a.rbuf = rb;
+    a.stamps = nullptr;
+    a.zero = rb + c->x_zero_off;
+    const dim3 block(64 * SWEEP_NW * SWEEP_WPF);
+    const int nb = (int)c->snodes.size();
+    if (c->x_n_merges > 0) {
+        a.node_base = nb;
+        hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(c->x_n_merges), block,
+                           sweep_lds_bytes(SWEEP_MAX_W, SWEEP_NW, SWEEP_WPF), c->stream, a);
+    }
+    a.node_base = nb + c->x_n_merges;
+    hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(1), block, sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF), c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    int rc = launch_gain(c, rb + c->x_root_off);
     if (rc != MSCKF_OK) return rc;
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;

@@ -38,21 +38,34 @@ def partition_features(view_ptr: np.ndarray, world: int) -> List[Tuple[int, int]
 
 
 class HipShardBackend:
-    """Compute side of a shard on one MI355X (the product path)."""
+    """Compute side of a shard on one MI355X (the product path).
+
+    What a rank sends depends on the WHOLE batch (every rank sees it, so all agree): when it qualifies for
+    the band pipeline (`UpdateEngine.band_ok`) the ranks stop in front of their root sweep and send the
+    triangles of their first-slot groups (one record); rank 0 folds them group by group and runs ONE root
+    sweep.  Otherwise they send their root blocks [R | Q^T r] and rank 0 merges those with the fold tree."""
 
     def __init__(self, engine, device_buffers: bool = False):
         self.engine = engine
         self.device_buffers = device_buffers
+        self.groups = False
+
+    def prepare(self, prob: UpdateProblem):
+        self.groups = bool(self.engine.band_ok(prob))
+        self.engine.set_group_exchange(self.groups)
 
     def compress(self, local: UpdateProblem):
         self.engine.load(local)
         self.engine.run_compress()
-        blk, n_acc = self.engine.export_block()
+        blk, n_acc = self.engine.export_groups() if self.groups else self.engine.export_block()
         acc = self.engine.result().accepted
         return blk, n_acc, acc
 
     def merge_gain(self, state: UpdateProblem, blocks: np.ndarray, total_accepted: int):
-        self.engine.merge_gain(blocks, total_accepted)
+        if self.groups:
+            self.engine.merge_groups(blocks, total_accepted)
+        else:
+            self.engine.merge_gain(blocks, total_accepted)
         res = self.engine.result()
         return res.status, res.dx, res.P_new
 
@@ -67,6 +80,8 @@ class ShardedUpdate:
         """Every rank passes the same full problem (state + all features) and gets
         back (status, dx, P_new, accepted[F])."""
         import torch
+        if hasattr(self.backend, "prepare"):
+            self.backend.prepare(prob)                                # exchange format, from the whole batch
         shards = partition_features(prob.view_ptr, self.world)
         lo, hi = shards[self.rank]
         local = prob.subset(lo, hi)

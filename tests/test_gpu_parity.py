@@ -351,3 +351,57 @@ def test_band_pipeline_tracks_with_holes_and_group_gaps(eng, seed, first_slots):
     assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
     T, rn = eng.debug_compressed()
     assert not np.triu(T, 60).any()                  # band plan taken (every track spans <= 10 slots)
+
+
+@pytest.mark.parametrize("N,F,M,shards,kw", [
+    (30, 2000, 10, 2, {}),
+    (30, 2000, 10, 8, {}),
+    (20, 500, 8, 3, {"outlier_fraction": 0.1, "outlier_px": 500.0}),
+    (12, 60, 10, 4, {"variable_tracks": True}),          # shards without tracks at some first slots
+    (30, 700, 10, 16, {}),                               # more records than fold slots: two rounds per group
+])
+def test_group_exchange_shards_on_one_gpu(N, F, M, shards, kw):
+    """Sharded band pipeline: every logical shard exports its group triangles (no root sweep of its own), the
+    root folds them group by group, runs ONE root sweep and K6-K7 -- equal to the single-shard update."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from msckf_amd.shard import partition_features
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=51, **kw)
+    ref = oracle.update(prob, dense_noise=False)
+    assert UpdateEngine.band_ok(prob)
+    with UpdateEngine(max_clones=N, max_features=F, max_track=max(M, 2)) as e:
+        e.set_group_exchange(True)
+        recs, total, acc = [], 0, np.zeros(prob.F, dtype=np.uint8)
+        for lo, hi in partition_features(prob.view_ptr, shards):
+            e.load(prob.subset(lo, hi))
+            e.run_compress()
+            rec, n = e.export_groups()
+            acc[lo:hi] = e.result().accepted
+            recs.append(rec); total += n
+        e.set_state(prob)
+        for _ in range(2):                                   # the second call reuses the cached merge plan
+            e.merge_groups(np.stack(recs), total)
+            res = e.result()
+            assert res.status == 0 and np.array_equal(acc, ref["accepted"])
+            assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        # a full single-rank update still works on an engine in exchange mode (its own root sweep runs)
+        one = e.update_problem(prob)
+        assert rel_err(one.dx, ref["dx"]) < TOL and rel_err(one.P_new, ref["P_new"]) < TOL
+
+
+def test_group_exchange_refuses_tree_planned_batches(eng):
+    from msckf_amd import synth
+    from msckf_amd._ffi import EngineError
+    prob = synth.make_problem(16, 120, 14, seed=36)          # tracks of 14 slots: merge tree
+    assert not eng.band_ok(prob)
+    eng.set_group_exchange(True)
+    try:
+        eng.load(prob)
+        eng.run_compress()
+        with pytest.raises(EngineError):
+            eng.export_groups()
+        blk, n = eng.export_block()                          # the block exchange still works
+        assert blk.shape == (96, 97) and n > 0
+    finally:
+        eng.set_group_exchange(False)
