@@ -159,35 +159,36 @@ def main():
         eng.load(local)
         nblk = eng.group_record_doubles() if groups else eng.block_doubles()
         d = prob.d
-        # send buffer: the block [R | Q^T r] plus one trailing double, the shard's accepted count (it rides
-        # with the gather instead of a second collective); rank 0 receives `world` such records
-        rec = nblk + 1
+        # send buffer: a group record carries the shard's accepted count itself; a root block [R | Q^T r] gets one
+        # trailing double for it (so the gather stays the only collective before the merge)
+        rec = nblk if groups else nblk + 1
         mine = torch.zeros(rec, dtype=torch.float64, device="cuda")
         gathered = torch.zeros(world * rec, dtype=torch.float64, device="cuda") if rank == 0 else None
         glist = list(gathered.view(world, rec).unbind(0)) if rank == 0 else None
-        packed = torch.zeros(world * nblk, dtype=torch.float64, device="cuda") if rank == 0 and world > 1 else None
+        packed = torch.zeros(world * nblk, dtype=torch.float64, device="cuda") if rank == 0 and world > 1 and not groups else None
         out = torch.zeros(d + d * d, dtype=torch.float64, device="cuda")
 
         def step():
-            eng.run_compress()                                   # K1-K5 on the local shard
+            eng.run_compress()                                   # K1-K5 on the local shard (no root sweep with groups)
             if groups:
-                _, n = eng.export_groups(dst_ptr=mine.data_ptr())    # D2D into the torch-owned send buffer (syncs)
+                eng.export_groups(dst_ptr=mine.data_ptr())       # D2D into the torch-owned send buffer (syncs)
             else:
                 _, n = eng.export_block(dst_ptr=mine.data_ptr())
-            mine[nblk] = float(n)
-            dist.gather(mine, gather_list=glist, dst=0)          # ONE RCCL gather of the R blocks
+                mine[nblk] = float(n)
+            dist.gather(mine, gather_list=glist, dst=0)          # ONE RCCL gather
             if rank == 0:
-                g2 = gathered.view(world, rec)
-                total = int(g2[:, nblk].sum().item())            # syncs: the gather has landed
-                if world > 1:
-                    packed.view(world, nblk).copy_(g2[:, :nblk])   # contiguous blocks for the merge
-                    torch.cuda.current_stream().synchronize()      # the engine works on its own stream
-                    src = packed
-                else:
-                    src = gathered
                 if groups:
-                    eng.merge_groups(int(src.data_ptr()), total, n_records=world)
+                    torch.cuda.current_stream().synchronize()    # the gather has landed (the engine has its own stream)
+                    eng.merge_groups(int(gathered.data_ptr()), -1, n_records=world)   # counts are in the records
                 else:
+                    g2 = gathered.view(world, rec)
+                    total = int(g2[:, nblk].sum().item())        # syncs: the gather has landed
+                    if world > 1:
+                        packed.view(world, nblk).copy_(g2[:, :nblk])   # contiguous blocks for the merge
+                        torch.cuda.current_stream().synchronize()
+                        src = packed
+                    else:
+                        src = gathered
                     eng.merge_gain(int(src.data_ptr()), total, n_blocks=world)
                 eng.sync()
                 eng.export_result(out.data_ptr(), out.data_ptr() + d * 8)   # dx | P+ -> broadcast buffer (D2D)

@@ -226,17 +226,17 @@ int msckf_run_merge_gain(msckf_ctx* ctx, const void* blocks, int32_t n_blocks, i
                          int32_t total_accepted /* sum of the shards' n_accepted */);
 
 /* Group exchange (band pipeline, every track spans <= 10 slots and N <= 37): instead of its root block a
- * rank exports the triangles of its first-slot groups, one record of N flags + N slots of 60 x 61 doubles
- * (the triangle of group s covers the fixed window of min(10, N - s) slots).  The rank then stops in front
+ * rank exports the triangles of its first-slot groups, one record of N flags, its accepted count and N slots
+ * of 60 x 61 doubles (the triangle of group s covers the fixed window of min(10, N - s) slots).  The rank then stops in front
  * of its root sweep (msckf_run_compress) and the root folds, per group, the triangles of all shards and
  * runs ONE root sweep and K6-K7 -- a constant number of steps instead of log2(G) dense merges.
  * msckf_set_group_exchange must precede msckf_set_features; msckf_export_groups returns MSCKF_ERR_STATE
  * when the batch was planned as a merge tree (then use msckf_export_block / msckf_run_merge_gain). */
 int msckf_set_group_exchange(msckf_ctx* ctx, int on);
-size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + N * 3660 */
+size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + N * 3660 */
 int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted);
 int msckf_run_merge_groups(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,
-                           int32_t total_accepted);
+                           int32_t total_accepted /* < 0: the sum of the counts in the records */);
 
 /* Copy dx[d] and P_out[d*d] of the last run into caller buffers that may live in HBM
  * (device_ptr != 0), e.g. the send buffer of the broadcast that follows the merge. */

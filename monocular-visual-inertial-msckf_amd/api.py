@@ -371,9 +371,10 @@ class UpdateEngine:
                     allow_noop=False)
         return rec, int(n_acc.value)
 
-    def merge_groups(self, records, total_accepted: int, n_records: Optional[int] = None):
+    def merge_groups(self, records, total_accepted: int = -1, n_records: Optional[int] = None):
         """Root side: fold the shards' group triangles, one root sweep, K6-K7.  `records` is a host array
-        (G, record_doubles) or an int device address (then pass n_records)."""
+        (G, record_doubles) or an int device address (then pass n_records); `total_accepted` < 0 takes the
+        sum of the counts the shards wrote into their records."""
         if isinstance(records, (int, np.integer)):
             self._check(self._lib.msckf_run_merge_groups(self._h, C.c_void_p(int(records)), int(n_records), 1,
                                                          int(total_accepted)), allow_noop=False)

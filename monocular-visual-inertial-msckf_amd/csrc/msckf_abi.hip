@@ -315,10 +315,10 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         if (live(f) && 6 * (fmax[f] - fmin[f] + 1) > SWEEP_MAX_W) return false;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 250;
     c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear();
-    // group exchange: the record [N flags | N slots of XCHG_SLOT doubles] heads the workspace; the triangle of
+    // group exchange: the record [N flags | accepted count | N slots of XCHG_SLOT doubles] heads the workspace; the triangle of
     // group s (fixed window of min(10, N - s) slots, so its shape depends on (N, s) only) is produced in slot s
     const bool xchg = c->xchg;
-    size_t off = xchg ? (size_t)N + (size_t)N * XCHG_SLOT : 0;
+    size_t off = xchg ? (size_t)N + 1 + (size_t)N * XCHG_SLOT : 0;
     if (xchg) c->h_xflags.assign(N, 0.0);
     struct Tri { long long src; int lo, w; };
     std::vector<Tri> group_tri;                                           // one triangle per group, by first slot
@@ -355,7 +355,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         // merge levels of this group: one k_sweep node folds up to 2 * SWEEP_NW triangles (two rounds of the
         // fold slots); larger groups first reduce chunks of SWEEP_NW triangles in parallel workgroups
         std::vector<Tri> cur = leaves;
-        const long long xdest = xchg ? (long long)((size_t)N + (size_t)s * XCHG_SLOT) : -1;
+        const long long xdest = xchg ? (long long)((size_t)N + 1 + (size_t)s * XCHG_SLOT) : -1;
         auto merge_node = [&](size_t b, size_t e, int level, long long dest = -1) -> Tri {
             SweepNode m{};
             m.fold_begin = (int)c->sfolds.size();
@@ -1465,7 +1465,7 @@ int msckf_set_group_exchange(msckf_ctx* c, int on) {
 }
 
 size_t msckf_group_record_doubles(const msckf_ctx* c) {
-    return c ? (size_t)c->N + (size_t)c->N * XCHG_SLOT : 0;
+    return c ? (size_t)c->N + 1 + (size_t)c->N * XCHG_SLOT : 0;
 }
 
 int msckf_export_groups(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accepted) {
@@ -1483,7 +1483,12 @@ int msckf_export_groups(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_acce
     if (!c->xchg_planned) return MSCKF_ERR_STATE;     // tree plan (wide tracks, N > 37): use msckf_export_block
     HIPCHK(c, hipMemcpyAsync(dst, c->dRbuf.p, bytes, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     int counters[4] = {0, 0, 0, 0};
-    if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
+    if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;       // syncs
+    // the shard's accepted count rides in the record (double N): the merging rank sums them
+    const double nacc = (double)counters[0];
+    double* slot = static_cast<double*>(dst) + c->N;
+    if (device_ptr) HIPCHK(c, hipMemcpy(slot, &nacc, 8, hipMemcpyHostToDevice));
+    else *slot = nacc;
     if (n_accepted) *n_accepted = counters[0];
     return MSCKF_OK;
 }
@@ -1514,9 +1519,16 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
     HIPCHK(c, hipMemcpyAsync(rb + o_rec, records, (size_t)n_rec * rec * 8,
                              device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     // which groups does each record carry?  (N flags at the head of every record)
-    std::vector<double> key((size_t)n_rec * N);
-    HIPCHK(c, hipMemcpy2DAsync(key.data(), (size_t)N * 8, rb + o_rec, rec * 8, (size_t)N * 8, n_rec, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> head((size_t)n_rec * (N + 1)), key((size_t)n_rec * N);
+    HIPCHK(c, hipMemcpy2DAsync(head.data(), (size_t)(N + 1) * 8, rb + o_rec, rec * 8, (size_t)(N + 1) * 8, n_rec,
+                               hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    double acc_sum = 0.0;
+    for (int r = 0; r < n_rec; ++r) {
+        std::copy(head.begin() + (size_t)r * (N + 1), head.begin() + (size_t)r * (N + 1) + N, key.begin() + (size_t)r * N);
+        acc_sum += head[(size_t)r * (N + 1) + N];
+    }
+    if (total_accepted < 0) total_accepted = (int32_t)(acc_sum + 0.5);    // the counts the shards wrote into their records
     const bool reuse = c->x_plan_valid && c->x_nrec == n_rec && c->x_root_off == o_root && c->x_key == key;
     if (!reuse) {
         c->x_snodes.clear(); c->x_sfolds.clear();
@@ -1528,7 +1540,7 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
             const int w = 6 * (std::min(s0 + SWEEP_MAX_W / 6, N) - s0);
             std::vector<long long> src;
             for (int r = 0; r < n_rec; ++r)
-                if (key[(size_t)r * N + s0] != 0.0) src.push_back((long long)(o_rec + (size_t)r * rec + N + (size_t)s0 * XCHG_SLOT));
+                if (key[(size_t)r * N + s0] != 0.0) src.push_back((long long)(o_rec + (size_t)r * rec + N + 1 + (size_t)s0 * XCHG_SLOT));
             if (src.empty()) continue;
             if (src.size() == 1) { groups.push_back({src[0], s0, w}); continue; }
             SweepNode m{};

@@ -63,7 +63,7 @@ class HipShardBackend:
 
     def merge_gain(self, state: UpdateProblem, blocks: np.ndarray, total_accepted: int):
         if self.groups:
-            self.engine.merge_groups(blocks, total_accepted)
+            self.engine.merge_groups(blocks, -1)                      # the counts ride in the records
         else:
             self.engine.merge_gain(blocks, total_accepted)
         res = self.engine.result()
