@@ -163,20 +163,15 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             for (int k = 0; k < CS; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
     };
 
-    // the owners of local column slot KN publish their column (row slots rr <= RP) with its squared norm
+    // the owners of local column slot KN publish their column (row slots rr <= RP); its squared norm falls out
+    // of the next step's dots (the owners' own dot is v^T v)
     auto publish = [&](auto tagk, auto tagr) {
         constexpr int KN = decltype(tagk)::value;
         constexpr int RP = decltype(tagr)::value < 15 ? decltype(tagr)::value : 15;
         if constexpr (KN < CS) {
-            double q4[4] = {0.0, 0.0, 0.0, 0.0};
             double* dst = vb + rq * 16;
 #pragma unroll
-            for (int rr = 0; rr <= RP; ++rr) {
-                const double x = a[rr][KN];
-                q4[rr & 3] = fma(x, x, q4[rr & 3]);
-                dst[rr] = x;
-            }
-            vb[64] = quad_sum((q4[0] + q4[1]) + (q4[2] + q4[3]));
+            for (int rr = 0; rr <= RP; ++rr) dst[rr] = a[rr][KN];
         }
     };
 
@@ -213,13 +208,11 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
 #pragma unroll
             for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
         }
-        const double sg = vb[64];
         const double x0 = smem[rrow];
         double rck[CS], sd[CS];
 #pragma unroll
         for (int k = K0; k < CS; ++k) rck[k] = smem[ra[k]];
         const bool act0 = (cq + CL * K0) > i;             // slot K0: columns left of / at the pivot are retired
-        const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
 #ifdef SWEEP_PROF
         if (live) SWEEP_TICK(1);                            // LDS data arrived (the branch forces the wait)
 #endif
@@ -231,6 +224,9 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             for (int rr = 0; rr <= RMAX; ++rr) s4[rr & 3] = fma(v[rr], a[rr][k], s4[rr & 3]);
             sd[k] = quad_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
         }
+        // |column i|^2 = the pivot column's dot with itself: the lanes that published v hold a[.][K0] == v
+        const double sg = readlane_d(sd[K0], 4 * (i - CL * K0));
+        const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
 #ifdef SWEEP_PROF
         if (sd[CS - 1] != 1.2345e300) SWEEP_TICK(2);        // dots + quad sums done
 #endif
