@@ -85,6 +85,9 @@ __device__ __forceinline__ double quad_sum(double x) {
     return x;
 }
 
+#ifndef SWEEP_ACC
+#define SWEEP_ACC 1      // partial sums per dot: the step is bound by the FP64 instruction count, not by the FMA chain
+#endif
 template <int KK> struct STag { static constexpr int value = KK; };
 
 #ifdef SWEEP_PROF
@@ -219,10 +222,22 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         // ---- dots first: they do not depend on the reflector scalars (four partial sums: short chains)
 #pragma unroll
         for (int k = K0; k < CS; ++k) {
+#if SWEEP_ACC == 1
+            double s0 = v[0] * a[0][k];
+#pragma unroll
+            for (int rr = 1; rr <= RMAX; ++rr) s0 = fma(v[rr], a[rr][k], s0);
+            sd[k] = quad_sum(s0);
+#elif SWEEP_ACC == 2
+            double s0 = v[0] * a[0][k], s1 = v[1] * a[1][k];
+#pragma unroll
+            for (int rr = 2; rr <= RMAX; ++rr) { if (rr & 1) s1 = fma(v[rr], a[rr][k], s1); else s0 = fma(v[rr], a[rr][k], s0); }
+            sd[k] = quad_sum(s0 + s1);
+#else
             double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int rr = 0; rr <= RMAX; ++rr) s4[rr & 3] = fma(v[rr], a[rr][k], s4[rr & 3]);
             sd[k] = quad_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+#endif
         }
         // |column i|^2 = the pivot column's dot with itself: the lanes that published v hold a[.][K0] == v
         const double sg = readlane_d(sd[K0], 4 * (i - CL * K0));
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             if (ss > 1e-200 && ss < 1e200) {
                 const double y = fast_rsqrt(ss);
                 nrm = ss * y;                             // a few 1e-16 relative: the reflector stays orthogonal to that level
-                beta = y * fast_rcp(nrm + fabs(x0));
+                beta = y * fast_rcp(nrm + fabs(x0));      // 1 / (nrm (nrm + |x0|))
             } else {
                 nrm = sqrt(ss);
                 beta = 1.0 / (nrm * (nrm + fabs(x0)));
