@@ -178,25 +178,22 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         }
     };
 
-    // per-lane LDS indices (doubles) of this lane's R entries of the current pivot row, one per column slot:
-    //   ra[k]: where R(c, off + lc) is read  (a word that reads 0.0, stride 0, for columns outside the tile)
-    //   wa[k]: where it is written back      (row lane 0 only; everybody else writes into its dump word)
-    // Both advance by (SWEEP_RS - 1) per step (next row, one column less to the left); the rhs by SWEEP_RS.
-    int ra[CS], wa[CS], rs[CS], ws[CS];
+    // Every lane looks after ONE entry of the pivot row of R: row lane rq of a quad takes column slot rq, i.e. local
+    // column lco = cq + CL rq (the quad's four partial dots are reduce-scattered so that lane rq ends up with the
+    // dot of slot rq; tau is formed once per column and broadcast back over the quad).  ra / wa: LDS indices
+    // (doubles) where that entry is read / written; they advance by SWEEP_RS - 1 per step (next row, one column
+    // less to the left), the rhs by SWEEP_RS.  Columns outside the tile read a zero word and write a dump word.
+    static_assert(CS == 4, "one column slot per row lane of the quad");
+    int ra = 0, wa = 0, rstep = 0;
     const int dump_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + wv * 64 + lane;
     const int zero_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64;
+    const int lco = cq + CL * rq;
     auto init_addr = [&]() {
-#pragma unroll
-        for (int k = 0; k < CS; ++k) {
-            const int lc = cq + CL * k;
-            const bool isr = (k == CS - 1) && (cq == CL - 1);
-            const bool valid = isr || lc < f_ew;
-            ra[k] = valid ? f_off * SWEEP_RS + (isr ? 63 : lc) : zero_i;
-            rs[k] = valid ? (isr ? SWEEP_RS : SWEEP_RS - 1) : 0;
-            const bool wr = valid && rq == 0;
-            wa[k] = wr ? ra[k] : dump_i;
-            ws[k] = wr ? rs[k] : 0;
-        }
+        const bool isr = (rq == CS - 1) && (cq == CL - 1);
+        const bool valid = isr || lco < f_ew;
+        ra = valid ? f_off * SWEEP_RS + (isr ? 63 : lco) : zero_i;
+        wa = valid ? ra : dump_i;
+        rstep = valid ? (isr ? SWEEP_RS : SWEEP_RS - 1) : 0;
     };
 
     auto step = [&](auto tagk, int i) {
@@ -212,39 +209,35 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
         }
         const double x0 = smem[rrow];
-        double rck[CS], sd[CS];
+        const double rck = smem[ra];                       // R(c, off + lco)
+        const bool on = (lco > i) || (rq == CS - 1 && cq == CL - 1);   // left of / at the pivot: retired (the rhs never is)
+        // ---- dots (one partial sum per live slot), reduce-scattered over the quad ---------------------
+        double sp[CS];
 #pragma unroll
-        for (int k = K0; k < CS; ++k) rck[k] = smem[ra[k]];
-        const bool act0 = (cq + CL * K0) > i;             // slot K0: columns left of / at the pivot are retired
-#ifdef SWEEP_PROF
-        if (live) SWEEP_TICK(1);                            // LDS data arrived (the branch forces the wait)
-#endif
-        // ---- dots first: they do not depend on the reflector scalars (four partial sums: short chains)
+        for (int k = 0; k < CS; ++k) {
+            sp[k] = 0.0;
+            if (k >= K0) {
+                double s0 = v[0] * a[0][k];
 #pragma unroll
-        for (int k = K0; k < CS; ++k) {
-#if SWEEP_ACC == 1
-            double s0 = v[0] * a[0][k];
-#pragma unroll
-            for (int rr = 1; rr <= RMAX; ++rr) s0 = fma(v[rr], a[rr][k], s0);
-            sd[k] = quad_sum(s0);
-#elif SWEEP_ACC == 2
-            double s0 = v[0] * a[0][k], s1 = v[1] * a[1][k];
-#pragma unroll
-            for (int rr = 2; rr <= RMAX; ++rr) { if (rr & 1) s1 = fma(v[rr], a[rr][k], s1); else s0 = fma(v[rr], a[rr][k], s0); }
-            sd[k] = quad_sum(s0 + s1);
-#else
-            double s4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int rr = 0; rr <= RMAX; ++rr) s4[rr & 3] = fma(v[rr], a[rr][k], s4[rr & 3]);
-            sd[k] = quad_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
-#endif
+                for (int rr = 1; rr <= RMAX; ++rr) s0 = fma(v[rr], a[rr][k], s0);
+                sp[k] = s0;
+            }
+        }
+        double tot;                                       // lane rq: the full dot of slot rq
+        {
+            const bool b0 = (rq & 1) != 0, b1 = (rq & 2) != 0;
+            double pB = (b0 ? sp[3] : sp[2]) + quad_move<0xB1>(b0 ? sp[2] : sp[3]);
+            if constexpr (K0 <= 1) {
+                double pA = (b0 ? sp[1] : sp[0]) + quad_move<0xB1>(b0 ? sp[0] : sp[1]);
+                tot = (b1 ? pB : pA) + quad_move<0x4E>(b1 ? pA : pB);
+            } else {
+                tot = pB + quad_move<0x4E>(pB);           // slots 0, 1 are retired: lanes 0, 1 hold a copy nobody uses
+                (void)b1;
+            }
         }
         // |column i|^2 = the pivot column's dot with itself: the lanes that published v hold a[.][K0] == v
-        const double sg = readlane_d(sd[K0], 4 * (i - CL * K0));
+        const double sg = readlane_d(tot, 4 * (i - CL * K0) + K0);
         const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
-#ifdef SWEEP_PROF
-        if (sd[CS - 1] != 1.2345e300) SWEEP_TICK(2);        // dots + quad sums done
-#endif
         // ---- reflector scalars (every lane, uniform values) ---------------------------
         double alpha = x0, beta = 0.0;
         if (live) {
@@ -261,19 +254,18 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             alpha = (x0 > 0.0) ? -nrm : nrm;
         }
         const double v0 = x0 - alpha;
-#ifdef SWEEP_PROF
-        if (beta != 1.2345e300) SWEEP_TICK(3);              // scalar chain done
-#endif
-        const double beta0 = act0 ? beta : 0.0;
+        // ---- tau of this lane's column, its R entry, then the rank-1 update of every slot ----------
+        const double tau_own = (on ? beta : 0.0) * fma(v0, rck, tot);
+        smem[on ? wa : dump_i] = fma(-tau_own, v0, rck);
+        if (rq == 0 && cq == 0) smem[rrow] = alpha;
+        ra += rstep; wa += rstep;
         auto slot = [&](auto tags) {
             constexpr int k = decltype(tags)::value;
             if constexpr (k < CS) {
-                const double tau = ((k == K0) ? beta0 : beta) * fma(v0, rck[k], sd[k]);
-                const double rnew = fma(-tau, v0, rck[k]);
+                constexpr int CTRL = (k == 0) ? 0x00 : (k == 1) ? 0x55 : (k == 2) ? 0xAA : 0xFF;   // quad_perm [k,k,k,k]
+                const double tau = quad_move<CTRL>(tau_own);
 #pragma unroll
                 for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
-                const int dst = (k == K0) ? (act0 ? wa[k] : dump_i) : wa[k];
-                smem[dst] = rnew;
             }
         };
         // the slot of the next pivot column first, then its owners publish it while the other slots update
@@ -285,9 +277,6 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         slot(STag<K0 + 1>{});
         slot(STag<K0 + 2>{});
         slot(STag<K0 + 3>{});
-        smem[(rq == 0 && cq == 0) ? rrow : dump_i] = alpha;
-#pragma unroll
-        for (int k = K0; k < CS; ++k) { ra[k] += rs[k]; wa[k] += ws[k]; }
         if (in < f_w && (in & 7) == 0) {
             // first column of the next chunk: slot 8 (KK + 1) / CL, column lane 8 (KK + 1) % CL, two more row slots
             constexpr int KN = (8 * (KK + 1)) / CL;
