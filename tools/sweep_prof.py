@@ -18,7 +18,7 @@ eng.sync()
 buf = (C.c_longlong * 64)()
 eng._lib.msckf_debug_fold_stamps(eng._h, buf, -1000000)
 a = np.frombuffer(buf, dtype=np.int64).reshape(8, 8)
-names = ["loop", "LDS reads", "dots", "scalars", "tau/update/publish", "barrier wait"]
+names = ["loop / idle", "-", "-", "-", "step (reads .. publish)", "barrier wait"]
 steps = 60 * 21 / 8.0
 print("per-wave cycle sums (root sweep), cycles per step assuming %.0f steps per wave" % steps)
 for w in range(8):
