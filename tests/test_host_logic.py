@@ -175,3 +175,20 @@ def test_host_transition_and_augmentation_match_reference(case):
             S = M @ P @ M.T
             assert rel_err((S + S.T) / 2, op["P_after"]) < 1e-14
         P = op["P_after"]
+
+
+def test_band_ok_mirrors_the_planner_rule():
+    """`UpdateEngine.band_ok` (host side, no GPU): the exchange format of a sharded update is chosen from the
+    whole batch -- every track within 10 clone slots and at most 37 clones."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    assert UpdateEngine.band_ok(synth.make_problem(30, 200, 10, seed=1))
+    assert UpdateEngine.band_ok(synth.make_problem(12, 40, 10, seed=2, variable_tracks=True))
+    assert not UpdateEngine.band_ok(synth.make_problem(16, 40, 14, seed=3))        # tracks of 14 slots
+    assert not UpdateEngine.band_ok(synth.make_problem(40, 40, 6, seed=4))         # band R over the LDS budget
+    wide = synth.make_problem(30, 50, 10, seed=5)
+    slots = wide.obs_slot.copy()
+    a, b = int(wide.view_ptr[3]), int(wide.view_ptr[4])
+    slots[b - 1] = min(int(slots[a]) + 12, 29)                                       # one track skips ahead: span 13
+    wide.obs_slot = slots
+    assert not UpdateEngine.band_ok(wide)
