@@ -23,6 +23,11 @@
 //     compile-time loop bounds; each wavefront runs its own straight-line
 //     sequence  [idle barriers] [chunk 0 .. chunk 7] [idle barriers] ...  and all
 //     wavefronts execute the same number of barriers (nsteps).
+//   * inside a step a lane forms one partial dot per live column slot (one running sum each: the step time
+//     follows the FP64 instruction count, not the FMA chain); the quad's partials are reduce-scattered so
+//     that row lane rq holds the dot of slot rq, i.e. every lane looks after ONE column of the pivot row:
+//     it reads that R entry, forms tau, writes the entry back, and tau is broadcast over the quad for the
+//     rank-1 update.  The pivot column's own dot is v^T v: its squared norm costs no extra reduction.
 //   * the rows of the source triangle are fetched two row slots per chunk, one
 //     chunk ahead of their first use; the first two row slots of the NEXT fold are
 //     fetched during the last chunks of the current one.
@@ -85,9 +90,6 @@ __device__ __forceinline__ double quad_sum(double x) {
     return x;
 }
 
-#ifndef SWEEP_ACC
-#define SWEEP_ACC 1      // partial sums per dot: the step is bound by the FP64 instruction count, not by the FMA chain
-#endif
 template <int KK> struct STag { static constexpr int value = KK; };
 
 #ifdef SWEEP_PROF
