@@ -166,12 +166,14 @@ def main():
         gathered = torch.zeros(world * rec, dtype=torch.float64, device="cuda") if rank == 0 else None
         glist = list(gathered.view(world, rec).unbind(0)) if rank == 0 else None
         packed = torch.zeros(world * nblk, dtype=torch.float64, device="cuda") if rank == 0 and world > 1 and not groups else None
-        out = torch.zeros(d + d * d, dtype=torch.float64, device="cuda")
+        # broadcast buffer: on rank 0 the engine's own result range dx | P+ (zero copy), a plain tensor elsewhere
+        out = torch.as_tensor(eng.result_device_view(), device="cuda") if rank == 0 else \
+            torch.zeros(d + d * d, dtype=torch.float64, device="cuda")
 
         def step():
             eng.run_compress()                                   # K1-K5 on the local shard (no root sweep with groups)
             if groups:
-                eng.export_groups(dst_ptr=mine.data_ptr())       # D2D into the torch-owned send buffer (syncs)
+                eng.export_groups(dst_ptr=mine.data_ptr(), count=False)   # D2D into the torch-owned send buffer (syncs)
             else:
                 _, n = eng.export_block(dst_ptr=mine.data_ptr())
                 mine[nblk] = float(n)
@@ -190,8 +192,7 @@ def main():
                     else:
                         src = gathered
                     eng.merge_gain(int(src.data_ptr()), total, n_blocks=world)
-                eng.sync()
-                eng.export_result(out.data_ptr(), out.data_ptr() + d * 8)   # dx | P+ -> broadcast buffer (D2D)
+                eng.sync()                                       # dx | P+ are in the engine's result range = `out`
             dist.broadcast(out, src=0)                           # state for the next update on every rank
 
         for _ in range(args.warmup):

@@ -234,7 +234,7 @@ int msckf_run_merge_gain(msckf_ctx* ctx, const void* blocks, int32_t n_blocks, i
  * when the batch was planned as a merge tree (then use msckf_export_block / msckf_run_merge_gain). */
 int msckf_set_group_exchange(msckf_ctx* ctx, int on);
 size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + N * 3660 */
-int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted);
+int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted /* nullable */);
 int msckf_run_merge_groups(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,
                            int32_t total_accepted /* < 0: the sum of the counts in the records */);
 

@@ -360,11 +360,13 @@ class UpdateEngine:
     def group_record_doubles(self) -> int:
         return int(self._lib.msckf_group_record_doubles(self._h))
 
-    def export_groups(self, dst_ptr: Optional[int] = None):
-        """The shard's group triangles (one record) after `run_compress`; host array or HBM address."""
-        n_acc = C.c_int32(0)
+    def export_groups(self, dst_ptr: Optional[int] = None, count: bool = True):
+        """The shard's group triangles (one record, accepted count included) after `run_compress`; host array
+        or HBM address.  `count=False` skips reading the gate results back (returns -1 for the count)."""
+        n_acc = C.c_int32(-1)
         if dst_ptr is not None:
-            self._check(self._lib.msckf_export_groups(self._h, C.c_void_p(dst_ptr), 1, C.byref(n_acc)), allow_noop=False)
+            self._check(self._lib.msckf_export_groups(self._h, C.c_void_p(dst_ptr), 1, C.byref(n_acc) if count else None),
+                        allow_noop=False)
             return None, int(n_acc.value)
         rec = np.zeros(self.group_record_doubles())
         self._check(self._lib.msckf_export_groups(self._h, rec.ctypes.data_as(C.c_void_p), 0, C.byref(n_acc)),
@@ -382,6 +384,18 @@ class UpdateEngine:
             b = _ffi.f64(records)
             self._check(self._lib.msckf_run_merge_groups(self._h, b.ctypes.data_as(C.c_void_p), int(b.shape[0]), 0,
                                                          int(total_accepted)), allow_noop=False)
+
+    def result_device_view(self):
+        """`dx | P+` of the last run as ONE contiguous HBM range (d + d*d doubles) exposed through
+        `__cuda_array_interface__`: `torch.as_tensor(view, device="cuda")` wraps it without a copy, e.g. as the
+        send buffer of the broadcast that follows the merge on rank 0.  Valid until the engine is closed; its
+        contents change with every run (synchronise the engine's stream first)."""
+        d = 15 + 6 * self._N
+        ptr = int(self._lib.msckf_device_pointer(self._h, 0))
+
+        class _View:
+            __cuda_array_interface__ = {"shape": (d + d * d,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+        return _View()
 
     def export_result(self, dx_ptr: int, P_ptr: int):
         """dx and P+ of the last run into HBM buffers owned by the caller."""

@@ -90,6 +90,18 @@ __device__ __forceinline__ double quad_sum(double x) {
     return x;
 }
 
+// Group exchange: the shard's accepted count (features with accepted == 1) as a double into its record.
+__global__ __launch_bounds__(256) void k_count_accepted(const unsigned char* accepted, int F, double* dst) {
+    __shared__ int part[4];
+    int n = 0;
+    for (int f = threadIdx.x; f < F; f += 256) n += accepted[f] == 1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = (double)(part[0] + part[1] + part[2] + part[3]);
+}
+
 template <int KK> struct STag { static constexpr int value = KK; };
 
 #ifdef SWEEP_PROF

@@ -669,6 +669,11 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (c->F > 0 && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, with_gain || !c->xchg_planned)) != MSCKF_OK) return rc;
+    if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
+        hipLaunchKernelGGL(k_count_accepted, dim3(1), dim3(256), 0, c->stream, ptr<unsigned char>(c->dAcc), c->F,
+                           ptr<double>(c->dRbuf) + c->N);
+        HIPCHK(c, hipGetLastError());
+    }
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     if (with_gain && c->F > 0 && c->root >= 0) {
         if ((rc = launch_gain(c, root_block(c))) != MSCKF_OK) return rc;
@@ -1481,15 +1486,16 @@ int msckf_export_groups(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_acce
         return MSCKF_OK;
     }
     if (!c->xchg_planned) return MSCKF_ERR_STATE;     // tree plan (wide tracks, N > 37): use msckf_export_block
+    if (c->ran_gain) return MSCKF_ERR_STATE;           // records come out of msckf_run_compress (it also counts the accepted)
+    // the shard's accepted count already sits in the record (double N, k_count_accepted): the merging rank sums them
     HIPCHK(c, hipMemcpyAsync(dst, c->dRbuf.p, bytes, device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    int counters[4] = {0, 0, 0, 0};
-    if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;       // syncs
-    // the shard's accepted count rides in the record (double N): the merging rank sums them
-    const double nacc = (double)counters[0];
-    double* slot = static_cast<double*>(dst) + c->N;
-    if (device_ptr) HIPCHK(c, hipMemcpy(slot, &nacc, 8, hipMemcpyHostToDevice));
-    else *slot = nacc;
-    if (n_accepted) *n_accepted = counters[0];
+    if (n_accepted) {                                  // optional: costs a device-to-host copy of the gate results
+        int counters[4] = {0, 0, 0, 0};
+        if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;       // syncs
+        *n_accepted = counters[0];
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return MSCKF_OK;
 }
 

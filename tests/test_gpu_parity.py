@@ -405,3 +405,17 @@ def test_group_exchange_refuses_tree_planned_batches(eng):
         assert blk.shape == (96, 97) and n > 0
     finally:
         eng.set_group_exchange(False)
+
+
+def test_result_device_view_is_dx_and_P(eng):
+    """`result_device_view` exposes dx | P+ of the last run as one HBM range (the broadcast buffer of rank 0)."""
+    torch = pytest.importorskip("torch")
+    from msckf_amd import synth
+    prob = synth.make_problem(12, 80, 6, seed=61)
+    eng.set_group_exchange(False)
+    eng.load(prob); eng.run(); eng.sync()
+    res = eng.result()
+    o = torch.as_tensor(eng.result_device_view(), device="cuda").cpu().numpy()
+    d = prob.d
+    assert o.shape == (d + d * d,)
+    assert np.array_equal(o[:d], res.dx) and np.array_equal(o[d:].reshape(d, d), res.P_new)
