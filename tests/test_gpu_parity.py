@@ -241,6 +241,34 @@ out = torch.zeros(prob.d + prob.d ** 2, dtype=torch.float64, device='cuda:0')
 eng.export_result(out.data_ptr(), out.data_ptr() + 8 * prob.d)
 torch.cuda.synchronize()
 assert np.array_equal(out[:prob.d].cpu().numpy(), res.dx)
+# rank 0's broadcast buffer: the engine's own result range dx | P+ wrapped without a copy
+view = torch.as_tensor(eng.result_device_view(), device='cuda')
+assert view.shape == (prob.d + prob.d ** 2,)
+assert np.array_equal(view[:prob.d].cpu().numpy(), res.dx)
+assert np.array_equal(view[prob.d:].cpu().numpy().reshape(prob.d, prob.d), res.P_new)
+# group exchange through HBM buffers: records exported without reading the gate back, counts taken from the records
+from msckf_amd import synth
+from msckf_amd.shard import partition_features as pf
+from oracle import msckf_oracle as oracle
+prob3 = synth.make_problem(20, 300, 8, seed=7)
+ref3 = oracle.update(prob3, dense_noise=False)
+eng3 = UpdateEngine(max_clones=20, max_features=300, max_track=8)
+eng3.set_group_exchange(True)
+rec = eng3.group_record_doubles() if False else None
+shards = pf(prob3.view_ptr, 3)
+bufs = None
+for i, (lo, hi) in enumerate(shards):
+    eng3.load(prob3.subset(lo, hi)); eng3.run_compress()
+    if bufs is None:
+        bufs = torch.zeros(3 * eng3.group_record_doubles(), dtype=torch.float64, device='cuda:0')
+    _, n3 = eng3.export_groups(dst_ptr=bufs.data_ptr() + i * eng3.group_record_doubles() * 8, count=False)
+    assert n3 == -1
+torch.cuda.synchronize()
+eng3.set_state(prob3)
+eng3.merge_groups(int(bufs.data_ptr()), -1, n_records=3)
+r3 = eng3.result()
+assert r3.status == 0 and int(r3.stats['n_accepted']) == int(ref3['accepted'].sum())
+assert rel_err(r3.dx, ref3['dx']) < 1e-8 and rel_err(r3.P_new, ref3['P_new']) < 1e-8
 # the bench's N>1 data path with 3 shards on one device: blocks gathered in a torch HBM buffer
 from msckf_amd.shard import partition_features
 prob2, ref2 = load_golden('cfg2_B')
@@ -406,16 +434,3 @@ def test_group_exchange_refuses_tree_planned_batches(eng):
     finally:
         eng.set_group_exchange(False)
 
-
-def test_result_device_view_is_dx_and_P(eng):
-    """`result_device_view` exposes dx | P+ of the last run as one HBM range (the broadcast buffer of rank 0)."""
-    torch = pytest.importorskip("torch")
-    from msckf_amd import synth
-    prob = synth.make_problem(12, 80, 6, seed=61)
-    eng.set_group_exchange(False)
-    eng.load(prob); eng.run(); eng.sync()
-    res = eng.result()
-    o = torch.as_tensor(eng.result_device_view(), device="cuda").cpu().numpy()
-    d = prob.d
-    assert o.shape == (d + d * d,)
-    assert np.array_equal(o[:d], res.dx) and np.array_equal(o[d:].reshape(d, d), res.P_new)
