@@ -254,7 +254,6 @@ prob3 = synth.make_problem(20, 300, 8, seed=7)
 ref3 = oracle.update(prob3, dense_noise=False)
 eng3 = UpdateEngine(max_clones=20, max_features=300, max_track=8)
 eng3.set_group_exchange(True)
-rec = eng3.group_record_doubles() if False else None
 shards = pf(prob3.view_ptr, 3)
 bufs = None
 for i, (lo, hi) in enumerate(shards):
