@@ -133,6 +133,7 @@ struct msckf_ctx {
     std::vector<SweepFold> x_sfolds;
     int x_n_merges = 0;
     size_t x_root_off = 0, x_zero_off = 0;
+    long long x_rec_base = 0;             // where the records lay (offset from the workspace base) when the plan was made
     size_t rbuf_doubles = 0;              // used by the plan
     size_t gather_off = 0;                // region for gathered shard blocks
     int gather_cap = 0;
@@ -1522,11 +1523,15 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
         c->x_plan_valid = false;
     }
     double* rb = ptr<double>(c->dRbuf);
-    HIPCHK(c, hipMemcpyAsync(rb + o_rec, records, (size_t)n_rec * rec * 8,
-                             device_ptr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    // which groups does each record carry?  (N flags at the head of every record)
+    // records already in HBM are folded where they lie (sources are offsets from the workspace base, which may
+    // point outside it); host records are staged behind the local plan
+    const double* recs = rb + o_rec;
+    if (device_ptr) recs = static_cast<const double*>(records);
+    else HIPCHK(c, hipMemcpyAsync(rb + o_rec, records, (size_t)n_rec * rec * 8, hipMemcpyHostToDevice, c->stream));
+    const long long rec_base = (long long)(recs - rb);
+    // which groups does each record carry?  (N flags and the accepted count at the head of every record)
     std::vector<double> head((size_t)n_rec * (N + 1)), key((size_t)n_rec * N);
-    HIPCHK(c, hipMemcpy2DAsync(head.data(), (size_t)(N + 1) * 8, rb + o_rec, rec * 8, (size_t)(N + 1) * 8, n_rec,
+    HIPCHK(c, hipMemcpy2DAsync(head.data(), (size_t)(N + 1) * 8, recs, rec * 8, (size_t)(N + 1) * 8, n_rec,
                                hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double acc_sum = 0.0;
@@ -1535,7 +1540,8 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
         acc_sum += head[(size_t)r * (N + 1) + N];
     }
     if (total_accepted < 0) total_accepted = (int32_t)(acc_sum + 0.5);    // the counts the shards wrote into their records
-    const bool reuse = c->x_plan_valid && c->x_nrec == n_rec && c->x_root_off == o_root && c->x_key == key;
+    const bool reuse = c->x_plan_valid && c->x_nrec == n_rec && c->x_root_off == o_root && c->x_rec_base == rec_base &&
+                       c->x_key == key;
     if (!reuse) {
         c->x_snodes.clear(); c->x_sfolds.clear();
         const int fold_base = (int)c->sfolds.size();      // the tables sit behind the local plan's
@@ -1546,7 +1552,7 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
             const int w = 6 * (std::min(s0 + SWEEP_MAX_W / 6, N) - s0);
             std::vector<long long> src;
             for (int r = 0; r < n_rec; ++r)
-                if (key[(size_t)r * N + s0] != 0.0) src.push_back((long long)(o_rec + (size_t)r * rec + N + 1 + (size_t)s0 * XCHG_SLOT));
+                if (key[(size_t)r * N + s0] != 0.0) src.push_back(rec_base + (long long)((size_t)r * rec + N + 1 + (size_t)s0 * XCHG_SLOT));
             if (src.empty()) continue;
             if (src.size() == 1) { groups.push_back({src[0], s0, w}); continue; }
             SweepNode m{};
@@ -1588,7 +1594,8 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
         if (!all_f.empty()) HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, all_f.data(), all_f.size() * sizeof(SweepFold), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(rb + o_mrg, 0, (o_end - o_mrg) * 8, c->stream));   // merged triangles, root block, zero words
         HIPCHK(c, hipStreamSynchronize(c->stream));                                  // all_n / all_f are locals
-        c->x_key = key; c->x_nrec = n_rec; c->x_root_off = o_root; c->x_zero_off = o_zero; c->x_plan_valid = true;
+        c->x_key = key; c->x_nrec = n_rec; c->x_root_off = o_root; c->x_zero_off = o_zero; c->x_rec_base = rec_base;
+        c->x_plan_valid = true;
     }
     if (c->x_snodes.empty()) {            // no shard has a track: nothing to update
         c->ran = true; c->ran_gain = false; c->acc_override = 0;
