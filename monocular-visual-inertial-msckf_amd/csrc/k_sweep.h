@@ -33,7 +33,8 @@
 //     fetched during the last chunks of the current one.
 //
 // The host (build_plan_band) orders the folds by first column and assigns
-//   t0[0] = 1,  t0[g] = max(t0[g-1] + off[g] - off[g-1] + 1,  t0[g-NF] + w[g-NF] + 1)
+//   t0[0] = 0 (adopted: its rows are copied into R),  t0[1] = 1,
+//   t0[g] = max(t0[g-1] + off[g] - off[g-1] + 1,  t0[g-NF] + w[g-NF] + 1)
 // (pipeline lag / wavefront reuse).  A fold's tile must cover the envelope of
 // the R rows it meets (ew >= w: columns [off, off+ew) can fill in).
 #pragma once
@@ -52,7 +53,8 @@ struct SweepFold {
 };
 
 struct SweepNode {
-    int fold_begin, fold_end;   // folds [begin, end): fold i runs on wavefront (i - begin) % NW
+    int fold_begin, fold_end;   // folds [begin, end); a first fold with t0 == 0 is adopted (copied into R), the others
+                                // run on fold slot (i - first scheduled) % NF
     int wtot;                   // columns of the node's R
     int nsteps;                 // macro steps
     long long out_off;          // output block in rbuf: row-major wtot x (wtot+1)
@@ -136,6 +138,18 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
 
     for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
     if (t < 2) smem[nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + t] = 0.0;
+    // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
+    const SweepFold f0 = p.folds[nd.fold_begin];
+    const int adopt = (nd.fold_end > nd.fold_begin && f0.t0 == 0) ? 1 : 0;
+    if (adopt) {
+        __syncthreads();
+        const double* src = p.rbuf + f0.src_off;
+        const int ldw = f0.w + 1;
+        for (int e = t; e < f0.w * ldw; e += 64 * NW) {
+            const int r = e / ldw, lc = e - r * ldw;
+            if (lc >= r) Rb[(size_t)(f0.off + r) * SWEEP_RS + (lc == f0.w ? 63 : lc - r)] = src[e];
+        }
+    }
 
     double a[16][CS];
     double nxt[2][CS];
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     };
 
     __syncthreads();                                       // R zeroed
-    int fi = nd.fold_begin + fs;
+    int fi = nd.fold_begin + adopt + fs;
     bool have = fi < fold_end;
     if (have) {
         read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);

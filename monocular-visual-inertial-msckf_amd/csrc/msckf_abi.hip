@@ -296,10 +296,12 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
 // Returns false when the batch does not qualify (wide tracks, R band over the LDS budget): tree plan then.
 void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps) {
     int last = 0;
-    for (int g = begin; g < end; ++g) {
+    if (end > begin) folds[begin].t0 = 0;                  // adopted: copied into the empty R, no elimination steps
+    const int first = begin + 1;
+    for (int g = first; g < end; ++g) {
         int t0 = 1;                                        // step t0 - 1 publishes the fold's first column
-        if (g > begin) t0 = folds[g - 1].t0 + (folds[g].off - folds[g - 1].off) + 1;
-        if (g - begin >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].w + 1);
+        if (g > first) t0 = folds[g - 1].t0 + (folds[g].off - folds[g - 1].off) + 1;
+        if (g - first >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].w + 1);
         folds[g].t0 = t0;
         last = std::max(last, t0 + folds[g].w);
     }
