@@ -154,7 +154,7 @@ def main():
         # exchange format (every rank sees the whole batch, so all agree): group triangles when the batch
         # runs the band pipeline -- each rank stops in front of its root sweep, rank 0 folds the shards' groups
         # and runs ONE root sweep -- else the root blocks [R | Q^T r] and the fold-tree merge
-        groups = UpdateEngine.band_ok(prob)
+        groups = eng.band_ok(prob)
         eng.set_group_exchange(groups)
         eng.load(local)
         nblk = eng.group_record_doubles() if groups else eng.block_doubles()

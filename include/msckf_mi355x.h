@@ -233,6 +233,11 @@ int msckf_run_merge_gain(msckf_ctx* ctx, const void* blocks, int32_t n_blocks, i
  * msckf_set_group_exchange must precede msckf_set_features; msckf_export_groups returns MSCKF_ERR_STATE
  * when the batch was planned as a merge tree (then use msckf_export_block / msckf_run_merge_gain). */
 int msckf_set_group_exchange(msckf_ctx* ctx, int on);
+/* The planner's rule, for callers that must agree on the exchange format BEFORE sharding a batch: 1 when a
+ * batch of tracks spanning at most `max_span` clone slots over N clones is planned as the band pipeline on
+ * this context (so msckf_export_groups will work), 0 when it gets the merge tree (MSCKF_FLAG_TREE_PLAN,
+ * tracks wider than the sweep tiles, band R over the LDS budget): then use msckf_export_block. */
+int msckf_band_rule(const msckf_ctx* ctx, int32_t N, int32_t max_span);
 size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + N * 3660 */
 int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted /* nullable */);
 int msckf_run_merge_groups(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,

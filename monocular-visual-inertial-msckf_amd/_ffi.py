@@ -21,7 +21,7 @@ SYMBOLS = [
     "msckf_create", "msckf_destroy", "msckf_strerror", "msckf_last_error", "msckf_device_count",
     "msckf_update", "msckf_set_state", "msckf_set_features", "msckf_run", "msckf_run_timed", "msckf_sync",
     "msckf_get_result", "msckf_commit_covariance", "msckf_run_compress", "msckf_block_doubles",
-    "msckf_export_block", "msckf_run_merge_gain", "msckf_set_group_exchange", "msckf_group_record_doubles",
+    "msckf_export_block", "msckf_run_merge_gain", "msckf_set_group_exchange", "msckf_band_rule", "msckf_group_record_doubles",
     "msckf_export_groups", "msckf_run_merge_groups", "msckf_export_result", "msckf_import_covariance", "msckf_debug_gate", "msckf_debug_compressed", "msckf_debug_fold_stamps",
     "msckf_device_pointer", "msckf_stream",
     "msckf_set_tracks", "msckf_run_select", "msckf_clear_selection", "msckf_get_selection",
@@ -105,6 +105,8 @@ def load():
     lib.msckf_run_merge_gain.restype = C.c_int
     lib.msckf_set_group_exchange.argtypes = [vp, C.c_int]
     lib.msckf_set_group_exchange.restype = C.c_int
+    lib.msckf_band_rule.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.msckf_band_rule.restype = C.c_int
     lib.msckf_group_record_doubles.argtypes = [vp]
     lib.msckf_group_record_doubles.restype = C.c_size_t
     lib.msckf_export_groups.argtypes = [vp, vp, C.c_int, _ip]

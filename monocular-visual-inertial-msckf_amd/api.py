@@ -338,20 +338,28 @@ class UpdateEngine:
                                                        int(total_accepted)), allow_noop=False)
 
     # -- group exchange: the sharded band pipeline ------------------------------
-    BAND_MAX_SPAN = 10        # clone slots a track may span (k_sweep tiles are 60 columns wide)
-    BAND_MAX_CLONES = 37      # the band R of 6 N rows x 64 doubles has to fit LDS
-
-    @classmethod
-    def band_ok(cls, prob: UpdateProblem) -> bool:
-        """True when every shard of `prob` is planned as the band pipeline (the rule of `build_plan_band`):
-        then the ranks may exchange group triangles (`export_groups` / `merge_groups`) instead of root blocks."""
-        if prob.N > cls.BAND_MAX_CLONES or prob.F == 0:
-            return False
+    @staticmethod
+    def max_span(prob: UpdateProblem) -> int:
+        """Longest track of the batch in clone slots (last slot - first slot + 1)."""
+        if prob.F == 0:
+            return 0
         vp = np.asarray(prob.view_ptr)
         slots = np.asarray(prob.obs_slot).reshape(-1)
         lo = np.minimum.reduceat(slots, vp[:-1])
         hi = np.maximum.reduceat(slots, vp[:-1])
-        return bool((hi - lo + 1).max() <= cls.BAND_MAX_SPAN)
+        return int((hi - lo + 1).max())
+
+    def band_ok(self, prob: UpdateProblem) -> bool:
+        """True when every shard of `prob` is planned as the band pipeline ON THIS ENGINE: the library's own
+        rule (`msckf_band_rule`: plan flag, sweep tile width, LDS budget), asked with the whole batch's longest
+        track, so that all ranks agree before sharding.  Then the ranks may exchange group triangles
+        (`export_groups` / `merge_groups`); otherwise root blocks (`export_block` / `merge_gain`)."""
+        if prob.F == 0:
+            return False
+        rc = self._lib.msckf_band_rule(self._h, int(prob.N), self.max_span(prob))
+        if rc < 0:
+            self._check(rc, allow_noop=False)
+        return rc == 1
 
     def set_group_exchange(self, on: bool = True):
         """Plan the following batches with the group-record layout (call before `load`)."""

@@ -308,14 +308,21 @@ void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nste
     *nsteps = last;
 }
 
+// THE rule for the band pipeline (msckf_band_rule exports it): N clones, longest track span in clone slots
+bool band_rule(const msckf_ctx* c, int N, int max_span) {
+    if (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) return false;                // tree plan forced
+    if (N < 1 || sweep_lds_bytes(6 * N, SWEEP_NW, SWEEP_WPF) > (size_t)FOLD_LDS_BYTES) return false;
+    return 6 * max_span <= SWEEP_MAX_W;
+}
+
 bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                      const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     const int F = c->F, N = c->N, dc = 6 * N;
-    if (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) return false;                // tree plan forced
-    if (sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF) > (size_t)FOLD_LDS_BYTES) return false;
     auto live = [&](int i) { return !valid || ((*valid)[i] & 1); };
+    int max_span = 0;
     for (int f = 0; f < F; ++f)
-        if (live(f) && 6 * (fmax[f] - fmin[f] + 1) > SWEEP_MAX_W) return false;
+        if (live(f)) max_span = std::max(max_span, fmax[f] - fmin[f] + 1);
+    if (!band_rule(c, N, max_span)) return false;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 250;
     c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear();
     // group exchange: the record [N flags | accepted count | N slots of XCHG_SLOT doubles] heads the workspace; the triangle of
@@ -729,35 +736,44 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
-    for (auto& e : c->ev) (void)hipEventCreate(&e);
+    // every failure here is reported at create time (a dropped attribute would only surface later as an
+    // opaque launch error of the first kernel that needs the LDS)
+    hipError_t cerr = hipSuccess;
+    const char* cwhat = "";
+    auto CK = [&](hipError_t e, const char* what) { if (cerr == hipSuccess && e != hipSuccess) { cerr = e; cwhat = what; } };
+    for (auto& e : c->ev) CK(hipEventCreate(&e), "hipEventCreate");
+    auto lds_attr = [&](const void* f, int bytes, const char* what) {
+        CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
+    };
     // kernels that use more than the default 64 KiB of dynamic LDS
     {
 #define FK(RPT, CPT) reinterpret_cast<const void*>(&k_fold<FOLD_T, FOLD_RL, RPT, CPT>)
         const void* fk[] = {FK(FOLD_RPT_LEAF, FOLD_CPT1), FK(FOLD_RPT_BIG, FOLD_CPT1), FK(FOLD_RPT_LEAF, FOLD_CPT2),
                             FK(FOLD_RPT_BIG, FOLD_CPT2), FK(FOLD_RPT_W3, FOLD_CPT3)};
 #undef FK
-        for (const void* f : fk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
+        for (const void* f : fk) lds_attr(f, FOLD_LDS_BYTES, "k_fold LDS attribute");
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold_g<FOLDG_T, 12, 6>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fold_g<FOLDG_T, 6, 10>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, FOLD_LDS_BYTES);
+    lds_attr(reinterpret_cast<const void*>(&k_fold_g<FOLDG_T, 12, 6>), FOLD_LDS_BYTES, "k_fold_g LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_fold_g<FOLDG_T, 6, 10>), FOLD_LDS_BYTES, "k_fold_g LDS attribute");
     {
 #define SK(NR, UN) reinterpret_cast<const void*>(&k_solve_lds<NR, SOLVE_WAVES, SOLVE_ROWS, UN>)
         const void* sk[] = {SK(1, true), SK(2, true), SK(3, true), SK(1, false), SK(2, false), SK(3, false)};
 #undef SK
-        for (const void* f : sk) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES - 1024);
+        for (const void* f : sk) lds_attr(f, LDS_MAX_BYTES - 1024, "k_solve_lds LDS attribute");
     }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              FOLD_LDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chol<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        LDS_MAX_BYTES - 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<24>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_MAX_BYTES - 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<32>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_MAX_BYTES - 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_feature<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS_MAX_BYTES - 1024);
+    lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_chol<512>), LDS_MAX_BYTES - 1024, "k_chol LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_feature<24>), LDS_MAX_BYTES - 1024, "k_feature LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_feature<32>), LDS_MAX_BYTES - 1024, "k_feature LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_feature<64>), LDS_MAX_BYTES - 1024, "k_feature LDS attribute");
+    // k_propagate keeps T = Phi P[:15, :] (15 x d) + a 15 x 15 block in LDS
+    if (((size_t)15 * (15 + 6 * c->maxN) + 225) * 8 > (size_t)(LDS_MAX_BYTES - 1024)) { msckf_destroy(c); return MSCKF_ERR_ARG; }
+    lds_attr(reinterpret_cast<const void*>(&k_propagate), LDS_MAX_BYTES - 1024, "k_propagate LDS attribute");
+    if (cerr != hipSuccess) {
+        std::fprintf(stderr, "msckf_create: %s: %s\n", cwhat, hipGetErrorString(cerr));
+        msckf_destroy(c);
+        return MSCKF_ERR_HIP;
+    }
     const int N = c->maxN, d = 15 + 6 * N, dc = 6 * N;
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
@@ -851,11 +867,15 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_us();
     const int N = c->N;
-    c->F = F;
+    // the previous batch is gone from here on: a validation failure below must not leave `have_features`
+    // standing over arenas / plan that describe another F (run() then returns MSCKF_ERR_STATE)
+    c->have_features = false;
+    c->feature_launched = false;
     c->ran = false;
     c->have_tracks = false;
     c->use_select = false;
     if (F == 0) {
+        c->F = 0;
         c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->band_plan = false; c->root = -1; c->perm.clear();
         c->have_features = true;
@@ -887,7 +907,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     }
     if (c->n_chi2 <= 2 * Mmax) return MSCKF_ERR_ARG;
     const int sumM = view_ptr[F];
-    c->sumM = sumM; c->Mmax = Mmax;
+    c->F = F; c->sumM = sumM; c->Mmax = Mmax;            // validated: commit the batch size
     // counting sort by (first slot, last slot): stable, O(F + N^2)
     c->perm.resize(F);
     {
@@ -1078,7 +1098,10 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     c->us_d2h = (float)(now_us() - t0);
     if (st) {
         std::memset(st, 0, sizeof(*st));
-        st->n_features = c->F - counters[3]; st->n_accepted = n_acc; st->n_rejected = c->F - counters[3] - n_acc;
+        st->n_features = c->F - counters[3]; st->n_accepted = n_acc;
+        // features whose gate matrix was not SPD never reached the chi-square test (the reference would have raised
+        // LinAlgError at MSCKF.py:562): they are reported in not_spd, not counted as gate rejections (:578)
+        st->n_rejected = std::max(0, c->F - counters[3] - n_acc - counters[2]);
         st->stacked_rows = counters[1]; st->not_spd = counters[2];
         st->n_leaves = c->n_leaves;
         st->n_levels = (int)c->levels.size() + (c->band_plan ? (int)c->sweep_levels.size() + 1 : 0);
@@ -1096,6 +1119,11 @@ int msckf_commit_covariance(msckf_ctx* c) {
     if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
     const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
+    // a non-positive Cholesky pivot leaves garbage in P_out: keep the prior (msckf_get_result reports the same code)
+    int status = 0;
+    HIPCHK(c, hipMemcpyAsync(&status, c->dStatus.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (status != 0) return MSCKF_ERR_NOT_SPD;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSCKF_OK;
@@ -1472,6 +1500,11 @@ int msckf_set_group_exchange(msckf_ctx* c, int on) {
     return MSCKF_OK;
 }
 
+int msckf_band_rule(const msckf_ctx* c, int32_t N, int32_t max_span) {
+    if (!c || N < 0 || max_span < 0) return MSCKF_ERR_ARG;
+    return band_rule(c, N, max_span) ? 1 : 0;
+}
+
 size_t msckf_group_record_doubles(const msckf_ctx* c) {
     return c ? (size_t)c->N + 1 + (size_t)c->N * XCHG_SLOT : 0;
 }
@@ -1507,7 +1540,7 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
     if (!c->have_state) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->N, dc = c->dc;
-    if (N < 1 || sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF) > (size_t)FOLD_LDS_BYTES) return MSCKF_ERR_ARG;
+    if (!band_rule(c, N, 1)) return MSCKF_ERR_ARG;
     const size_t rec = msckf_group_record_doubles(c);
     // workspace behind the local plan: records | merged group triangles | root block | zero words
     const size_t o_rec = c->gather_off, o_mrg = o_rec + (size_t)n_rec * rec, o_root = o_mrg + (size_t)N * XCHG_SLOT;

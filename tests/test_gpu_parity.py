@@ -396,8 +396,8 @@ def test_group_exchange_shards_on_one_gpu(N, F, M, shards, kw):
     from oracle import msckf_oracle as oracle
     prob = synth.make_problem(N, F, M, seed=51, **kw)
     ref = oracle.update(prob, dense_noise=False)
-    assert UpdateEngine.band_ok(prob)
     with UpdateEngine(max_clones=N, max_features=F, max_track=max(M, 2)) as e:
+        assert e.band_ok(prob)
         e.set_group_exchange(True)
         recs, total, acc = [], 0, np.zeros(prob.F, dtype=np.uint8)
         for lo, hi in partition_features(prob.view_ptr, shards):
@@ -433,3 +433,145 @@ def test_group_exchange_refuses_tree_planned_batches(eng):
     finally:
         eng.set_group_exchange(False)
 
+
+
+# ---- regressions for the round-1 review ------------------------------------------------------
+
+def test_failed_upload_invalidates_the_previous_batch(eng):
+    """A batch that fails validation must not leave the previous batch standing: run() after the failed
+    upload returns MSCKF_ERR_STATE instead of launching over buffers sized for another F."""
+    from msckf_amd import synth
+    from msckf_amd._ffi import EngineError, ERR_DUP_SLOT, ERR_STATE, ERR_ARG
+    good = synth.make_problem(12, 40, 6, seed=61)
+    eng.load(good)
+    eng.run()
+    assert eng.result().status == 0
+    bad = synth.make_problem(12, 400, 6, seed=62)            # larger than the good batch
+    slots = bad.obs_slot.copy()
+    a = int(bad.view_ptr[350])
+    slots[a + 1] = slots[a]                                  # a track observes the same clone twice
+    bad.obs_slot = slots
+    with pytest.raises(EngineError) as ei:
+        eng.set_features(bad)
+    assert ei.value.code == ERR_DUP_SLOT
+    with pytest.raises(EngineError) as ei:
+        eng.run()
+    assert ei.value.code == ERR_STATE
+    with pytest.raises(EngineError) as ei:
+        eng.run_compress()
+    assert ei.value.code == ERR_STATE
+    bad2 = synth.make_problem(12, 50, 6, seed=63)
+    vp = bad2.view_ptr.copy(); vp[0] = 1                      # CSR must start at 0
+    bad2.view_ptr = vp
+    with pytest.raises(EngineError) as ei:
+        eng.set_features(bad2)
+    assert ei.value.code == ERR_ARG
+    with pytest.raises(EngineError):
+        eng.run()
+    eng.set_features(good)                                   # and the engine recovers
+    eng.run()
+    assert eng.result().status == 0
+
+
+def test_commit_refuses_a_failed_cholesky(eng):
+    """S not positive definite: get_result reports MSCKF_ERR_NOT_SPD and hands back the prior;
+    commit_covariance must do the same instead of copying the garbage P_out over the resident prior."""
+    from msckf_amd import synth
+    from msckf_amd._ffi import EngineError, ERR_NOT_SPD
+    prob = synth.make_problem(30, 300, 10, seed=64)
+    # indefinite P whose 10-clone diagonal blocks stay SPD: a huge coupling between clone 0 and clone 29
+    # (no track sees both, so every per-feature gate passes; the 180 x 180 innovation covariance is indefinite)
+    P = 1e-3 * np.eye(prob.d)
+    P[15, 15 + 6 * 29] = P[15 + 6 * 29, 15] = 50.0
+    P[18, 18 + 6 * 29] = P[18 + 6 * 29, 18] = -50.0
+    prob.P = P
+    eng.load(prob)
+    eng.run()
+    with pytest.raises(EngineError) as ei:
+        eng.result()
+    assert ei.value.code == ERR_NOT_SPD
+    with pytest.raises(EngineError) as ei:
+        eng.commit_covariance()
+    assert ei.value.code == ERR_NOT_SPD
+    assert np.array_equal(eng.covariance(), P)               # the resident prior is untouched
+
+
+def test_band_rule_comes_from_the_library():
+    """The exchange format of a sharded update is the library's own rule (msckf_band_rule): it follows the
+    engine's plan flag and tile limits, so a tree-planned engine never promises group records."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from msckf_amd.shard import HipShardBackend
+    narrow = synth.make_problem(30, 200, 10, seed=1)
+    with UpdateEngine(max_clones=64, max_features=500, max_track=31) as e:
+        assert e.band_ok(narrow)
+        assert e.band_ok(synth.make_problem(12, 40, 10, seed=2, variable_tracks=True))
+        assert not e.band_ok(synth.make_problem(40, 40, 31, seed=3))           # tracks of 31 slots: merge tree
+        assert not e.band_ok(synth.make_problem(5, 0, 3, seed=0))              # empty batch
+    with UpdateEngine(max_clones=30, max_features=500, max_track=10, plan="tree") as e:
+        assert not e.band_ok(narrow)
+        be = HipShardBackend(e)
+        be.prepare(narrow)
+        assert not be.groups
+        blk, n, acc = be.compress(narrow)                                       # block exchange on a tree-planned engine
+        assert blk.shape == (180, 181) and n == int(acc.sum()) > 0
+
+
+# ---- BASELINE.json configs[3] and configs[4] at full size ------------------------------------------
+
+_BIG = {}
+
+
+def _big_case(N, F, M):
+    """Problem + oracle result, computed once per session (the oracle takes tens of seconds at these sizes)."""
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    key = (N, F, M)
+    if key not in _BIG:
+        prob = synth.make_problem(N, F, M, seed=0)
+        _BIG[key] = (prob, oracle.update(prob, dense_noise=False))
+    return _BIG[key]
+
+
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_config4_full_size_sharded(shards):
+    """BASELINE.json configs[3]: N = 30, 8000 features, track 10, feature-sharded 2 / 4 / 8 ways.  Logical shards
+    on one GPU: every shard exports its records, the root merges them (two-level group merges at this size),
+    runs one root sweep and K6-K7; against the oracle on the whole batch."""
+    from msckf_amd.api import UpdateEngine
+    from msckf_amd.shard import partition_features
+    prob, ref = _big_case(30, 8000, 10)
+    with UpdateEngine(max_clones=30, max_features=8000, max_track=10) as e:
+        groups = e.band_ok(prob)
+        e.set_group_exchange(groups)
+        recs, total, acc = [], 0, np.zeros(prob.F, dtype=np.uint8)
+        for lo, hi in partition_features(prob.view_ptr, shards):
+            e.load(prob.subset(lo, hi))
+            e.run_compress()
+            rec, n = e.export_groups() if groups else e.export_block()
+            acc[lo:hi] = e.result().accepted
+            recs.append(rec); total += n
+        e.set_state(prob)
+        if groups:
+            e.merge_groups(np.stack(recs), -1)
+        else:
+            e.merge_gain(np.stack(recs), total)
+        res = e.result()
+        assert res.status == 0 and total == int(ref["accepted"].sum())
+        assert np.array_equal(acc, ref["accepted"])
+        assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        e.set_group_exchange(False)
+        one = e.update_problem(prob)                         # and the unsharded update of the same batch
+        assert rel_err(one.dx, ref["dx"]) < TOL and rel_err(one.P_new, ref["P_new"]) < TOL
+
+
+def test_config5_full_size_fp64():
+    """BASELINE.json configs[4] in fp64: N = 50, 20000 features, track 15 (d = 315, 540000 stacked rows)."""
+    from msckf_amd.api import UpdateEngine
+    prob, ref = _big_case(50, 20000, 15)
+    with UpdateEngine(max_clones=50, max_features=20000, max_track=15) as e:
+        res = e.update_problem(prob)
+        assert res.status == 0
+        assert np.array_equal(res.accepted, ref["accepted"])
+        assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        assert np.array_equal(res.P_new, res.P_new.T)

@@ -177,18 +177,19 @@ def test_host_transition_and_augmentation_match_reference(case):
         P = op["P_after"]
 
 
-def test_band_ok_mirrors_the_planner_rule():
-    """`UpdateEngine.band_ok` (host side, no GPU): the exchange format of a sharded update is chosen from the
-    whole batch -- every track within 10 clone slots and at most 37 clones."""
+def test_max_span_of_a_batch():
+    """`UpdateEngine.max_span` (host side, no GPU): the longest track of the whole batch in clone slots is what
+    every rank passes to the library's `msckf_band_rule` before sharding (the rule itself lives in the library
+    and is tested on the GPU, tests/test_gpu_parity.py::test_band_rule_comes_from_the_library)."""
     from msckf_amd import synth
     from msckf_amd.api import UpdateEngine
-    assert UpdateEngine.band_ok(synth.make_problem(30, 200, 10, seed=1))
-    assert UpdateEngine.band_ok(synth.make_problem(12, 40, 10, seed=2, variable_tracks=True))
-    assert not UpdateEngine.band_ok(synth.make_problem(16, 40, 14, seed=3))        # tracks of 14 slots
-    assert not UpdateEngine.band_ok(synth.make_problem(40, 40, 6, seed=4))         # band R over the LDS budget
+    assert UpdateEngine.max_span(synth.make_problem(30, 200, 10, seed=1)) == 10
+    assert UpdateEngine.max_span(synth.make_problem(12, 40, 10, seed=2, variable_tracks=True)) <= 10
+    assert UpdateEngine.max_span(synth.make_problem(16, 40, 14, seed=3)) == 14
     wide = synth.make_problem(30, 50, 10, seed=5)
     slots = wide.obs_slot.copy()
     a, b = int(wide.view_ptr[3]), int(wide.view_ptr[4])
     slots[b - 1] = min(int(slots[a]) + 12, 29)                                       # one track skips ahead: span 13
     wide.obs_slot = slots
-    assert not UpdateEngine.band_ok(wide)
+    assert UpdateEngine.max_span(wide) == 13
+    assert UpdateEngine.max_span(synth.make_problem(5, 0, 3, seed=0)) == 0
