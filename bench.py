@@ -5,12 +5,22 @@
 
 A "step" is one complete measurement update (K1..K7: per-feature Jacobian stack,
 nullspace projection, chi-square gate, QR compression, gain, Joseph covariance
-update) of ONE filter over one synthetic feature batch, inputs resident in HBM.
-N = 1 runs BASELINE.json configs[2] (headline: N=30 clones, 2000 features, track
-10, fp64).  N > 1 (launched by torch.distributed.run, one rank per GPU) runs the
-feature-sharded update: 2000 features per rank (configs[3] at 4 GPUs), one RCCL
-gather of the compressed R blocks to rank 0, serial gain on rank 0, broadcast of
-dx / P+; `value` counts 2000-feature update equivalents (weak scaling).
+update) of ONE filter over one synthetic feature batch.
+
+N = 1 : BASELINE.json configs[2] (headline: N=30 clones, 2000 features, track 10,
+        fp64).  `value` is the rate with the inputs resident in HBM when the timed
+        region starts (the bench contract); the rate of the complete drop-in call
+        (host arrays in -> dx, P+, mask on the host: sort, plan, PCIe both ways) is
+        reported right beside it as `value_host_inclusive`.  The same line carries
+        one row per other single-GPU config (configs[1], the north-star target
+        (30, 10000, 10), configs[3] on one GPU, configs[4] in fp64 and with fp32
+        storage) with its own roofline fractions, `roofline` for the dominant
+        kernel group (K5) and `cpu_baseline`.
+N > 1 : (launched by torch.distributed.run, one rank per GPU) the feature-sharded
+        update: `value` = weak scaling, 2000 features per rank (configs[3] at 4
+        GPUs), one gather of the compressed blocks to rank 0, serial gain there,
+        broadcast of dx / P+; the same line also carries configs[3] as written
+        (8000 features in all, split N ways: strong scaling).
 
 Rank 0 prints ONE JSON line.  The oracle (oracle/msckf_oracle.py) is only timed
 as the CPU baseline; it is never on the measured GPU path.
@@ -27,24 +37,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak (AMD public; half the 157.3 TF FP32 rate)
+FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak (AMD public; measured 77.2 TF with v_mfma_f64_16x16x4_f64,
+                               # tools/ubench/f64_tput.hip)
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: FP32 vector = matrix peak
 
 
-def algorithmic_costs(N, F, M):
+def algorithmic_costs(N, F, M, s=8):
     """Canonical per-update bytes / flops of the reference's dense formulation,
-    SURVEY.md section 8(d) (all features accepted)."""
-    s = 8
+    SURVEY.md section 8(d) (all features accepted); s = bytes per stored scalar."""
     d, dc, q = 15 + 6 * N, 6 * N, 2 * M - 3
     m = F * q
+    peak = (FP64_PEAK_TFLOPS if s == 8 else FP32_PEAK_TFLOPS) * 1e12
     bytes_inputs = s * (F * (2 * M + 7) + 24 * N + 2 * d * d + d) + 4 * F * M + F
     bytes_stack = F * q * (d + 1) * s                       # written once (K4), read once (K5)
     fl_A = F * (200 * M + 36 * M + 24 * M * (6 * M + 1) + 2 * q * (6 * M) ** 2 + 12 * q * q * M + q ** 3 / 3 + 2 * q * q)
     fl_B = 2 * m * dc * dc - (2.0 / 3.0) * dc ** 3 + 4 * m * dc
     fl_C = 6 * dc * d * d + 4 * dc * dc * d + (2.0 / 3.0) * dc ** 3 + 4 * d ** 3
-    t_roof = (bytes_inputs + bytes_stack) / (HBM_PEAK_GBS * 1e9) + fl_B / (FP64_PEAK_TFLOPS * 1e12) \
-        + fl_C / (FP64_PEAK_TFLOPS * 1e12)
+    t_A = (bytes_inputs + bytes_stack) / (HBM_PEAK_GBS * 1e9)
+    t_B = fl_B / peak
+    t_C = fl_C / peak
     return dict(bytes=bytes_inputs + 2 * bytes_stack, flops_A=fl_A, flops_B=fl_B, flops_C=fl_C,
-                bytes_A=bytes_inputs + bytes_stack, t_roof_s=t_roof, rows=m)
+                bytes_A=bytes_inputs + bytes_stack, t_roof_s=t_A + t_B + t_C, t_A=t_A, t_B=t_B, t_C=t_C, rows=m)
 
 
 def pmc_traffic(kernel_prefixes):
@@ -58,35 +71,82 @@ def pmc_traffic(kernel_prefixes):
     d = json.load(open(files[-1]))
     tot, calls = 0.0, 0
     for name, k in d["kernels"].items():
-        if any(pfx in name for pfx in kernel_prefixes) and k["fetch_kb"] is not None and k["write_kb"] is not None:
+        if any(pfx in name for pfx in kernel_prefixes) and k.get("fetch_kb") is not None and k.get("write_kb") is not None:
             tot += (k["fetch_kb"] + k["write_kb"]) * 1024.0 * k["calls"]
             calls += k["calls"]
     return tot / calls if calls else None
 
 
-def cpu_baseline(prob, reps=10):
-    """The oracle (NumPy restatement of the reference path) on this box's host
-    cores: reference-faithful per-feature Python loop, SVD nullspace, np.linalg.qr,
-    explicit inverses, Joseph form -- minus the dense sigma^2*eye(m) allocation
-    (9.2 GB at the headline; R_n = sigma^2 I analytically, BASELINE.md section 3 mode ii)."""
-    from oracle import msckf_oracle as oracle
-    np.linalg.qr(np.random.default_rng(0).standard_normal((400, 60)))      # LAPACK warm-up
-    ts = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        out = oracle.update(prob, dense_noise=False)
-        ts.append(time.perf_counter() - t0)
-    t = float(np.median(ts))
+def blas_threads():
     try:                                                    # threads the BLAS / LAPACK calls of the oracle may use
         from threadpoolctl import threadpool_info
-        cores = max([int(p.get("num_threads", 1)) for p in threadpool_info()] or [1])
+        return max([int(p.get("num_threads", 1)) for p in threadpool_info()] or [1])
     except Exception:
-        cores = os.cpu_count()
-    return out, dict(value=1.0 / t, unit="updates/s", cores=cores, kind="port",
-                     sample=f"{reps} full updates of the same workload (median {t:.2f} s each, {sum(ts):.0f} s in all); "
-                            "per-feature stage is a single-threaded Python loop, QR / products use the BLAS "
-                            f"thread pool ({cores} threads, {os.cpu_count()} logical CPUs); oracle with "
-                            "R_n = sigma^2 I analytic instead of the reference's dense sigma^2*eye(m)")
+        return os.cpu_count()
+
+
+def cpu_baseline(prob, budget_s=12.0, dense_noise=False, max_reps=10):
+    """The oracle (NumPy restatement of the reference path) on this box's host cores: reference-faithful
+    per-feature Python loop, SVD nullspace, np.linalg.qr, explicit inverses, Joseph form.
+    dense_noise=True is BASELINE.md section 3 mode (i): with the reference's dense sigma^2 * eye(m)
+    (MSCKF.py:589) and Q^T R_o Q (:598); False is mode (ii), R_n = sigma^2 I analytically."""
+    from oracle import msckf_oracle as oracle
+    np.linalg.qr(np.random.default_rng(0).standard_normal((400, 60)))      # LAPACK warm-up
+    ts, out = [], None
+    t_all = time.perf_counter()
+    while len(ts) < max_reps and (not ts or time.perf_counter() - t_all < budget_s):
+        t0 = time.perf_counter()
+        out = oracle.update(prob, dense_noise=dense_noise)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    return out, t, len(ts), float(sum(ts))
+
+
+def time_config(N, F, M, steps, warmup, dtype="f64", device=0, host_reps=10):
+    """One single-GPU config: resident rate (HIP events over `steps` back-to-back pipelines), per-stage device
+    times, host-inclusive rate of the drop-in call, roofline fractions."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    prob = synth.make_problem(N, F, M, seed=0)
+    s = 8 if dtype == "f64" else 4
+    costs = algorithmic_costs(N, F, M, s)
+    with UpdateEngine(max_clones=N, max_features=F, max_track=max(M, 2), device=device, dtype=dtype) as eng:
+        eng.load(prob)
+        for _ in range(warmup):
+            eng.run()
+        eng.sync()
+        t0 = time.perf_counter()
+        ms_ev, _ = eng.run_timed(steps)
+        eng.sync()
+        wall = time.perf_counter() - t0
+        _, stages = eng.run_timed(min(steps, 30), stages=True)
+        res = eng.result()
+        for _ in range(2):
+            one = eng.update_problem(prob)
+        t1 = time.perf_counter()
+        for _ in range(host_reps):
+            one = eng.update_problem(prob)
+        host_s = (time.perf_counter() - t1) / host_reps
+    us = 1e3 * ms_ev / steps
+    peak = FP64_PEAK_TFLOPS if dtype == "f64" else FP32_PEAK_TFLOPS
+    row = {
+        "workload": f"N={N} clones, F={F} features, track={M}, {'fp64' if dtype == 'f64' else 'fp32 storage'}",
+        "dtype": dtype,
+        "updates_per_s": 1e6 / us, "us_per_update": us, "wall_us_per_update": 1e6 * wall / steps,
+        "host_inclusive_updates_per_s": 1.0 / host_s, "host_inclusive_us": 1e6 * host_s,
+        "stages_us": {"feature_K1_K4": stages[0], "qr_K5": stages[1], "gain_K6_K7": stages[2]},
+        "accepted": int(res.accepted.sum()), "stacked_rows": int(one.stats.get("stacked_rows", 0)),
+        "k5_launches": int(one.stats.get("n_levels", 0)), "leaves": int(one.stats.get("n_leaves", 0)),
+        "host_prep_us": one.stats.get("us_host_prep"), "h2d_us": one.stats.get("us_h2d"), "d2h_us": one.stats.get("us_d2h"),
+        "roofline_frac_pipeline": costs["t_roof_s"] * 1e6 / us,
+        "t_roof_us": costs["t_roof_s"] * 1e6,
+        "roofline_frac_K1_K4_hbm": costs["t_A"] * 1e6 / stages[0],
+        "roofline_frac_K5": costs["t_B"] * 1e6 / stages[1],
+        "roofline_frac_K6_K7": costs["t_C"] * 1e6 / stages[2],
+        "K5_tflops_canonical": costs["flops_B"] / (stages[1] * 1e-6) / 1e12, "peak_tflops": peak,
+        "hbm_gbs_algorithmic": costs["bytes"] / (us * 1e-6) / 1e9,
+    }
+    return prob, res, one, row, costs
 
 
 def main():
@@ -98,6 +158,7 @@ def main():
     ap.add_argument("--features", type=int, default=2000, help="features per GPU")
     ap.add_argument("--track", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--force-dist", action="store_true", help="run the sharded code path even at world size 1")
     args = ap.parse_args()
 
@@ -108,47 +169,175 @@ def main():
         args.gpus = world
     N, Fg, M = args.clones, args.features, args.track
 
-    dist = None
-    torch = None
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        import torch                                           # plumbing: rendezvous + RCCL gather
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
+        import torch  # noqa: F401  (must be imported before the library: both ship a libamdhip64)
     import msckf_amd  # noqa: F401
     from msckf_amd import synth
     from msckf_amd.api import UpdateEngine
 
-    prob = synth.make_problem(N, Fg * world, M, seed=0)
-    eng = UpdateEngine(max_clones=N, max_features=Fg * max(world, 1), max_track=max(M, 2), device=local_rank)
-    costs = algorithmic_costs(N, Fg, M)
+    if use_dist:
+        line = bench_sharded(args, world, rank, local_rank)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        return
 
-    if not use_dist:
-        eng.load(prob)                                           # inputs resident in HBM before the timed region
-        for _ in range(args.warmup):
-            eng.run()
+    prob, res, one, head, costs = time_config(N, Fg, M, args.steps, args.warmup, device=local_rank, host_reps=20)
+    stats = one.stats
+    us_step = head["us_per_update"]
+    us_qr = head["stages_us"]["qr_K5"]
+    n_lv = max(1, head["k5_launches"])
+    line = {
+        "metric": "MSCKF measurement-updates/sec (N=30 clones, 2000 features, track=10)",
+        "value": head["updates_per_s"],
+        "unit": "updates/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": us_step * 1e-3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"N={N} clones, F={Fg} features, track={M}, fp64",
+                   "unit_definition": "one 2000-feature measurement update (K1-K7)", "seed": 0,
+                   "value_definition": "K1-K7 per step, state + sorted tracks + K5 plan resident in HBM before the timed "
+                                       "region, HIP events over all steps (bench contract); value_host_inclusive is the "
+                                       "complete drop-in call of SURVEY 8(d): host arrays in -> dx, P+, mask on the host"},
+        "value_host_inclusive": head["host_inclusive_updates_per_s"],
+        "host_inclusive_updates_per_s": head["host_inclusive_updates_per_s"],
+        "host_inclusive_breakdown_us": {"call": head["host_inclusive_us"], "device_pipeline": us_step,
+                                        "host_sort_plan": head["host_prep_us"], "h2d": head["h2d_us"], "d2h": head["d2h_us"]},
+    }
+    line["roofline"] = {
+        "kernel": "K5 QR compression: k_fold leaves + k_sweep group merges and root sweep (%d launches per update)" % n_lv,
+        "bound": "fp64_valu", "unit": "TFLOP/s",
+        "achieved": costs["flops_B"] / (us_qr * 1e-6) / 1e12,
+        "peak": FP64_PEAK_TFLOPS,
+        "frac": costs["flops_B"] / (us_qr * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
+        "traffic": pmc_traffic(("k_fold<", "k_sweep<", "k_wsweep<")),
+        "flops_per_launch": costs["flops_B"] / n_lv,
+        "avg_launch_us": us_qr / n_lv,
+        "flops_model": "canonical dense Householder QR of the m x 6N stack (SURVEY 8d: 2 m dc^2 - 2/3 dc^3 + 4 m dc), NOT the "
+                       "executed flops: the band pipeline factors windows of 6 x track columns only (~0.3 GF real at the headline)",
+    }
+    line["pipeline_roofline"] = {"t_roof_us": costs["t_roof_s"] * 1e6, "t_measured_us": us_step,
+                                 "frac": costs["t_roof_s"] * 1e6 / us_step,
+                                 "hbm_gbs_algorithmic": costs["bytes"] / (us_step * 1e-6) / 1e9}
+    line["stages_us"] = dict(head["stages_us"], hip_event_ms_per_step=us_step * 1e-3)
+    line["accepted"] = head["accepted"]
+    line["plan"] = {"leaves": stats.get("n_leaves"), "levels": stats.get("n_levels"),
+                    "host_prep_us": stats.get("us_host_prep"), "h2d_us": stats.get("us_h2d")}
+
+    # ---- the other single-GPU configs, same protocol, fewer steps -------------------------------------
+    rows = [dict(head, config="configs[2] headline")]
+    if not args.no_extra_configs:
+        extra = [("configs[1]", 20, 500, 8, "f64", 100), ("north-star target", 30, 10000, 10, "f64", 50),
+                 ("configs[3] on one GPU", 30, 8000, 10, "f64", 50),
+                 ("configs[4] in fp64", 50, 20000, 15, "f64", 20),
+                 ("configs[4] fp32 storage + f32 MFMA P-update", 50, 20000, 15, "f32", 20)]
+        for name, n, f, m, dt, st in extra:
+            try:
+                _, _, _, row, _ = time_config(n, f, m, st, 5, dtype=dt, device=local_rank, host_reps=5)
+                rows.append(dict(row, config=name))
+            except Exception as e:                           # a config that cannot run is reported, not hidden
+                rows.append({"config": name, "error": repr(e)})
+    line["configs"] = rows
+
+    # f1, reported beside the headline, never inside `value`: the selection +
+    # triangulation kernel on the same tracks, and the fused select -> update pass.
+    with UpdateEngine(max_clones=N, max_features=Fg, max_track=max(M, 2), device=local_rank) as eng:
+        tracks = synth.make_tracks(prob, 0, lost_fraction=0.5)
+        sp = synth.SelectParams(min_parallax_deg=8.0)
+        eng.load(prob)
+        eng.set_tracks(tracks)
+        eng.run_select(sp, prob.K)
+        us_sel = eng.time_select(50)
+        eng.run()
         eng.sync()
-        t0 = time.perf_counter()
-        ms_ev, _ = eng.run_timed(args.steps)                     # K steps, HIP events on the engine's stream
+        ms_masked, _ = eng.run_timed(50)                       # K1-K7 over the valid subset, HIP events
+        us_fused = us_sel + ms_masked / 50 * 1e3
+        t2 = time.perf_counter()
+        eng.replan()                                           # tree over the valid features only (syncs)
+        us_replan = (time.perf_counter() - t2) * 1e6
+        eng.run()
         eng.sync()
-        wall = time.perf_counter() - t0
-        _, stages = eng.run_timed(min(args.steps, 50), stages=True)
-        res = eng.result()
-        # host-inclusive rate: host arrays in -> dx, P+, mask on host (the drop-in call)
-        t1 = time.perf_counter()
-        reps = 20
-        for _ in range(reps):
-            one = eng.update_problem(prob)
-        host_inclusive = reps / (time.perf_counter() - t1)
-        units = args.steps
-        seconds = wall
-        stats = one.stats
-    else:
-        from msckf_amd.shard import partition_features
+        ms_replanned, _ = eng.run_timed(50)
+        n_views = int(prob.view_ptr[-1])
+        sel_bytes = n_views * (7 * 8 + 4) + prob.F * (3 * 4 + 1 + 7 * 8)
+        line["select_f1"] = {"kernel": "k_select (get_valid_features)", "us_per_launch": us_sel,
+                             "candidates": prob.F, "valid": int(eng.selection().valid.sum()),
+                             "bytes_algorithmic": sel_bytes, "hbm_gbs_algorithmic": sel_bytes / (us_sel * 1e-6) / 1e9,
+                             "fused_select_update_us": us_fused,
+                             "replan_host_us": us_replan,
+                             "fused_replanned_us": us_sel + us_replan + ms_replanned / 50 * 1e3}
+        # f2 / f3: the covariance steps either side of the update on the resident P (host clock
+        # around async launches + one sync; augment / remove include their pose upload and sync)
+        rng = np.random.default_rng(0)
+        eng.set_prior(prob.P, prob.gravity, prob.K, prob.sigma, prob.cam_R, prob.cam_t)
+        Phi = np.eye(15) + 1e-3 * rng.standard_normal((15, 15))
+        Qd = 1e-8 * np.eye(15)
+        for _ in range(10):
+            eng.propagate(Phi, Qd)
+        eng.sync()
+        t3 = time.perf_counter()
+        for _ in range(200):
+            eng.propagate(Phi, Qd)
+        eng.sync()
+        us_prop = (time.perf_counter() - t3) / 200 * 1e6
+        J15 = np.zeros((6, 15)); J15[:3, :3] = np.eye(3); J15[3:, 12:] = np.eye(3)
+        t4 = time.perf_counter()
+        for _ in range(20):
+            eng.remove_clones([0])
+            eng.augment(J15, prob.cam_R[0], prob.cam_t[0])
+        us_window = (time.perf_counter() - t4) / 20 * 1e6
+        line["resident_f2_f3"] = {"propagate_us": us_prop, "remove_plus_augment_us": us_window,
+                                  "clones": N, "bytes_per_propagate": (2 * 15 * prob.d * 2 + prob.d * prob.d * 2) * 8}
+
+    # the CPU baseline runs last: its BLAS threads keep spinning and would disturb host-clocked numbers
+    if not args.no_cpu_baseline:
+        cores = blas_threads()
+        ref, t, reps, tot = cpu_baseline(prob, budget_s=12.0)
+        line["cpu_baseline"] = dict(
+            value=1.0 / t, unit="updates/s", cores=cores, kind="port",
+            sample=f"{reps} full updates of the headline workload (median {t:.2f} s each, {tot:.0f} s in all); "
+                   "per-feature stage is a single-threaded Python loop, QR / products use the BLAS "
+                   f"thread pool ({cores} threads, {os.cpu_count()} logical CPUs); mode (ii) of BASELINE.md 3: oracle with "
+                   "R_n = sigma^2 I analytic instead of the reference's dense sigma^2*eye(m) (9.2 GB at this size)")
+        e_dx = float(np.linalg.norm(res.dx - ref["dx"]) / np.linalg.norm(ref["dx"]))
+        e_P = float(np.linalg.norm(res.P_new - ref["P_new"]) / np.linalg.norm(ref["P_new"]))
+        line["parity_vs_cpu_baseline"] = {"dx_rel": e_dx, "P_rel": e_P}
+        # mode (i): reference-faithful WITH the dense sigma^2 * eye(m) (MSCKF.py:589, :598), where it fits: configs 1-2
+        mode_i = []
+        for name, n, f, m in (("configs[0]", 10, 50, 5), ("configs[1]", 20, 500, 8)):
+            p = synth.make_problem(n, f, m, seed=0)
+            _, t_i, reps_i, _ = cpu_baseline(p, budget_s=4.0, dense_noise=True, max_reps=7)
+            _, t_ii, _, _ = cpu_baseline(p, budget_s=2.0, dense_noise=False, max_reps=7)
+            mode_i.append({"config": name, "workload": f"N={n}, F={f}, track={m}", "rows": int(f * (2 * m - 3)),
+                           "mode_i_dense_eye_updates_per_s": 1.0 / t_i, "mode_i_median_s": t_i, "reps": reps_i,
+                           "mode_ii_updates_per_s": 1.0 / t_ii})
+        line["cpu_baseline"]["mode_i"] = mode_i
+    print(json.dumps(line), flush=True)
+
+
+def bench_sharded(args, world, rank, local_rank):
+    """N > 1: one rank per GPU.  Weak scaling (2000 features per rank) is `value`; configs[3] as written (8000
+    features in all, split over the ranks) rides in the same line as `strong_scaling_configs3`."""
+    import torch                                           # plumbing: rendezvous + RCCL gather / broadcast
+    import torch.distributed as dist
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from msckf_amd.shard import partition_features
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    N, Fg, M = args.clones, args.features, args.track
+
+    def run_case(F_total, steps, warmup):
+        prob = synth.make_problem(N, F_total, M, seed=0)
+        eng = UpdateEngine(max_clones=N, max_features=F_total, max_track=max(M, 2), device=local_rank)
         lo, hi = partition_features(prob.view_ptr, world)[rank]
         local = prob.subset(lo, hi)
         # exchange format (every rank sees the whole batch, so all agree): group triangles when the batch
@@ -195,26 +384,28 @@ def main():
                 eng.sync()                                       # dx | P+ are in the engine's result range = `out`
             dist.broadcast(out, src=0)                           # state for the next update on every rank
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
         torch.cuda.synchronize()
         dist.barrier()
         wall = time.perf_counter() - t0
         tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        seconds = float(tmax.item())
-        units = args.steps * world                               # 2000-feature update equivalents
-        stages = None
-        host_inclusive = None
-        ms_ev = seconds * 1e3
-        stats = {}
+        del out
+        eng.close()
+        return float(tmax.item()), groups
 
+    seconds, groups = run_case(Fg * world, args.steps, args.warmup)
+    strong_steps = max(10, min(args.steps, 100))
+    s_seconds, s_groups = run_case(8000, strong_steps, min(args.warmup, 10))
+    line = None
     if rank == 0:
+        units = args.steps * world                               # 2000-feature update equivalents
         line = {
             "metric": "MSCKF measurement-updates/sec (N=30 clones, 2000 features, track=10)",
             "value": units / seconds,
@@ -228,96 +419,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"N={N} clones, F={Fg} features per GPU, track={M}, fp64"
-                                   + ("" if world == 1 else f", feature-sharded over {world} GPUs "
-                                      f"({Fg * world} features per update), 1 RCCL gather + broadcast per update"),
-                       **({"exchange": "group triangles" if groups else "root blocks"} if use_dist else {}),
+            "config": {"workload": f"N={N} clones, F={Fg} features per GPU, track={M}, fp64, feature-sharded over {world} GPUs "
+                                   f"({Fg * world} features per update), 1 RCCL gather + broadcast per update",
+                       "exchange": "group triangles" if groups else "root blocks",
                        "unit_definition": "one 2000-feature measurement update (K1-K7)", "seed": 0},
+            "sharded_updates_per_s": args.steps / seconds,
+            "strong_scaling_configs3": {
+                "workload": f"BASELINE.json configs[3]: N={N} clones, 8000 features in all, track={M}, fp64, split over {world} GPUs",
+                "updates_per_s": strong_steps / s_seconds, "ms_per_update": 1e3 * s_seconds / strong_steps,
+                "steps": strong_steps, "exchange": "group triangles" if s_groups else "root blocks", "scaling": "strong"},
         }
-        if not use_dist:
-            us_step = 1e6 * seconds / args.steps
-            us_qr = stages[1]
-            n_lv = max(1, stats.get("n_levels", 1))
-            line["roofline"] = {
-                "kernel": "K5 QR compression: k_fold leaves + k_sweep group merges and root sweep "
-                          "(%d launches per update)" % n_lv,
-                "bound": "mfma", "unit": "TFLOP/s",
-                "achieved": costs["flops_B"] / (us_qr * 1e-6) / 1e12,
-                "peak": FP64_PEAK_TFLOPS,
-                "frac": costs["flops_B"] / (us_qr * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
-                "traffic": pmc_traffic(("k_fold<", "k_sweep<")),
-                "flops_per_launch": costs["flops_B"] / n_lv,
-                "avg_launch_us": us_qr / n_lv,
-            }
-            line["pipeline_roofline"] = {"t_roof_us": costs["t_roof_s"] * 1e6, "t_measured_us": us_step,
-                                         "frac": costs["t_roof_s"] * 1e6 / us_step,
-                                         "hbm_gbs_algorithmic": costs["bytes"] / (us_step * 1e-6) / 1e9}
-            line["stages_us"] = {"feature_K1_K4": stages[0], "qr_K5": stages[1], "gain_K6_K7": stages[2],
-                                 "hip_event_ms_per_step": ms_ev / args.steps}
-            line["host_inclusive_updates_per_s"] = host_inclusive
-            line["accepted"] = int(res.accepted.sum())
-            line["plan"] = {"leaves": stats.get("n_leaves"), "levels": stats.get("n_levels"),
-                            "host_prep_us": stats.get("us_host_prep"), "h2d_us": stats.get("us_h2d")}
-            # f1, reported beside the headline, never inside `value`: the selection +
-            # triangulation kernel on the same tracks, and the fused select -> update pass.
-            tracks = synth.make_tracks(prob, 0, lost_fraction=0.5)
-            sp = synth.SelectParams(min_parallax_deg=8.0)
-            eng.load(prob)
-            eng.set_tracks(tracks)
-            eng.run_select(sp, prob.K)
-            us_sel = eng.time_select(50)
-            eng.run()
-            eng.sync()
-            ms_masked, _ = eng.run_timed(50)                       # K1-K7 over the valid subset, HIP events
-            us_fused = us_sel + ms_masked / 50 * 1e3
-            t2 = time.perf_counter()
-            eng.replan()                                           # tree over the valid features only (syncs)
-            us_replan = (time.perf_counter() - t2) * 1e6
-            eng.run()
-            eng.sync()
-            ms_replanned, _ = eng.run_timed(50)
-            n_views = int(prob.view_ptr[-1])
-            sel_bytes = n_views * (7 * 8 + 4) + prob.F * (3 * 4 + 1 + 7 * 8)
-            line["select_f1"] = {"kernel": "k_select (get_valid_features)", "us_per_launch": us_sel,
-                                 "candidates": prob.F, "valid": int(eng.selection().valid.sum()),
-                                 "bytes_algorithmic": sel_bytes, "hbm_gbs_algorithmic": sel_bytes / (us_sel * 1e-6) / 1e9,
-                                 "fused_select_update_us": us_fused,
-                                 "replan_host_us": us_replan,
-                                 "fused_replanned_us": us_sel + us_replan + ms_replanned / 50 * 1e3}
-            # f2 / f3: the covariance steps either side of the update on the resident P (host clock
-            # around async launches + one sync; augment / remove include their pose upload and sync)
-            rng = np.random.default_rng(0)
-            eng.set_prior(prob.P, prob.gravity, prob.K, prob.sigma, prob.cam_R, prob.cam_t)
-            Phi = np.eye(15) + 1e-3 * rng.standard_normal((15, 15))
-            Qd = 1e-8 * np.eye(15)
-            for _ in range(10):
-                eng.propagate(Phi, Qd)
-            eng.sync()
-            t3 = time.perf_counter()
-            for _ in range(200):
-                eng.propagate(Phi, Qd)
-            eng.sync()
-            us_prop = (time.perf_counter() - t3) / 200 * 1e6
-            J15 = np.zeros((6, 15)); J15[:3, :3] = np.eye(3); J15[3:, 12:] = np.eye(3)
-            t4 = time.perf_counter()
-            for _ in range(20):
-                eng.remove_clones([0])
-                eng.augment(J15, prob.cam_R[0], prob.cam_t[0])
-            us_window = (time.perf_counter() - t4) / 20 * 1e6
-            line["resident_f2_f3"] = {"propagate_us": us_prop, "remove_plus_augment_us": us_window,
-                                      "clones": N, "bytes_per_propagate": (2 * 15 * prob.d * 2 + prob.d * prob.d * 2) * 8}
-            # the CPU baseline runs last: its BLAS threads keep spinning and would disturb host-clocked numbers
-            if not args.no_cpu_baseline:
-                ref, cpu = cpu_baseline(prob)
-                line["cpu_baseline"] = cpu
-                e_dx = float(np.linalg.norm(res.dx - ref["dx"]) / np.linalg.norm(ref["dx"]))
-                e_P = float(np.linalg.norm(res.P_new - ref["P_new"]) / np.linalg.norm(ref["P_new"]))
-                line["parity_vs_cpu_baseline"] = {"dx_rel": e_dx, "P_rel": e_P}
-        print(json.dumps(line), flush=True)
-    eng.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MSCKF_ABI_VERSION 1
+#define MSCKF_ABI_VERSION 2
 
 #define MSCKF_OK 0
 #define MSCKF_NOOP 1
@@ -53,6 +53,9 @@ extern "C" {
 #define MSCKF_FLAG_TREE_PLAN 1      /* K5: always the merge tree (default: the band pipeline
                                        whenever every track spans <= 10 clone slots)        */
 
+#define MSCKF_DTYPE_F64 0
+#define MSCKF_DTYPE_F32 1
+
 #define MSCKF_MAX_TRACK 31          /* views per feature (2M+1 rows fit one wavefront)      */
 
 typedef struct msckf_ctx msckf_ctx;
@@ -66,6 +69,13 @@ typedef struct msckf_config {
     int32_t leaf_rows;              /* 0 = default; target stacked rows per QR leaf         */
     int32_t merge_arity;            /* 0 = default; max children per QR tree node           */
     int32_t flags;                  /* MSCKF_FLAG_*; 0 = defaults                           */
+    int32_t dtype;                  /* MSCKF_DTYPE_F64 (reference arithmetic, 1e-8 parity) or
+                                       MSCKF_DTYPE_F32: fp32 STORAGE of the stacked system (K4 output,
+                                       the dominant HBM traffic) and the Joseph covariance update
+                                       (MSCKF.py:612-614) on the f32 matrix cores; K1-K3, the QR
+                                       accumulators and the Cholesky stay fp64.  Tolerance of this
+                                       mode: DESIGN.md section 5 (1e-4 dx / 1e-5 P+)            */
+    int32_t reserved0;
 } msckf_config;
 
 /* Filled by msckf_get_stats / msckf_update (nullable there). Times are device

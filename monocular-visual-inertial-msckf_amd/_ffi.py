@@ -10,7 +10,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FLAG_TREE_PLAN = 1      # msckf_config.flags: always plan the K5 merge tree (no band pipeline)
 LIB_PATH = os.environ.get("MSCKF_LIB") or os.path.join(_HERE, "libmsckf_mi355x.so")   # MSCKF_LIB: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
+DTYPE_F64, DTYPE_F32 = 0, 1
 
 OK, NOOP = 0, 1
 ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_SPD, ERR_STATE, ERR_DUP_SLOT = -1, -2, -3, -4, -5, -6
@@ -33,7 +34,7 @@ SYMBOLS = [
 class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("max_clones", C.c_int32),
                 ("max_features", C.c_int32), ("max_track", C.c_int32), ("leaf_rows", C.c_int32),
-                ("merge_arity", C.c_int32), ("flags", C.c_int32)]
+                ("merge_arity", C.c_int32), ("flags", C.c_int32), ("dtype", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Stats(C.Structure):

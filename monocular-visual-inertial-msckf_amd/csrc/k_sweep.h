@@ -299,13 +299,13 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         // the slot of the next pivot column first, then its owners publish it while the other slots update
         const int in = i + 1;
         slot(STag<K0>{});
-        if (in < f_w && (in & 7) != 0) {
+        if (in < f_ew && (in & 7) != 0) {
             if (cq == (in & (CL - 1))) publish(STag<K0>{}, STag<RMAX>{});         // same chunk: in / CL == K0
         }
         slot(STag<K0 + 1>{});
         slot(STag<K0 + 2>{});
         slot(STag<K0 + 3>{});
-        if (in < f_w && (in & 7) == 0) {
+        if (in < f_ew && (in & 7) == 0) {
             // first column of the next chunk: slot 8 (KK + 1) / CL, column lane 8 (KK + 1) % CL, two more row slots
             constexpr int KN = (8 * (KK + 1)) / CL;
             if (cq == (8 * (KK + 1)) % CL) publish(STag<KN>{}, STag<RMAX + 2>{});
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     // one chunk of 8 columns: fetch the two row slots the chunk's LAST publish needs, then the steps
     auto chunk = [&](auto tagk, bool have_next) {
         constexpr int KK = decltype(tagk)::value;
-        if (8 * KK >= f_w) return;
+        if (8 * KK >= f_ew) return;
 #pragma unroll
         for (int rr = 2 * KK + 2; rr <= 2 * KK + 3 && rr < 16; ++rr) {
 #pragma unroll
@@ -323,8 +323,9 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
                 if (CL * k + CL - 1 >= 4 * rr) a[rr][k] = load_elem(f_src, f_w, rr, k);   // else structurally zero, never read
             }
         }
-        if (have_next && KK == max((f_w - 1) / 8 - 1, 0)) fetch_next_head();
-        const int ihi = min(8 * KK + 8, f_w);
+        if (have_next && KK == max((f_ew - 1) / 8 - 1, 0)) fetch_next_head();
+        const int ihi = min(8 * KK + 8, f_ew);        // (steps run over the ENVELOPE: the tile's rows fill in right of the
+                                                                // source's last column wherever R already reaches further, and that fill has to be eliminated too)
         for (int i = 8 * KK; i < ihi; ++i) {
             SWEEP_TICK(0);                                 // left the barrier
             step(tagk, i);

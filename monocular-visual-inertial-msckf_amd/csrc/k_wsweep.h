@@ -1,0 +1,383 @@
+// K5, upper part, general form of k_sweep.h (reference MSCKF.py:594-598): the same systolic
+// pipeline -- NF wavefronts fold NF source triangles into the band R at NF different columns,
+// one workgroup barrier per macro step, arithmetic exactly that of folding the triangles one
+// after the other -- for
+//   * wider source triangles: a register tile of W = 16 CS columns (CS = 4: tracks of up to 10
+//     clone slots, CS = 6: up to 15 slots; local column W-1 holds the rhs), lane (rq, cq) =
+//     (lane & 3, lane >> 2) owns rows {rq + 4 rr}, rr < 4 CS, and local columns {cq + 16 k}, k < CS;
+//   * any number of clones: the band R lives in a RING of RC rows x W doubles in LDS (entry (c, col)
+//     at [c mod RC][col - c], rhs at [c mod RC][W-1]).  The schedule is static, so the host
+//     (sweep_flush_table) knows for every macro step t which rows no present or future fold step
+//     touches any more; at the head of step t the wavefronts copy rows [flo(t), fhi(t)) to the
+//     output block and clear their ring slots for rows RC further down.
+// Per step the quad's partial dots are reduce-scattered: row lane rq ends up with the dot of column
+// slot rq and, for rq < 2 when CS > 4, of slot 4 + rq, i.e. every lane looks after one or two
+// entries of the pivot row of R (reads them, forms tau, writes them back; tau is broadcast over the
+// quad for the rank-1 update).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "k_sweep.h"
+
+namespace msckf {
+
+struct WSweepArgs {
+    const SweepNode* nodes;
+    const SweepFold* folds;
+    int node_base;
+    double* rbuf;
+    const double* zero;         // a double that reads 0.0 (tail of the workspace)
+    const int* flush;           // per node: nsteps + 1 entries (lo | n << 16), at flush_off[node]
+    const int* flush_off;       // [nodes] offset into `flush`
+    int rc_log2;                // ring rows = 1 << rc_log2
+};
+
+template <int CS> struct WSweepGeom {
+    static constexpr int W = 16 * CS;          // tile columns = LDS row stride
+    static constexpr int MAX_W = W - 6;        // widest source / envelope
+    static constexpr int RSL = 4 * CS;         // row slots of a lane
+    static constexpr int NCH = 2 * CS;         // chunks of 8 columns
+    static constexpr int VB = 16 * CS + 8;     // published column: [rq][RSL] rows (+ pad)
+};
+
+template <int CS>
+__host__ __device__ inline size_t wsweep_lds_bytes(int rc, int nf, int nsteps) {
+    // pad | ring | published columns | dump words | zero words | flush table (ints)
+    return ((size_t)(rc + 1) * WSweepGeom<CS>::W + (size_t)nf * WSweepGeom<CS>::VB + (size_t)nf * 64 + 2) * 8 + ((size_t)nsteps + 2) * 4;
+}
+
+template <int NF, int CS>
+__global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
+    using G = WSweepGeom<CS>;
+    constexpr int W = G::W, RSL = G::RSL, VB = G::VB;
+    constexpr int CL = 16;
+    constexpr bool HAS2 = CS > 4;          // lanes rq < 2 look after a second column slot (4 + rq)
+    static_assert(CS >= 4 && CS <= 6, "column slots 4..6");
+    static_assert((NF & (NF - 1)) == 0, "NF must be a power of two");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SweepNode nd = p.nodes[p.node_base + blockIdx.x];
+    const int t = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lane = t & 63;
+    const int rq = lane & 3;
+    const int cq = lane >> 2;
+    const int RC = 1 << p.rc_log2, RCM = RC - 1;
+    // (one row of padding in front of the ring: a lane whose column has retired keeps walking its band
+    //  offset below zero; with the pivot in ring row 0 that address must still be inside the allocation)
+    double* Rb = smem + W;                                    // [RC][W]
+    constexpr int RB0 = W;                                    // index of the ring in smem
+    double* vb = smem + (size_t)(RC + 1) * W + wv * VB;       // published column of this fold slot
+    const int dump_i = (RC + 1) * W + NF * VB + wv * 64 + lane;
+    const int zero_i = (RC + 1) * W + NF * VB + NF * 64;
+    int* ftab = reinterpret_cast<int*>(smem + (size_t)(RC + 1) * W + NF * VB + NF * 64 + 2);
+    const int nsteps = __builtin_amdgcn_readfirstlane(nd.nsteps);
+    const int fold_end = __builtin_amdgcn_readfirstlane(nd.fold_end);
+    const int wtot = __builtin_amdgcn_readfirstlane(nd.wtot);
+    double* out = p.rbuf + nd.out_off;
+    const int ldo = wtot + 1;
+
+    for (int e = t; e < (RC + 1) * W; e += 64 * NF) smem[e] = 0.0;
+    if (t < 2) smem[zero_i + t] = 0.0;
+    {
+        const int* src = p.flush + p.flush_off[p.node_base + blockIdx.x];
+        for (int e = t; e <= nsteps; e += 64 * NF) ftab[e] = src[e];
+    }
+    // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
+    const SweepFold f0 = p.folds[nd.fold_begin];
+    const int adopt = (nd.fold_end > nd.fold_begin && f0.t0 == 0) ? 1 : 0;
+    if (adopt) {
+        __syncthreads();
+        const double* src = p.rbuf + f0.src_off;
+        const int ldw = f0.w + 1;
+        for (int e = t; e < f0.w * ldw; e += 64 * NF) {
+            const int r = e / ldw, lc = e - r * ldw;
+            if (lc >= r) Rb[(size_t)((f0.off + r) & RCM) * W + (lc == f0.w ? W - 1 : lc - r)] = src[e];
+        }
+    }
+
+    // The head (row slots 0, 1) of a wavefront's NEXT fold is fetched during the last chunks of the current one
+    // only where the registers allow it (CS = 4); the 90-column tile loads it at the start of the fold.
+    constexpr bool PREFETCH_HEAD = (CS == 4);
+    double a[RSL][CS];
+    double nxt[PREFETCH_HEAD ? 2 : 1][PREFETCH_HEAD ? CS : 1];
+#pragma unroll
+    for (int rr = 0; rr < RSL; ++rr)
+#pragma unroll
+        for (int k = 0; k < CS; ++k) a[rr][k] = 0.0;
+
+    int tcur = 0;                       // macro steps (= barriers) this wavefront has done
+    int f_off = 0, f_w = 0, f_ew = 0, f_t0 = 0;
+    const double* f_src = p.rbuf;
+    int n_off = 0, n_w = 0, n_ew = 0, n_t0 = 0;
+    const double* n_src = p.rbuf;
+
+    auto read_desc = [&](int fi, int& o_off, int& o_w, int& o_ew, int& o_t0, const double*& o_src) {
+        const SweepFold f = p.folds[fi];
+        o_off = __builtin_amdgcn_readfirstlane(f.off);
+        o_w = __builtin_amdgcn_readfirstlane(f.w);
+        o_ew = __builtin_amdgcn_readfirstlane(f.ew);
+        o_t0 = __builtin_amdgcn_readfirstlane(f.t0);
+        o_src = p.rbuf + f.src_off;
+    };
+    auto load_elem = [&](const double* src, int w, int rr, int k) -> double {
+        const int r = rq + 4 * rr, lc = cq + CL * k;
+        const bool isr = (k == CS - 1) && (cq == CL - 1);
+        const bool ok = (r < w) && (isr || (lc >= r && lc < w));
+        const int col = isr ? w : lc;
+        const double* q = ok ? src + (r * (w + 1) + col) : p.zero;
+        return *q;
+    };
+    auto fetch_next_head = [&]() {      // row slots 0, 1 of the next fold
+        if constexpr (PREFETCH_HEAD) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int k = 0; k < CS; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
+        }
+    };
+    auto publish = [&](auto tagk, auto tagr) {
+        constexpr int KN = decltype(tagk)::value;
+        constexpr int RP = decltype(tagr)::value < RSL - 1 ? decltype(tagr)::value : RSL - 1;
+        if constexpr (KN < CS) {
+            double* dst = vb + rq * RSL;
+#pragma unroll
+            for (int rr = 0; rr <= RP; ++rr) dst[rr] = a[rr][KN];
+        }
+    };
+
+    // rows [lo, lo + n) are final at the head of macro step ts: out to HBM, ring slots cleared
+    auto flush_rows = [&](int ts) {
+        const int e = ftab[ts];
+        const int n = __builtin_amdgcn_readfirstlane(e >> 16);
+        if (n == 0) return;
+        const int lo = __builtin_amdgcn_readfirstlane(e & 0xFFFF);
+        for (int r = (wv + ts) & (NF - 1); r < n; r += NF) {   // (rotating: a single row is not always wavefront 0's)
+            const int c = lo + r;
+            double* Rrow = Rb + (size_t)(c & RCM) * W;
+            double* orow = out + (size_t)c * ldo;
+#pragma unroll
+            for (int h = 0; h < (W + 63) / 64; ++h) {
+                const int dlt = lane + 64 * h;
+                if (dlt < W) {
+                    const double x = Rrow[dlt];
+                    if (dlt == W - 1) orow[wtot] = x;
+                    else if (c + dlt < wtot) orow[c + dlt] = x;
+                    Rrow[dlt] = 0.0;
+                }
+            }
+        }
+    };
+    auto barrier_step = [&]() {
+        __syncthreads();
+        ++tcur;
+        flush_rows(tcur);
+    };
+
+    // The R entries this lane looks after: primary slot rq (local column lco1), secondary slot 4 + rq for rq < 2.
+    int ra1 = 0, wa1 = 0, st1 = 0, wr1 = 0;
+    int ra2 = 0, wa2 = 0, st2 = 0, wr2 = 0;
+    const int lco1 = cq + CL * rq;
+    const int lco2 = cq + CL * (4 + rq);
+    const bool isr1 = (CS == 4) && (rq == 3) && (cq == CL - 1);
+    const bool isr2 = HAS2 && (4 + rq == CS - 1) && (cq == CL - 1);
+    const bool has1 = rq < CS;                          // CS >= 4: always
+    const bool has2 = HAS2 && (rq < 2) && (4 + rq < CS);
+    auto init_addr = [&]() {
+        const int r0 = RB0 + (f_off & RCM) * W;
+        {
+            const bool valid = has1 && (isr1 || lco1 < f_ew);
+            ra1 = valid ? r0 + (isr1 ? W - 1 : lco1) : zero_i;
+            wa1 = valid ? ra1 : dump_i;
+            st1 = valid ? (isr1 ? W : W - 1) : 0;
+            wr1 = valid ? RC * W : 0;
+        }
+        if constexpr (HAS2) {
+            const bool valid = has2 && (isr2 || lco2 < f_ew);
+            ra2 = valid ? r0 + (isr2 ? W - 1 : lco2) : zero_i;
+            wa2 = valid ? ra2 : dump_i;
+            st2 = valid ? (isr2 ? W : W - 1) : 0;
+            wr2 = valid ? RC * W : 0;
+        }
+    };
+
+    auto step = [&](auto tagk, int i) {
+        constexpr int KK = decltype(tagk)::value;
+        constexpr int RMAX = (2 * KK + 1 < RSL - 1) ? 2 * KK + 1 : RSL - 1;     // live row slots
+        constexpr int K0 = (8 * KK) / CL;                                        // first live column slot
+        const int prow = (f_off + i) & RCM;
+        const int rrow = RB0 + prow * W;                   // pivot row of R (uniform)
+        // ---- reads ------------------------------------------------------------------
+        double v[RMAX + 1];
+        {
+            const double* src = vb + rq * RSL;
+#pragma unroll
+            for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
+        }
+        const double x0 = smem[rrow];
+        const double rck1 = smem[ra1];
+        double rck2 = 0.0;
+        if constexpr (HAS2) rck2 = smem[ra2];
+        const bool on1 = (lco1 > i) || isr1;
+        const bool on2 = HAS2 && has2 && ((lco2 > i) || isr2);
+        // ---- dots (one partial sum per live slot), reduce-scattered over the quad ---------------------
+        double sp[CS];
+#pragma unroll
+        for (int k = 0; k < CS; ++k) {
+            sp[k] = 0.0;
+            if (k >= K0) {
+                double s0 = v[0] * a[0][k];
+#pragma unroll
+                for (int rr = 1; rr <= RMAX; ++rr) s0 = fma(v[rr], a[rr][k], s0);
+                sp[k] = s0;
+            }
+        }
+        const bool b0 = (rq & 1) != 0, b1 = (rq & 2) != 0;
+        double tot1 = 0.0, tot2 = 0.0;                     // lane rq: full dot of slot rq / of slot 4 + (rq & 1)
+        if constexpr (K0 <= 3) {
+            double pB = (b0 ? sp[3] : sp[2]) + quad_move<0xB1>(b0 ? sp[2] : sp[3]);
+            if constexpr (K0 <= 1) {
+                double pA = (b0 ? sp[1] : sp[0]) + quad_move<0xB1>(b0 ? sp[0] : sp[1]);
+                tot1 = (b1 ? pB : pA) + quad_move<0x4E>(b1 ? pA : pB);
+            } else {
+                tot1 = pB + quad_move<0x4E>(pB);           // slots 0, 1 are retired
+            }
+        }
+        if constexpr (HAS2) {
+            double pC;
+            if constexpr (CS == 6) pC = (b0 ? sp[5] : sp[4]) + quad_move<0xB1>(b0 ? sp[4] : sp[5]);
+            else pC = sp[4] + quad_move<0xB1>(sp[4]);      // CS == 5: one secondary slot
+            tot2 = pC + quad_move<0x4E>(pC);
+        }
+        (void)b1;
+        // |column i|^2 = the pivot column's dot with itself: its owners hold a[.][K0] == v
+        double sg;
+        if constexpr (K0 <= 3) sg = readlane_d(tot1, 4 * (i - CL * K0) + K0);
+        else sg = readlane_d(tot2, 4 * (i - CL * K0) + (K0 - 4));
+        const bool live = sg > SWEEP_TINY;
+        // ---- reflector scalars (every lane, uniform values) ---------------------------
+        double alpha = x0, beta = 0.0;
+        if (live) {
+            const double ss = fma(x0, x0, sg);
+            double nrm;
+            if (ss > 1e-200 && ss < 1e200) {
+                const double y = fast_rsqrt(ss);
+                nrm = ss * y;
+                beta = y * fast_rcp(nrm + fabs(x0));
+            } else {
+                nrm = sqrt(ss);
+                beta = 1.0 / (nrm * (nrm + fabs(x0)));
+            }
+            alpha = (x0 > 0.0) ? -nrm : nrm;
+        }
+        const double v0 = x0 - alpha;
+        // ---- tau of this lane's column(s), its R entries, then the rank-1 update of every slot ----------
+        const double tau1 = (on1 ? beta : 0.0) * fma(v0, rck1, tot1);
+        smem[on1 ? wa1 : dump_i] = fma(-tau1, v0, rck1);
+        double tau2 = 0.0;
+        if constexpr (HAS2) {
+            tau2 = (on2 ? beta : 0.0) * fma(v0, rck2, tot2);
+            smem[on2 ? wa2 : dump_i] = fma(-tau2, v0, rck2);
+        }
+        if (rq == 0 && cq == 0) smem[rrow] = alpha;
+        ra1 += st1; wa1 += st1;
+        if constexpr (HAS2) { ra2 += st2; wa2 += st2; }
+        if (prow == RCM) {                                  // the next pivot row wraps around the ring
+            ra1 -= wr1; wa1 -= wr1;
+            if constexpr (HAS2) { ra2 -= wr2; wa2 -= wr2; }
+        }
+        auto slot = [&](auto tags) {
+            constexpr int k = decltype(tags)::value;
+            if constexpr (k < CS) {
+                double tau;
+                if constexpr (k < 4) {
+                    constexpr int CTRL = (k == 0) ? 0x00 : (k == 1) ? 0x55 : (k == 2) ? 0xAA : 0xFF;   // quad_perm [k,k,k,k]
+                    tau = quad_move<CTRL>(tau1);
+                } else {
+                    constexpr int CTRL = (k == 4) ? 0x00 : 0x55;
+                    tau = quad_move<CTRL>(tau2);
+                }
+#pragma unroll
+                for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
+            }
+        };
+        // the slot of the next pivot column first, then its owners publish it while the other slots update
+        const int in = i + 1;
+        slot(STag<K0>{});
+        if (in < f_ew && (in & 7) != 0) {
+            if (cq == (in & (CL - 1))) publish(STag<K0>{}, STag<RMAX>{});         // same chunk: in / CL == K0
+        }
+        slot(STag<K0 + 1>{});
+        slot(STag<K0 + 2>{});
+        slot(STag<K0 + 3>{});
+        slot(STag<K0 + 4>{});
+        slot(STag<K0 + 5>{});
+        if (in < f_ew && (in & 7) == 0) {
+            constexpr int KN = (8 * (KK + 1)) / CL;
+            if (cq == (8 * (KK + 1)) % CL) publish(STag<KN>{}, STag<RMAX + 2>{});
+        }
+    };
+
+    // one chunk of 8 columns: fetch the two row slots the chunk's LAST publish needs, then the steps
+    auto chunk = [&](auto tagk, bool have_next) {
+        constexpr int KK = decltype(tagk)::value;
+        if constexpr (KK < G::NCH) {
+            if (8 * KK >= f_ew) return;
+#pragma unroll
+            for (int rr = 2 * KK + 2; rr <= 2 * KK + 3 && rr < RSL; ++rr) {
+#pragma unroll
+                for (int k = 0; k < CS; ++k) {
+                    if (CL * k + CL - 1 >= 4 * rr) a[rr][k] = load_elem(f_src, f_w, rr, k);   // else structurally zero, never read
+                }
+            }
+            if (have_next && KK == max((f_ew - 1) / 8 - 1, 0)) fetch_next_head();
+            const int ihi = min(8 * KK + 8, f_ew);        // (steps run over the ENVELOPE: the tile's rows fill in right of the
+                                                                // source's last column wherever R already reaches further, and that fill has to be eliminated too)
+            for (int i = 8 * KK; i < ihi; ++i) {
+                step(tagk, i);
+                barrier_step();
+            }
+        }
+    };
+
+    __syncthreads();                                       // R zeroed / adopted, flush table in place
+    flush_rows(0);
+    int fi = nd.fold_begin + adopt + wv;
+    bool have = fi < fold_end;
+    if (have) {
+        read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
+        fetch_next_head();
+    }
+    while (have) {
+        f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
+        while (tcur < f_t0 - 1) barrier_step();
+        init_addr();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int k = 0; k < CS; ++k) {
+                if constexpr (PREFETCH_HEAD) a[rr][k] = nxt[rr][k];
+                else a[rr][k] = load_elem(f_src, f_w, rr, k);
+            }
+        if (cq == 0) publish(STag<0>{}, STag<1>{});
+        barrier_step();                                    // (the host schedules t0 >= 1 and one spare step per slot reuse)
+        fi += NF;
+        const bool have_next = fi < fold_end;
+        if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
+        chunk(STag<0>{}, have_next);
+        chunk(STag<1>{}, have_next);
+        chunk(STag<2>{}, have_next);
+        chunk(STag<3>{}, have_next);
+        chunk(STag<4>{}, have_next);
+        chunk(STag<5>{}, have_next);
+        chunk(STag<6>{}, have_next);
+        chunk(STag<7>{}, have_next);
+        chunk(STag<8>{}, have_next);
+        chunk(STag<9>{}, have_next);
+        chunk(STag<10>{}, have_next);
+        chunk(STag<11>{}, have_next);
+        have = have_next;
+    }
+    while (tcur < nsteps) barrier_step();
+    // (the table's last entry, index nsteps, covers every row still in the ring)
+}
+
+}  // namespace msckf

@@ -18,6 +18,7 @@
 #include "k_gain.h"
 #include "k_select.h"
 #include "k_sweep.h"
+#include "k_wsweep.h"
 #include "k_state.h"
 
 using namespace msckf;
@@ -120,6 +121,9 @@ struct msckf_ctx {
     std::vector<SweepFold> sfolds;
     int n_group_merges = 0;
     std::vector<std::pair<int, int>> sweep_levels;   // (node_base, count) per group-merge launch
+    int sweep_mode = 0;                   // 0 k_sweep (60-column tiles, whole band R in LDS), 1 k_wsweep<4> (ring), 2 k_wsweep<6> (90-column tiles, ring)
+    std::vector<int> h_flush, h_flush_off;            // k_wsweep: per sweep node the rows final at the head of every macro step
+    Buf dFlush, dFlushOff;
     size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
     size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
     // group exchange (sharded band pipeline): the group triangles live in one export record at the head of rbuf
@@ -301,18 +305,60 @@ void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nste
     for (int g = first; g < end; ++g) {
         int t0 = 1;                                        // step t0 - 1 publishes the fold's first column
         if (g > first) t0 = folds[g - 1].t0 + (folds[g].off - folds[g - 1].off) + 1;
-        if (g - first >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].w + 1);
+        // (a fold runs one step per column of its ENVELOPE ew >= w: where R already reaches further right than the
+        //  source triangle, the tile's rows fill in there and the fill has to be eliminated as well)
+        if (g - first >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].ew + 1);
         folds[g].t0 = t0;
-        last = std::max(last, t0 + folds[g].w);
+        last = std::max(last, t0 + folds[g].ew);
     }
     *nsteps = last;
 }
 
-// THE rule for the band pipeline (msckf_band_rule exports it): N clones, longest track span in clone slots
-bool band_rule(const msckf_ctx* c, int N, int max_span) {
-    if (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) return false;                // tree plan forced
-    if (N < 1 || sweep_lds_bytes(6 * N, SWEEP_NW, SWEEP_WPF) > (size_t)FOLD_LDS_BYTES) return false;
-    return 6 * max_span <= SWEEP_MAX_W;
+// Which sweep kernel runs the group merges and the root of a batch of N clones whose longest track spans
+// `max_span` clone slots: 0 = k_sweep (tiles of 60 columns, the whole band R in LDS), 1 = k_wsweep<4> (the
+// same tiles, R in a ring: any N), 2 = k_wsweep<6> (tiles of 90 columns, ring), -1 = none: merge tree.
+constexpr int WS_RC_LOG2_4 = 8;            // ring rows of k_wsweep<4>: 256 x 64 doubles
+constexpr int WS_RC_LOG2_6 = 7;            // ring rows of k_wsweep<6>: 128 x 96 doubles
+int sweep_mode_for(const msckf_ctx* c, int N, int max_span) {
+    if (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) return -1;                   // tree plan forced
+    if (N < 1) return -1;
+    if (6 * max_span <= SWEEP_MAX_W) {
+        if (sweep_lds_bytes(6 * N, SWEEP_NW, SWEEP_WPF) <= (size_t)FOLD_LDS_BYTES) return 0;
+        return 1;
+    }
+    if (6 * max_span <= WSweepGeom<6>::MAX_W) return 2;
+    return -1;
+}
+// THE rule for the group exchange of the sharded band pipeline (msckf_band_rule exports it): the record
+// layout and the merging rank's sweeps are those of k_sweep.
+bool band_rule(const msckf_ctx* c, int N, int max_span) { return sweep_mode_for(c, N, max_span) == 0; }
+
+// k_wsweep: rows of R no present or future fold step touches at the head of macro step t (the schedule is
+// static).  Entry t = lo | n << 16: rows [lo, lo + n) leave the ring at the head of step t; entry nsteps covers
+// the rest.  Returns false when some step would touch a row whose ring slot still holds an unflushed row.
+bool sweep_flush_table(const std::vector<SweepFold>& folds, int begin, int end, int nsteps, int wtot, int rc,
+                       std::vector<int>& tab) {
+    const int first = (end > begin && folds[begin].t0 == 0) ? begin + 1 : begin;   // an adopted triangle runs no step
+    int lprev = 0;
+    bool ok = true;
+    for (int t = 0; t <= nsteps; ++t) {
+        int L = wtot, H = -1;
+        if (t < nsteps) {
+            for (int g = first; g < end; ++g) {
+                const SweepFold& f = folds[g];
+                if (t >= f.t0 + f.ew) continue;                           // finished (one step per envelope column)
+                const int row = f.off + std::max(0, t - f.t0);            // its present (or first) pivot row
+                L = std::min(L, row);
+                if (t >= f.t0) H = std::max(H, row);
+            }
+        }
+        L = std::max(L, lprev);
+        if (H >= lprev + rc) ok = false;                                  // a touched row aliases one flushed in this step
+        if (t == 0 && first > begin && folds[begin].off + folds[begin].w > rc) ok = false;   // the adopted rows fit the ring
+        tab.push_back(lprev | ((L - lprev) << 16));
+        lprev = L;
+    }
+    return ok;
 }
 
 bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
@@ -322,9 +368,13 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     int max_span = 0;
     for (int f = 0; f < F; ++f)
         if (live(f)) max_span = std::max(max_span, fmax[f] - fmin[f] + 1);
-    if (!band_rule(c, N, max_span)) return false;
+    const int mode = sweep_mode_for(c, N, max_span);
+    if (mode < 0) return false;
+    if (c->xchg && mode != 0) return false;                               // the exchange records are k_sweep's: root blocks then
+    c->sweep_mode = mode;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 250;
     c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear();
+    c->sweep_levels.clear(); c->n_group_merges = 0;
     // group exchange: the record [N flags | accepted count | N slots of XCHG_SLOT doubles] heads the workspace; the triangle of
     // group s (fixed window of min(10, N - s) slots, so its shape depends on (N, s) only) is produced in slot s
     const bool xchg = c->xchg;
@@ -437,6 +487,14 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     off += 16;
     c->rbuf_doubles = off;
     c->xchg_planned = xchg;
+    c->h_flush.clear(); c->h_flush_off.clear();
+    if (mode > 0) {
+        const int rc = 1 << (mode == 1 ? WS_RC_LOG2_4 : WS_RC_LOG2_6);
+        for (const SweepNode& nd : c->snodes) {
+            c->h_flush_off.push_back((int)c->h_flush.size());
+            if (!sweep_flush_table(c->sfolds, nd.fold_begin, nd.fold_end, nd.nsteps, nd.wtot, rc, c->h_flush)) return false;
+        }
+    }
     return true;
 }
 
@@ -506,8 +564,35 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
 }
 
 // band plan, levels 1-2: group merges (one workgroup each), then the root sweep
+template <int CS>
+void launch_wsweep(msckf_ctx* c, int node_base, int count, int rc_log2) {
+    WSweepArgs a{};
+    a.nodes = ptr<SweepNode>(c->dSweepNodes);
+    a.folds = ptr<SweepFold>(c->dSweepFolds);
+    a.node_base = node_base;
+    a.rbuf = ptr<double>(c->dRbuf);
+    a.zero = ptr<double>(c->dRbuf) + c->zero_off;
+    a.flush = ptr<int>(c->dFlush);
+    a.flush_off = ptr<int>(c->dFlushOff);
+    a.rc_log2 = rc_log2;
+    int nsteps = 0;
+    for (int i = node_base; i < node_base + count; ++i) nsteps = std::max(nsteps, c->snodes[i].nsteps);
+    hipLaunchKernelGGL((k_wsweep<SWEEP_NW, CS>), dim3(count), dim3(64 * SWEEP_NW), wsweep_lds_bytes<CS>(1 << rc_log2, SWEEP_NW, nsteps),
+                       c->stream, a);
+}
+
 int launch_sweeps(msckf_ctx* c, bool with_root = true) {
     if (c->snodes.empty()) return MSCKF_OK;
+    if (c->sweep_mode > 0) {
+        auto go = [&](int base, int count) {
+            if (c->sweep_mode == 1) launch_wsweep<4>(c, base, count, WS_RC_LOG2_4);
+            else launch_wsweep<6>(c, base, count, WS_RC_LOG2_6);
+        };
+        for (const auto& lv : c->sweep_levels) go(lv.first, lv.second);
+        if (with_root) go(c->n_group_merges, 1);
+        HIPCHK(c, hipGetLastError());
+        return MSCKF_OK;
+    }
     SweepArgs a{};
     a.nodes = ptr<SweepNode>(c->dSweepNodes);
     a.folds = ptr<SweepFold>(c->dSweepFolds);
@@ -547,6 +632,13 @@ int upload_plan(msckf_ctx* c) {
                                  hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, c->sfolds.data(), c->sfolds.size() * sizeof(SweepFold),
                                  hipMemcpyHostToDevice, c->stream));
+        if (c->sweep_mode > 0 && c->band_plan) {
+            if (int rc = ensure(c, c->dFlush, c->h_flush.size() * 4)) return rc;
+            if (int rc = ensure(c, c->dFlushOff, c->h_flush_off.size() * 4)) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->dFlush.p, c->h_flush.data(), c->h_flush.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->dFlushOff.p, c->h_flush_off.data(), c->h_flush_off.size() * 4, hipMemcpyHostToDevice,
+                                     c->stream));
+        }
     }
     return MSCKF_OK;
 }
@@ -725,6 +817,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     if (!out || !cfg || cfg->abi_version != MSCKF_ABI_VERSION) return MSCKF_ERR_ARG;
     if (cfg->max_track < 1 || cfg->max_track > MSCKF_MAX_TRACK || cfg->max_clones < 1 || cfg->max_features < 0)
         return MSCKF_ERR_ARG;
+    if (cfg->dtype != MSCKF_DTYPE_F64 && cfg->dtype != MSCKF_DTYPE_F32) return MSCKF_ERR_ARG;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || cfg->device < 0 || cfg->device >= n) return MSCKF_ERR_NO_DEVICE;
     msckf_ctx* c = new msckf_ctx();
@@ -762,6 +855,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         for (const void* f : sk) lds_attr(f, LDS_MAX_BYTES - 1024, "k_solve_lds LDS attribute");
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 4>), FOLD_LDS_BYTES, "k_wsweep<4> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 6>), FOLD_LDS_BYTES, "k_wsweep<6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_chol<512>), LDS_MAX_BYTES - 1024, "k_chol LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_feature<24>), LDS_MAX_BYTES - 1024, "k_feature LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_feature<32>), LDS_MAX_BYTES - 1024, "k_feature LDS attribute");
@@ -815,7 +910,8 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
                   &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dSweepNodes, &c->dSweepFolds, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
-                  &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld};
+                  &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
+                  &c->dFlush, &c->dFlushOff};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);

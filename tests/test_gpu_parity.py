@@ -294,7 +294,9 @@ print('TORCH_INTEROP_OK')
 @pytest.mark.parametrize("N,F,M,seed,kw", [
     (30, 2000, 10, 31, {}),                                        # headline shape: 21 groups, 7 leaves each
     (20, 500, 8, 32, {"outlier_fraction": 0.1, "outlier_px": 500.0}),
-    (12, 300, 10, 33, {"variable_tracks": True}),                  # ragged windows: envelopes wider than the sources
+    (12, 300, 10, 33, {"variable_tracks": True}),                  # ragged windows
+    (30, 300, 10, 5, {"variable_tracks": True}),                   # ... with groups whose longest track is shorter than the
+    (30, 120, 10, 6, {"variable_tracks": True}),                   #     reach of earlier groups: envelopes wider than the sources
     (10, 7, 3, 34, {}),                                            # fewer features than groups, single-row leaves
     (37, 600, 10, 35, {}),                                         # widest band R that still fits LDS next to the tiles
 ])
@@ -327,17 +329,6 @@ def test_band_pipeline_equals_merge_tree(N, F, M, seed, kw):
     assert not np.triu(Tb, 6 * span).any()
 
 
-def test_wide_tracks_fall_back_to_the_tree(eng):
-    """Tracks spanning more than 10 clone slots do not fit the sweep tiles: the merge tree runs."""
-    from msckf_amd import synth
-    from oracle import msckf_oracle as oracle
-    prob = synth.make_problem(16, 120, 14, seed=36)
-    ref = oracle.update(prob, dense_noise=False)
-    res = eng.update_problem(prob)
-    assert res.status == 0
-    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
-
-
 def _drop_views(prob, rng, keep_first=True, p_drop=0.35, only_first_slots=None):
     """Remove interior observations (tracks that skip clones) and, optionally, whole features so that only
     some first slots carry tracks (groups with gaps between them)."""
@@ -361,6 +352,59 @@ def _drop_views(prob, rng, keep_first=True, p_drop=0.35, only_first_slots=None):
                                view_ptr=np.asarray(new_vp, dtype=np.int32), obs_uv=prob.obs_uv[ko],
                                obs_slot=prob.obs_slot[ko], idp_base=prob.idp_base[kf], idp_m=prob.idp_m[kf],
                                idp_rho=prob.idp_rho[kf])
+
+
+@pytest.mark.parametrize("N,F,M,seed,kw,band", [
+    (16, 120, 14, 36, {}, 90),                          # tracks of 11-15 slots: the 90-column sweep tiles (k_wsweep<6>)
+    (50, 400, 15, 37, {}, 90),                          # ... with the band R in a ring of 128 rows (d = 315)
+    (30, 500, 15, 38, {"variable_tracks": True}, 90),   # ragged tracks up to 15 slots
+    (24, 300, 13, 39, {"outlier_fraction": 0.1, "outlier_px": 500.0}, 90),
+    (52, 300, 10, 40, {}, 60),                          # 60-column tiles, 312 rows of R: ring of 256 rows (k_wsweep<4>)
+    (31, 64, 31, 24, {}, None),                         # tracks wider than any sweep tile: the merge tree
+])
+def test_wide_sweep_and_ring(N, F, M, seed, kw, band):
+    """Batches the plain sweep kernel cannot take -- tracks spanning 11-15 clone slots, band R larger than
+    LDS -- run the general sweep (wider register tiles, R in a ring with a static flush schedule); beyond
+    15 slots the merge tree.  All against the oracle; the band plan shows in the zero pattern of T."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=seed, **kw)
+    ref = oracle.update(prob, dense_noise=False)
+    with UpdateEngine(max_clones=N, max_features=F, max_track=max(M, 2)) as e:
+        res = e.update_problem(prob)
+        assert res.status == ref["status"] == 0
+        assert np.array_equal(res.accepted, ref["accepted"])
+        assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        T, rn = e.debug_compressed()
+        H, r = ref["H_X"][:, 15:], ref["r_o"]
+        assert rel_err(T.T @ T, H.T @ H) < 1e-10 and rel_err(T.T @ rn, H.T @ r) < 1e-10
+        assert np.allclose(np.tril(T, -1), 0.0)
+        if band is not None:
+            assert not np.triu(T, band).any()             # a band plan ran
+            assert res.stats["n_levels"] >= 2
+        e.load(prob)                                      # resident path, twice: bitwise reproducible
+        e.run(); r1 = e.result()
+        e.run(); r2 = e.result()
+        assert np.array_equal(r1.dx, r2.dx) and np.array_equal(r1.P_new, r2.P_new)
+
+
+@pytest.mark.parametrize("seed,first_slots", [(44, None), (45, {0, 3, 20, 21}), (46, {11})])
+def test_wide_sweep_tracks_with_holes_and_group_gaps(seed, first_slots):
+    """The ring's flush schedule with rows no fold ever touches and envelopes that do not overlap."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from oracle import msckf_oracle as oracle
+    rng = np.random.default_rng(seed)
+    prob = _drop_views(synth.make_problem(40, 500, 15, seed=seed), rng, only_first_slots=first_slots)
+    ref = oracle.update(prob, dense_noise=False)
+    with UpdateEngine(max_clones=40, max_features=500, max_track=15) as e:
+        res = e.update_problem(prob)
+        assert res.status == ref["status"] == 0
+        assert np.array_equal(res.accepted, ref["accepted"])
+        assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        T, rn = e.debug_compressed()
+        assert not np.triu(T, 90).any()
 
 
 @pytest.mark.parametrize("seed,first_slots", [(41, None), (42, {0, 1, 9, 10, 17}), (43, {5})])
