@@ -402,8 +402,12 @@ __global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
 
 // K = Y S^-1 with the packed factor L resident in LDS (n(n+1)/2 doubles): one
 // wavefront per row of Y, WAVES rows per workgroup.
-template <int NREG, int WAVES, int ROWS = 1, bool UNIT = false>
+// MODE: 3 = both sweeps (K = Y S^-1), 1 = forward only (X = Y L^-T), 2 = backward only (K = X L^-1); the
+// one-sided forms serve the two-block factorisation of windows wider than one register-tiled Cholesky
+// (launch_gain_blocked) and need the unit-diagonal packed factor.  Rows may be updated in place (Kg == Y).
+template <int NREG, int WAVES, int ROWS = 1, bool UNIT = false, int MODE = 3>
 __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
+    static_assert(MODE == 3 || UNIT, "one-sided sweeps use the unit-diagonal packed factor");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int n = s.n, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     double* lp = smem;                          // packed lower: (i, j) at i(i+1)/2 + j
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
             x[r][m] = (row0 + r < s.d && i < n) ? s.Y[(size_t)(row0 + r) * s.ldy + i] : 0.0;
         }
     // forward sweep  L x = y
+    if constexpr ((MODE & 1) != 0) {
 #pragma unroll
     for (int mj = 0; mj < NREG; ++mj) {
 #pragma unroll 4
@@ -455,8 +460,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
             }
         }
     }
+    }
     // unit-diagonal factor L' = L D^-1:  L x = y  <=>  L' (D x) = y  and  L^T k = x  <=>  L'^T k = D^-1 x,
-    // so the two sweeps need no per-step scaling, just D^-2 in between
+    // so the two sweeps need no per-step scaling, just D^-2 in between (D^-1 after a forward-only sweep
+    // and before a backward-only one)
     if (unit) {
 #pragma unroll
         for (int r = 0; r < ROWS; ++r)
@@ -464,10 +471,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
             for (int m = 0; m < NREG; ++m) {
                 const int i = lane + 64 * m;
                 const double di = (i < n) ? sinv[i] : 0.0;
-                x[r][m] *= di * di;
+                x[r][m] *= (MODE == 3) ? di * di : di;
             }
     }
     // backward sweep  L^T k = x
+    if constexpr ((MODE & 2) != 0) {
 #pragma unroll
     for (int mj = NREG - 1; mj >= 0; --mj) {
 #pragma unroll 4
@@ -491,6 +499,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
             }
         }
     }
+    }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         if (row0 + r >= s.d) break;
@@ -500,12 +509,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
             const int i = lane + 64 * m;
             if (i < n) {
                 s.Kg[(size_t)(row0 + r) * s.ldk + i] = x[r][m];
-                dot += x[r][m] * s.z[(size_t)i * s.zstride];
+                if (s.dx) dot += x[r][m] * s.z[(size_t)i * s.zstride];
             }
         }
-        dot = wave_sum(dot);
-        if (lane == 0) s.dx[row0 + r] = dot;
+        if (s.dx) {
+            dot = wave_sum(dot);
+            if (lane == 0) s.dx[row0 + r] = dot;
+        }
     }
+}
+
+// dx = K z  (MSCKF.py:607) for the blocked solve: one wavefront per row of K.
+__global__ __launch_bounds__(256) void k_matvec(const double* K, int ldk, int n, const double* z, int zstride, double* dx, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= d) return;
+    double dot = 0.0;
+    for (int i = lane; i < n; i += 64) dot = fma(K[(size_t)row * ldk + i], z[(size_t)i * zstride], dot);
+    dot = wave_sum(dot);
+    if (lane == 0) dx[row] = dot;
 }
 
 // P_out = (Pn + Pn^T) / 2   (reference MSCKF.py:614)

@@ -101,6 +101,7 @@ struct msckf_ctx {
     // current problem
     int N = 0, d = 0, dc = 0, F = 0, sumM = 0, Mmax = 0;
     bool have_state = false, have_features = false, ran = false, ran_gain = false;
+    bool gain_blocked = false;            // the last K6 ran the two-block factorisation (second status word in use)
     double sigma = 0.0;
     double g[3]{}, Kinv[9]{};
     int n_chi2 = 0;
@@ -673,6 +674,66 @@ void gemm(msckf_ctx* c, const double* A, int lda, const double* B, int ldb, cons
     hipLaunchKernelGGL(k_gemm_f64, dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, c->stream, g);
 }
 
+// One-sided / two-sided triangular sweeps over the rows of X (in place) with the unit-diagonal packed factor Lp.
+template <int MODE>
+void launch_tri_sweep(msckf_ctx* c, double* X, int ldx, int rows, const double* Lp, const double* invd, int n) {
+    SolveArgs a{};
+    a.Y = X; a.ldy = ldx; a.L = nullptr; a.U = nullptr; a.invd = invd; a.Lp = Lp; a.n = n;
+    a.z = nullptr; a.zstride = 0; a.Kg = X; a.ldk = ldx; a.dx = nullptr; a.d = rows;
+    constexpr int WV = SOLVE_WAVES;
+    const dim3 grid((rows + WV - 1) / WV), block(64 * WV);
+    const size_t lds_need = ((size_t)n * (n + 1) / 2 + n) * 8;
+    const int nreg = (n + 63) / 64;
+    if (nreg <= 1) hipLaunchKernelGGL((k_solve_lds<1, WV, 1, true, MODE>), grid, block, lds_need, c->stream, a);
+    else if (nreg <= 2) hipLaunchKernelGGL((k_solve_lds<2, WV, 1, true, MODE>), grid, block, lds_need, c->stream, a);
+    else hipLaunchKernelGGL((k_solve_lds<3, WV, 1, true, MODE>), grid, block, lds_need, c->stream, a);
+}
+
+// K6 for windows wider than one register-tiled Cholesky (4 CHOL_TILE_MAX_NT < dc <= 2 GAIN_BLK): S is factored
+// as a 2 x 2 block matrix, S = [A B^T; B C], L = [L11 0; W L22] with W = B L11^-T, L22 L22^T = C - W W^T; both
+// diagonal factors come from k_chol_tile, everything else is triangular sweeps with the factor in LDS and MFMA
+// GEMMs.  K = Y S^-1 row by row:  X1 = Y1 L11^-T,  K2 = (Y2 - X1 W^T) L22^-T L22^-1,  K1 = (X1 - K2 W) L11^-1.
+constexpr int GAIN_BLK = 160;
+int launch_chol_solve_blocked(msckf_ctx* c, double* S, const double* Y, double* Kg, const double* z, int zstride) {
+    const int d = c->d, dc = c->dc, n1 = GAIN_BLK, n2 = dc - GAIN_BLK;
+    double* work1 = ptr<double>(c->dCholWork);
+    double* work2 = work1 + (size_t)n1 * (n1 + 1) / 2;
+    double* invd = ptr<double>(c->dInvd);
+    double* W = ptr<double>(c->dD);            // [n2][n1]  (D is written after the solve)
+    double* C2 = ptr<double>(c->dB2);          // [n2][n2]  (B2 likewise)
+    int* status = ptr<int>(c->dStatus);
+    {   // A = L11 L11^T
+        CholArgs a{};
+        a.S = S; a.lds_ = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = invd; a.n = n1;
+        a.work = work1; a.status = status;
+        hipLaunchKernelGGL((k_chol_tile<CHOL_T>), dim3(1), dim3(CHOL_T), 0, c->stream, a);
+    }
+    // W = B L11^-T  (rows n1.. of S, first n1 columns), then the Schur complement C2 = C - W W^T
+    HIPCHK(c, hipMemcpy2DAsync(W, (size_t)n1 * 8, S + (size_t)n1 * dc, (size_t)dc * 8, (size_t)n1 * 8, n2, hipMemcpyDeviceToDevice,
+                               c->stream));
+    launch_tri_sweep<1>(c, W, n1, n2, work1, invd, n1);
+    gemm(c, W, n1, W, n1, S + (size_t)n1 * dc + n1, dc, C2, n2, n2, n2, n1, -1.0, 1.0, 0.0, 1, 0);
+    {   // C2 = L22 L22^T
+        CholArgs a{};
+        a.S = C2; a.lds_ = n2; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = invd + n1; a.n = n2;
+        a.work = work2; a.status = status + 1;
+        hipLaunchKernelGGL((k_chol_tile<CHOL_T>), dim3(1), dim3(CHOL_T), 0, c->stream, a);
+    }
+    // X1 = Y1 L11^-T (into K)
+    HIPCHK(c, hipMemcpy2DAsync(Kg, (size_t)dc * 8, Y, (size_t)dc * 8, (size_t)n1 * 8, d, hipMemcpyDeviceToDevice, c->stream));
+    launch_tri_sweep<1>(c, Kg, dc, d, work1, invd, n1);
+    // K2 = (Y2 - X1 W^T) L22^-T L22^-1
+    gemm(c, Kg, dc, W, n1, Y + n1, dc, Kg + n1, dc, d, n2, n1, -1.0, 1.0, 0.0, 1, 0);
+    launch_tri_sweep<3>(c, Kg + n1, dc, d, work2, invd + n1, n2);
+    // K1 = (X1 - K2 W) L11^-1
+    gemm(c, Kg + n1, dc, W, n1, Kg, dc, Kg, dc, d, n1, n2, -1.0, 1.0, 0.0, 0, 0);
+    launch_tri_sweep<2>(c, Kg, dc, d, work1, invd, n1);
+    // dx = K r_n
+    hipLaunchKernelGGL(k_matvec, dim3((d + 3) / 4), dim3(256), 0, c->stream, Kg, dc, dc, z, zstride, ptr<double>(c->dDx), d);
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
 // K6-K7 from the root block [T | r_n] (dc x (dc+1), row-major) and the prior P.
 int launch_gain(msckf_ctx* c, const double* Tblk) {
     const int d = c->d, dc = c->dc, ldt = dc + 1;
@@ -688,6 +749,10 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
     gemm(c, P + 15, d, Tblk, ldt, nullptr, 0, Y, dc, d, dc, dc, 1.0, 0.0, 0.0, 1, 1);
     // S = T Y[15:, :] + sigma^2 I            (MSCKF.py:605)
     gemm(c, Tblk, ldt, Y + (size_t)15 * dc, dc, nullptr, 0, S, dc, dc, dc, dc, 1.0, 0.0, s2, 0, 2);
+    c->gain_blocked = dc > 4 * CHOL_TILE_MAX_NT && dc <= 2 * GAIN_BLK && dc - GAIN_BLK >= 4;
+    if (c->gain_blocked) {
+        if (int rcb = launch_chol_solve_blocked(c, S, Y, Kg, Tblk + dc, ldt)) return rcb;
+    } else {
     // S = L L^T
     bool packed_L = false;
     {
@@ -723,6 +788,7 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
 #undef SOLVE_LAUNCH
         } else if (nreg <= 4) hipLaunchKernelGGL(k_solve<4>, dim3(d), dim3(64), 0, c->stream, a);
         else hipLaunchKernelGGL(k_solve<5>, dim3(d), dim3(64), 0, c->stream, a);
+    }
     }
     // Joseph form (MSCKF.py:613) with A = I - K T_H, T_H = [0 | T]:
     //   B2 = A P = P - K (T_H P) = P - K Y^T           (P symmetric)
@@ -853,6 +919,10 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         const void* sk[] = {SK(1, true), SK(2, true), SK(3, true), SK(1, false), SK(2, false), SK(3, false)};
 #undef SK
         for (const void* f : sk) lds_attr(f, LDS_MAX_BYTES - 1024, "k_solve_lds LDS attribute");
+#define SM(NR, MD) reinterpret_cast<const void*>(&k_solve_lds<NR, SOLVE_WAVES, 1, true, MD>)
+        const void* sm[] = {SM(1, 1), SM(2, 1), SM(3, 1), SM(1, 2), SM(2, 2), SM(3, 2), SM(1, 3), SM(2, 3), SM(3, 3)};
+#undef SM
+        for (const void* f : sm) lds_attr(f, LDS_MAX_BYTES - 1024, "k_solve_lds (one-sided) LDS attribute");
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 4>), FOLD_LDS_BYTES, "k_wsweep<4> LDS attribute");
@@ -1177,7 +1247,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (c->ran_gain && n_acc > 0) std::memcpy(status, c->hRes, 16);
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
-    if (rc == MSCKF_OK && c->ran_gain && status[0] != 0) rc = MSCKF_ERR_NOT_SPD;
+    if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || (c->gain_blocked && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
     if (accepted && c->F > 0) {
         for (int s = 0; s < c->F; ++s) accepted[c->perm[s]] = (acc_sorted[s] == 1) ? 1 : 0;
     }
@@ -1216,10 +1286,10 @@ int msckf_commit_covariance(msckf_ctx* c) {
     const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
     // a non-positive Cholesky pivot leaves garbage in P_out: keep the prior (msckf_get_result reports the same code)
-    int status = 0;
-    HIPCHK(c, hipMemcpyAsync(&status, c->dStatus.p, 4, hipMemcpyDeviceToHost, c->stream));
+    int status[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(status, c->dStatus.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (status != 0) return MSCKF_ERR_NOT_SPD;
+    if (status[0] != 0 || (c->gain_blocked && status[1] != 0)) return MSCKF_ERR_NOT_SPD;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSCKF_OK;

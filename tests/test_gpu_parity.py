@@ -16,7 +16,7 @@ TOL = 1e-8
 @pytest.fixture(scope="module")
 def eng():
     from msckf_amd.api import UpdateEngine
-    e = UpdateEngine(max_clones=50, max_features=20000, max_track=31)
+    e = UpdateEngine(max_clones=53, max_features=20000, max_track=31)
     yield e
     e.close()
 
@@ -54,6 +54,9 @@ def test_golden(eng, case):
     (31, 64, 31, 24, {}),                      # maximum track length, every row of the wavefront in use
     (50, 400, 15, 25, {}),                     # N = 50 (d = 315): S too large for the LDS Cholesky path
     (6, 3, 2, 26, {}),                         # two-view tracks: one projected row each
+    (32, 200, 8, 27, {}),                      # dc = 192: just past one register-tiled Cholesky -> two-block K6 (160 + 32)
+    (45, 300, 10, 28, {"outlier_fraction": 0.05, "outlier_px": 500.0}),   # two-block K6, 160 + 110
+    (53, 200, 6, 29, {}),                      # dc = 318: the widest two-block window (160 + 158)
 ])
 def test_against_oracle(eng, N, F, M, seed, kw):
     from msckf_amd import synth

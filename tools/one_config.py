@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Run one (N, F, M) config a few times on the resident path (for rocprofv3 --kernel-trace --stats)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import msckf_amd  # noqa: F401
+from msckf_amd import synth
+from msckf_amd.api import UpdateEngine
+N, F, M = [int(x) for x in sys.argv[1:4]]
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+dtype = sys.argv[5] if len(sys.argv) > 5 else "f64"
+prob = synth.make_problem(N, F, M, seed=0)
+with UpdateEngine(max_clones=N, max_features=F, max_track=M, dtype=dtype) as eng:
+    eng.load(prob)
+    for _ in range(2):
+        eng.run()
+    ms, st = eng.run_timed(iters, stages=True)
+    print(f"N={N} F={F} M={M} {dtype}: {ms / iters * 1000:.0f} us/update  stages {st}")
