@@ -41,8 +41,9 @@ struct FeatureArgs {
     double g[3];
     double Kinv[9];
     double sigma2;
-    const long long* blk_off;    // [F] offset (doubles) of the feature's stack block
-    double* stack;               // blocks: column-major (6M+1) columns x 2M rows
+    const long long* blk_off;    // [F] offset (scalars) of the feature's stack block
+    void* stack;                 // blocks: row-major, q = 2M - rank rows x (6M+1) columns [H_o | r_o] (capacity 2M rows)
+    int stack_f32;               // scalars of the stack: 0 = double, 1 = float (MSCKF_DTYPE_F32)
     int* rank;                   // [F] rank of H_f (rows < rank are not part of the projection)
     unsigned char* accepted;     // [F] (sorted order): 1 accepted, 0 gate-rejected, 2 not-SPD, 3 not selected
     const unsigned char* select; // optional [F] flags of k_select: features without bit 0 are skipped
@@ -230,23 +231,35 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
 
     if (p.stamps) tq[2] = wall_clock64();
     // ---------------- K4: write the compact block [H_o | r_o] ----------------
+    // The rows are staged in sE (free until the gate's first pass) and leave as ONE contiguous range: the q
+    // projected rows, row-major with 6M + 1 columns, every lane storing consecutive scalars.
     const int q = R2 - rank;
     {
-        double* blk = p.stack + p.blk_off[f];
-        const bool live = (lane >= rank);
         if (lane < R2) {
             const double av[6] = {a0, a1, a2, a3, a4, a5};
+            double* erow = sE + lane * ldE;
             for (int vw = 0; vw < M; ++vw) {
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     const int c = 6 * vw + a;
                     double x = -(vv0 * sZ[c] + vv1 * sZ[C6 + c] + vv2 * sZ[2 * C6 + c]);
                     if (vw == view) x += av[a];
-                    blk[c * R2 + lane] = live ? x : 0.0;
+                    erow[c] = x;
                 }
             }
-            blk[C6 * R2 + lane] = live ? ro : 0.0;
+            erow[C6] = ro;
         }
+        __syncthreads();
+        const int nel = q * ldE;
+        const double* srcrows = sE + rank * ldE;
+        if (p.stack_f32) {
+            float* blk = static_cast<float*>(p.stack) + p.blk_off[f];
+            for (int e = lane; e < nel; e += 64) blk[e] = (float)srcrows[e];
+        } else {
+            double* blk = static_cast<double*>(p.stack) + p.blk_off[f];
+            for (int e = lane; e < nel; e += 64) blk[e] = srcrows[e];
+        }
+        __syncthreads();                       // sE is rewritten by the gate below
     }
 
     if (p.stamps) tq[3] = wall_clock64();

@@ -50,7 +50,8 @@ struct FoldArgs {
     const int* obs_slot;
     const int* fmin;            // [F] smallest slot of the feature
     const long long* blk_off;
-    const double* stack;
+    const void* stack;          // K4 blocks: row-major q x (6M+1) scalars per accepted feature (k_feature.h)
+    int stack_f32;              // 0 = double, 1 = float
     const int* rank;
     const unsigned char* accepted;
     double* rbuf;
@@ -188,28 +189,28 @@ __global__ __launch_bounds__(T) void k_fold_g(FoldArgs p) {
                     const int f = nd.src_begin + i;
                     const int vbeg = p.view_ptr[f];
                     const int M = p.view_ptr[f + 1] - vbeg;
-                    const int R2 = 2 * M, rk = p.rank[f];
-                    const float inv_r2 = 1.0f / (float)R2;
-                    const double* blk = p.stack + p.blk_off[f];
+                    const int ldb = 6 * M + 1;                                  // block: (r1 - r0) rows x ldb, row-major
+                    const float inv_ldb = 1.0f / (float)ldb;
+                    const double* blk = static_cast<const double*>(p.stack) + p.blk_off[f];
+                    const float* blkf = static_cast<const float*>(p.stack) + p.blk_off[f];
                     const int lead = 6 * (p.fmin[f] - nd.win_lo);
                     if (ln < M) smap[ln] = 6 * (p.obs_slot[vbeg + ln] - nd.win_lo);
-                    const int nel = (6 * M + 1) * R2;
-                    // (all loads of a block issued before the first use: the staging is bound by the HBM round trip;
-                    //  a track of 10 views is 1220 doubles = one trip of 20 loads per lane)
+                    const int nel = ldb * (r1 - r0);
+                    // (all loads of a trip issued before the first use: the staging is bound by the HBM round trip)
                     for (int e0 = 0; e0 < nel; e0 += 64 * STAGE_U) {
                         double x[STAGE_U];
 #pragma unroll
                         for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
-                            x[u] = (e < nel) ? blk[e] : 0.0;
+                            x[u] = (e < nel) ? (p.stack_f32 ? (double)blkf[e] : blk[e]) : 0.0;
                         }
 #pragma unroll
                         for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
                             if (e < nel) {
-                                const int c = (int)(((float)e + 0.5f) * inv_r2), L = e - c * R2;   // e / R2, exact for e < 2^20
-                                const int gr = r0 + (L - rk);           // node-global sorted row
-                                if (L >= rk && gr >= sub_lo && gr < sub_lo + np) {
+                                const int L = (int)(((float)e + 0.5f) * inv_ldb), c = e - L * ldb;   // e / ldb, exact for e < 2^20
+                                const int gr = r0 + L;                  // node-global sorted row
+                                if (gr >= sub_lo && gr < sub_lo + np) {
                                     const int col = (c == 6 * M) ? w : smap[c / 6] + (c % 6);
                                     panel[(gr - sub_lo) * ld + col] = x[u];
                                     if (c == 0) blead[gr - row_lo] = lead;
@@ -519,28 +520,28 @@ __global__ __launch_bounds__(T) void k_fold(FoldArgs p) {
                     const int f = nd.src_begin + i;
                     const int vbeg = p.view_ptr[f];
                     const int M = p.view_ptr[f + 1] - vbeg;
-                    const int R2 = 2 * M, rk = p.rank[f];
-                    const float inv_r2 = 1.0f / (float)R2;
-                    const double* blk = p.stack + p.blk_off[f];
+                    const int ldb = 6 * M + 1;                                  // block: (r1 - r0) rows x ldb, row-major
+                    const float inv_ldb = 1.0f / (float)ldb;
+                    const double* blk = static_cast<const double*>(p.stack) + p.blk_off[f];
+                    const float* blkf = static_cast<const float*>(p.stack) + p.blk_off[f];
                     const int lead = 6 * (p.fmin[f] - nd.win_lo);
                     if (ln < M) smap[ln] = 6 * (p.obs_slot[vbeg + ln] - nd.win_lo);
-                    const int nel = (6 * M + 1) * R2;
-                    // (all loads of a block issued before the first use: the staging is bound by the HBM round trip;
-                    //  a track of 10 views is 1220 doubles = one trip of 20 loads per lane)
+                    const int nel = ldb * (r1 - r0);
+                    // (all loads of a trip issued before the first use: the staging is bound by the HBM round trip)
                     for (int e0 = 0; e0 < nel; e0 += 64 * STAGE_U) {
                         double x[STAGE_U];
 #pragma unroll
                         for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
-                            x[u] = (e < nel) ? blk[e] : 0.0;
+                            x[u] = (e < nel) ? (p.stack_f32 ? (double)blkf[e] : blk[e]) : 0.0;
                         }
 #pragma unroll
                         for (int u = 0; u < STAGE_U; ++u) {
                             const int e = e0 + 64 * u + ln;
                             if (e < nel) {
-                                const int c = (int)(((float)e + 0.5f) * inv_r2), L = e - c * R2;   // e / R2, exact for e < 2^20
-                                const int gr = r0 + (L - rk);           // node-global sorted row
-                                if (L >= rk && gr >= sub_lo && gr < sub_lo + np) {
+                                const int L = (int)(((float)e + 0.5f) * inv_ldb), c = e - L * ldb;   // e / ldb, exact for e < 2^20
+                                const int gr = r0 + L;                  // node-global sorted row
+                                if (gr >= sub_lo && gr < sub_lo + np) {
                                     const int col = (c == 6 * M) ? w : smap[c / 6] + (c % 6);
                                     panel[(gr - sub_lo) * ld + col] = x[u];
                                     if (c == 0) blead[gr - row_lo] = lead;

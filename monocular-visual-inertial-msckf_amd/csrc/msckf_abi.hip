@@ -518,7 +518,7 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
     a.obs_slot = ptr<int>(c->dObsSlot);
     a.fmin = ptr<int>(c->dFmin);
     a.blk_off = ptr<long long>(c->dBlkOff);
-    a.stack = ptr<double>(c->dStack);
+    a.stack = c->dStack.p; a.stack_f32 = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
     a.rank = ptr<int>(c->dRank);
     a.accepted = ptr<unsigned char>(c->dAcc);
     a.rbuf = ptr<double>(c->dRbuf);
@@ -656,7 +656,7 @@ int launch_feature(msckf_ctx* c) {
     for (int i = 0; i < 3; ++i) a.g[i] = c->g[i];
     for (int i = 0; i < 9; ++i) a.Kinv[i] = c->Kinv[i];
     a.sigma2 = c->sigma * c->sigma;
-    a.blk_off = ptr<long long>(c->dBlkOff); a.stack = ptr<double>(c->dStack);
+    a.blk_off = ptr<long long>(c->dBlkOff); a.stack = c->dStack.p; a.stack_f32 = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
     a.rank = ptr<int>(c->dRank); a.accepted = ptr<unsigned char>(c->dAcc); a.gamma = ptr<double>(c->dGamma);
     a.select = c->use_select ? ptr<unsigned char>(c->dSelFlags) : nullptr;
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
@@ -1142,7 +1142,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     set_view(c->dAcc, c->dGateArena.p, (size_t)F * 4, (size_t)F);
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
-    E(c->dStack, (size_t)blk * 8); E(c->dGamma, (size_t)F * 8);
+    E(c->dStack, (size_t)blk * (c->cfg.dtype == MSCKF_DTYPE_F32 ? 4 : 8)); E(c->dGamma, (size_t)F * 8);
     if (rc != MSCKF_OK) return rc;
     // the tracks go first; in the one-shot call K1-K4 starts behind them while the host plans K5
     HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
