@@ -4,7 +4,7 @@
 // band storage) in LDS and folds "row blocks" into it: up to RB = 4 RSLOTS stacked rows [H_o | r_o] of a few
 // consecutive accepted features, held in the REGISTERS of one wavefront (lane (rq, cq) = (lane & 3, lane >> 2)
 // owns rows {rq + 4 rr} and window columns {cq + 16 k}).  NF wavefronts fold NF row blocks at NF consecutive
-// columns (block b runs column c at macro step t0(b) + c, t0(b) = 1 + (b / NF)(w + 1) + b % NF), one workgroup
+// columns (block b runs column c at macro step t0(b) + c, t0(b) = 1 + (b / NF)(w + gap) + b % NF), one workgroup
 // barrier per macro step; the arithmetic is that of folding the blocks one after the other.  Unlike a
 // triangle's, all rows of a block are alive from the first column on; columns retire in chunks of 8 as in
 // k_sweep.  While a wavefront runs the last chunk of a block it gathers its next block from the stack
@@ -34,11 +34,14 @@ struct LSweepArgs {
     const unsigned char* accepted;
     double* rbuf;
     int wide;                   // this launch takes the nodes with w + 1 > 64 (1) or <= 64 (0); the others exit at once
+    long long zero_idx;         // index (scalars) of a zero word behind the last block: absent entries load it (no branches)
 };
 
 constexpr int LS_MAXF = 256;    // features per leaf node
 constexpr int LS_MAXB = 128;    // row blocks per leaf node
 constexpr int LS_FB = 12;       // features per row block
+constexpr int LS_RS4 = 9;       // row slots of the 60-column leaf tile: 36 rows (two tracks of 10 views)
+constexpr int LS_RS6 = 8;       // row slots of the 90-column leaf tile: 32 rows (one track of up to 16 views)
 
 template <int CS, int RSLOTS> struct LSweepGeom {
     static constexpr int W = 16 * CS;
@@ -61,7 +64,12 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
     constexpr int CL = 16;
     constexpr bool HAS2 = CS > 4;
     constexpr int NCH = 2 * CS;
-    constexpr int KGMIN = (CS > 4) ? 8 : 1;        // first chunk whose instance may hold the gathered next block beside the tile
+    // PREF: a wavefront gathers its next block into a second register tile during the last chunk of the current
+    // one.  The 90-column tile has no room for that: there the rounds are aligned (every wavefront finishes its
+    // block, 7 idle steps), then all gather at the same time straight into the tile -- one load latency per round.
+    constexpr bool PREF = (CS == 4);
+    constexpr int RGAP = PREF ? 1 : NF;             // macro steps between two rounds of a fold slot beyond the w of the fold itself
+    constexpr int KGMIN = 1;                        // first chunk whose instance may hold the gathered next block beside the tile
     static_assert(CS >= 4 && CS <= 6, "column slots 4..6");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const FoldNode nd = p.nodes[p.node_base + blockIdx.x];
@@ -113,16 +121,16 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
     }
     __syncthreads();
     const int nblk = __builtin_amdgcn_readfirstlane(s_nblk[0]);
-    const int nsteps = nblk > 0 ? 1 + ((nblk - 1) / NF) * (w + 1) + ((nblk - 1) % NF) + w : 0;
+    const int nsteps = nblk > 0 ? 1 + ((nblk - 1) / NF) * (w + RGAP) + ((nblk - 1) % NF) + w : 0;
     const int KL = (w - 1) / 8;                                 // last chunk of a fold
 
     double a[RSLOTS][CS];
-    double nxt[RSLOTS][CS];
+    double nxt[PREF ? RSLOTS : 1][PREF ? CS : 1];
     // ---- next block: row tables (two phases around the feature-record load), then the gather ------------
     int pa_M = 0, pa_L = 0;
     long long pa_off = 0;
     unsigned int pa_c[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    auto prep_A = [&](int b) {          // lane r < RB: which feature / local row is block row r; issue the record load
+    auto prep_A = [&](int b) __attribute__((always_inline)) {          // lane r < RB: which feature / local row is block row r; issue the record load
         pa_M = 0;
         if (lane < RB) {
             const int i0 = blkfirst[b], i1 = blkfirst[b + 1];
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
             }
         }
     };
-    auto prep_B = [&]() {               // the tables of the wavefront's next block
+    auto prep_B = [&]() __attribute__((always_inline)) {               // the tables of the wavefront's next block
         if (lane < RB) {
             rowbase[lane] = (int)(pa_off + (long long)pa_L * (6 * pa_M + 1));
             rowM[lane] = pa_M;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
             cw[0] = pa_c[0]; cw[1] = pa_c[1]; cw[2] = pa_c[2]; cw[3] = pa_c[3];
         }
     };
-    auto gather = [&](double (&dst)[RSLOTS][CS]) {
+    auto gather = [&](auto& dst) __attribute__((always_inline)) {
         const double* sd = static_cast<const double*>(p.stack);
         const float* sf = static_cast<const float*>(p.stack);
 #pragma unroll
@@ -164,10 +172,12 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
                 const int v = rc[slot];
                 const bool ok = (Mr > 0) && (isr || v != 0xFF);
                 const int cc = isr ? 6 * Mr : 6 * v + aa;
-                double x = 0.0;
-                if (ok) x = p.stack_f32 ? (double)sf[rb + cc] : sd[rb + cc];
-                dst[rr][k] = x;
+                const long long idx = ok ? (long long)(rb + cc) : p.zero_idx;
+                dst[rr][k] = p.stack_f32 ? (double)sf[idx] : sd[idx];
             }
+            // (keeps the address arithmetic of one row slot from being hoisted over the loads of all the others:
+            //  without it the 90-column tile needs ~100 registers of addresses on top of the two blocks)
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -312,9 +322,9 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
         constexpr int KK = decltype(tagk)::value;
         if constexpr (KK < NCH) {
             if (8 * KK >= w) return;
-            if (bnext >= 0) {
+            if (PREF && bnext >= 0) {
                 if (KK == KL - 1) prep_A(bnext);
-                if constexpr (KK >= KGMIN) {
+                if constexpr (PREF && KK >= KGMIN) {
                     if (KK == KL) {
                         if (KL == 0) prep_A(bnext);
                         prep_B();
@@ -334,19 +344,30 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
 
     __syncthreads();
     int b = wv;
-    if (b < nblk) {
-        prep_A(b);
-        prep_B();
-        gather(nxt);
+    if constexpr (PREF) {
+        if (b < nblk) {
+            prep_A(b);
+            prep_B();
+            gather(nxt);
+        }
     }
     while (b < nblk) {
-        const int t0 = 1 + (b / NF) * (w + 1) + (b % NF);
+        const int t0 = 1 + (b / NF) * (w + RGAP) + (b % NF);
+        if constexpr (!PREF) {
+            const int tr = (b / NF) * (w + RGAP);           // head of the round: every wavefront has finished its block
+            while (tcur < tr) { __syncthreads(); ++tcur; }
+            prep_A(b);
+            prep_B();
+            gather(a);
+        }
         while (tcur < t0 - 1) { __syncthreads(); ++tcur; }
         init_addr();
+        if constexpr (PREF) {
 #pragma unroll
-        for (int rr = 0; rr < RSLOTS; ++rr)
+            for (int rr = 0; rr < RSLOTS; ++rr)
 #pragma unroll
-            for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
+                for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
+        }
         if (cq == 0) publish(STag<0>{});
         __syncthreads();
         ++tcur;
@@ -365,10 +386,12 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
         chunk(STag<9>{}, bnext);
         chunk(STag<10>{}, bnext);
         chunk(STag<11>{}, bnext);
-        if (bnext >= 0 && !gathered) {   // short windows: no chunk instance may hold a second block -- load it now
-            prep_A(bnext);
-            prep_B();
-            gather(nxt);
+        if constexpr (PREF) {
+            if (bnext >= 0 && !gathered) {   // short windows: no chunk instance may hold a second block -- load it now
+                prep_A(bnext);
+                prep_B();
+                gather(nxt);
+            }
         }
         b = bn;
     }

@@ -19,6 +19,7 @@
 #include "k_select.h"
 #include "k_sweep.h"
 #include "k_wsweep.h"
+#include "k_lsweep.h"
 #include "k_state.h"
 
 using namespace msckf;
@@ -125,6 +126,9 @@ struct msckf_ctx {
     int sweep_mode = 0;                   // 0 k_sweep (60-column tiles, whole band R in LDS), 1 k_wsweep<4> (ring), 2 k_wsweep<6> (90-column tiles, ring)
     std::vector<int> h_flush, h_flush_off;            // k_wsweep: per sweep node the rows final at the head of every macro step
     Buf dFlush, dFlushOff;
+    Buf dFeatInfo;                        // k_lsweep: per sorted feature the block offset and the window-slot -> view map
+    long long stack_elems = 0;            // scalars of the current batch's stack blocks (a zero word follows them)
+    bool leaf_narrow = false, leaf_wide = false;      // band plan: leaf nodes with w + 1 <= 64 / > 64 exist
     size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
     size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
     // group exchange (sharded band pipeline): the group triangles live in one export record at the head of rbuf
@@ -373,7 +377,22 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     if (mode < 0) return false;
     if (c->xchg && mode != 0) return false;                               // the exchange records are k_sweep's: root blocks then
     c->sweep_mode = mode;
-    const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 250;
+    // Leaf nodes (k_lsweep): one workgroup folds NF row blocks at a time, a block holds `fpb` features, so a node
+    // gets a multiple of NF * fpb features: enough nodes to fill the chip once, at most 128 features each.
+    // cfg.leaf_rows > 0 (tests) cuts the leaves by stacked rows instead.
+    const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : (1 << 30);
+    int leaf_feats = 128;
+    {
+        const bool wide_leaf = 6 * max_span + 1 > 64;
+        const int rb = wide_leaf ? LSweepGeom<6, LS_RS6>::RB : LSweepGeom<4, LS_RS4>::RB;
+        const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
+        const int unit = SWEEP_NW * fpb;
+        int want = (F + 239) / 240;
+        want = ((want + unit - 1) / unit) * unit;
+        leaf_feats = std::max(std::min(unit, 128), std::min(want, 128));
+        if (c->cfg.leaf_rows > 0) leaf_feats = 128;
+    }
+    c->leaf_narrow = c->leaf_wide = false;
     c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear();
     c->sweep_levels.clear(); c->n_group_merges = 0;
     // group exchange: the record [N flags | accepted count | N slots of XCHG_SLOT doubles] heads the workspace; the triangle of
@@ -393,12 +412,12 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         std::vector<Tri> leaves;
         while (f < F && (!live(f) || fmin[f] == s)) {
             if (!live(f)) { ++f; continue; }
-            int hi = fmax[f], rows = 0, e = f, last = f;
-            while (e < F && (e - f) < FOLD_MAX_SRC && (!live(e) || fmin[e] == s)) {
+            int hi = fmax[f], rows = 0, e = f, last = f, nlive = 0;
+            while (e < F && (e - f) < 128 && (!live(e) || fmin[e] == s)) {
                 if (live(e)) {
                     const int r = std::max(2 * (view_sorted[e + 1] - view_sorted[e]) - 3, 1);
-                    if (e > f && rows + r > leaf_rows) break;
-                    rows += r;
+                    if (e > f && (rows + r > leaf_rows || nlive >= leaf_feats)) break;
+                    rows += r; ++nlive;
                     hi = std::max(hi, fmax[e]);
                     last = e;
                 }
@@ -410,6 +429,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             n.out_off = (long long)off;
             off += (size_t)n.w * (n.w + 1);
             c->nodes.push_back(n);
+            if (n.w + 1 > 64) c->leaf_wide = true; else c->leaf_narrow = true;
             leaves.push_back({n.out_off, s, n.w});
             f = last + 1;
         }
@@ -559,6 +579,33 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
             if (maxw + 1 <= 6 * 32) hipLaunchKernelGGL((k_fold_g<FOLDG_T, 12, 6>), grid, block, FOLD_LDS_BYTES, c->stream, a);
             else hipLaunchKernelGGL((k_fold_g<FOLDG_T, 6, 10>), grid, block, FOLD_LDS_BYTES, c->stream, a);
         }
+    }
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
+// band plan, level 0: the leaves fold their features' K4 blocks (k_lsweep)
+int launch_leaves_band(msckf_ctx* c) {
+    if (c->n_leaves == 0) return MSCKF_OK;
+    LSweepArgs a{};
+    a.nodes = ptr<FoldNode>(c->dNodes);
+    a.node_base = 0;
+    a.info = ptr<FeatInfo>(c->dFeatInfo);
+    a.stack = c->dStack.p; a.stack_f32 = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
+    a.rank = ptr<int>(c->dRank);
+    a.accepted = ptr<unsigned char>(c->dAcc);
+    a.rbuf = ptr<double>(c->dRbuf);
+    a.zero_idx = c->stack_elems;
+    const dim3 grid(c->n_leaves), block(64 * SWEEP_NW);
+    if (c->leaf_narrow) {
+        a.wide = 0;
+        const size_t lds = lsweep_lds_bytes<4, LS_RS4>(SWEEP_NW);
+        hipLaunchKernelGGL((k_lsweep<SWEEP_NW, 4, LS_RS4>), grid, block, lds, c->stream, a);
+    }
+    if (c->leaf_wide) {
+        a.wide = 1;
+        const size_t lds = lsweep_lds_bytes<6, LS_RS6>(SWEEP_NW);
+        hipLaunchKernelGGL((k_lsweep<SWEEP_NW, 6, LS_RS6>), grid, block, lds, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
@@ -834,7 +881,8 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (!c->feature_launched && (rc = launch_feature(c)) != MSCKF_OK) return rc;
     c->feature_launched = false;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
-    if (c->F > 0 && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
+    if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c)) != MSCKF_OK) return rc;
+    if (c->F > 0 && !c->band_plan && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, with_gain || !c->xchg_planned)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
@@ -925,6 +973,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         for (const void* f : sm) lds_attr(f, LDS_MAX_BYTES - 1024, "k_solve_lds (one-sided) LDS attribute");
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 4, LS_RS4>), FOLD_LDS_BYTES, "k_lsweep<4> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 6, LS_RS6>), FOLD_LDS_BYTES, "k_lsweep<6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 4>), FOLD_LDS_BYTES, "k_wsweep<4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 6>), FOLD_LDS_BYTES, "k_wsweep<6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_chol<512>), LDS_MAX_BYTES - 1024, "k_chol LDS attribute");
@@ -981,7 +1031,7 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dSweepNodes, &c->dSweepFolds, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
-                  &c->dFlush, &c->dFlushOff};
+                  &c->dFlush, &c->dFlushOff, &c->dFeatInfo};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
@@ -1086,7 +1136,8 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const size_t o_uv = 0, o_base = o_uv + (size_t)sumM * 16, o_m = o_base + (size_t)F * 24, o_rho = o_m + (size_t)F * 24;
     const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
     const size_t o_slot = o_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7), o_fmin = o_slot + (((size_t)sumM * 4 + 7) & ~(size_t)7);
-    const size_t feat_bytes = o_fmin + (((size_t)F * 4 + 7) & ~(size_t)7);
+    const size_t o_info = (o_fmin + (size_t)F * 4 + 15) & ~(size_t)15;                    // FeatInfo records (16-byte aligned)
+    const size_t feat_bytes = o_info + (size_t)F * sizeof(FeatInfo);
     if (c->hFeatCap < feat_bytes) {
         if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
         c->hFeat = nullptr; c->hFeatCap = 0;
@@ -1103,6 +1154,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     int* h_viewp = reinterpret_cast<int*>(hb + o_view);
     int* h_slot = reinterpret_cast<int*>(hb + o_slot);
     int* h_fminp = reinterpret_cast<int*>(hb + o_fmin);
+    FeatInfo* h_info = reinterpret_cast<FeatInfo*>(hb + o_info);
     // gather into sorted order, straight into the pinned image
     std::vector<int> h_view(F + 1), h_fmin(F), h_fmax(F);
     long long blk = 0;
@@ -1119,6 +1171,15 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         h_fmin[sidx] = fmin_in[f]; h_fmax[sidx] = fmax_in[f];
         h_fminp[sidx] = fmin_in[f];
         h_blk[sidx] = blk;
+        {
+            FeatInfo& fi = h_info[sidx];
+            fi.blk_off = blk; fi.M = M; fi.pad = 0;
+            std::memset(fi.col, 0xFF, 16);
+            for (int v = 0; v < M; ++v) {
+                const int j = obs_slot[a + v] - fmin_in[f];
+                if (j < 16) fi.col[j] = (unsigned char)v;
+            }
+        }
         blk += (long long)(6 * M + 1) * (2 * M);
         pos += M;
     }
@@ -1137,15 +1198,19 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     set_view(c->dViewPtr, c->dFeatArena.p, o_view, (size_t)(F + 1) * 4);
     set_view(c->dObsSlot, c->dFeatArena.p, o_slot, (size_t)sumM * 4);
     set_view(c->dFmin, c->dFeatArena.p, o_fmin, (size_t)F * 4);
+    set_view(c->dFeatInfo, c->dFeatArena.p, o_info, (size_t)F * sizeof(FeatInfo));
     // gate results: rank[F] (int) then accepted[F] (byte), contiguous so they come back in one copy
     set_view(c->dRank, c->dGateArena.p, 0, (size_t)F * 4);
     set_view(c->dAcc, c->dGateArena.p, (size_t)F * 4, (size_t)F);
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
-    E(c->dStack, (size_t)blk * (c->cfg.dtype == MSCKF_DTYPE_F32 ? 4 : 8)); E(c->dGamma, (size_t)F * 8);
+    const size_t stack_es = c->cfg.dtype == MSCKF_DTYPE_F32 ? 4 : 8;
+    E(c->dStack, ((size_t)blk + 8) * stack_es); E(c->dGamma, (size_t)F * 8);
+    c->stack_elems = blk;
     if (rc != MSCKF_OK) return rc;
     // the tracks go first; in the one-shot call K1-K4 starts behind them while the host plans K5
     HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(static_cast<char*>(c->dStack.p) + (size_t)blk * stack_es, 0, 8 * stack_es, c->stream));   // k_lsweep's zero word
     c->feature_launched = false;
     if (c->oneshot) {
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
