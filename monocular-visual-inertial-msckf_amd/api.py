@@ -129,8 +129,8 @@ class UpdateEngine:
         N, F, d = prob.N, prob.F, prob.d
         a = self._pack(prob)
         chi = _ffi.f64(chi2_table())
-        dx = np.zeros(d)
-        P_out = np.zeros((d, d))
+        dx = np.empty(d)                           # the library writes every entry of dx, P_out, accepted[:F]
+        P_out = np.empty((d, d))
         acc = np.zeros(max(F, 1), dtype=np.uint8)
         st = _ffi.Stats()
         rc = self._lib.msckf_update(
@@ -143,13 +143,24 @@ class UpdateEngine:
         self._N, self._F = N, F
         return UpdateResult(rc, dx, P_out, acc[:F].copy(), st.as_dict())
 
-    @staticmethod
-    def _pack(prob: UpdateProblem) -> dict:
-        K = np.asarray(prob.K, dtype=np.float64)
+    _kinv_cache = (None, None)
+
+    @classmethod
+    def _kinv(cls, K) -> np.ndarray:
+        """inv(K) as the reference forms it (`MSCKF.py:519`); the intrinsics rarely change between calls."""
+        K = np.asarray(K, dtype=np.float64)
+        key, val = cls._kinv_cache
+        if key is None or key.shape != K.shape or not np.array_equal(key, K):
+            val = _ffi.f64(np.linalg.inv(K))
+            cls._kinv_cache = (K.copy(), val)
+        return val
+
+    @classmethod
+    def _pack(cls, prob: UpdateProblem) -> dict:
         return dict(
             P=_ffi.f64(prob.P), cam_R=_ffi.f64(prob.cam_R).reshape(-1), cam_t=_ffi.f64(prob.cam_t).reshape(-1),
             cam_R0=_ffi.f64(prob.cam_R0).reshape(-1), cam_t0=_ffi.f64(prob.cam_t0).reshape(-1),
-            g=_ffi.f64(prob.gravity), Kinv=_ffi.f64(np.linalg.inv(K)),      # reference MSCKF.py:519
+            g=_ffi.f64(prob.gravity), Kinv=cls._kinv(prob.K),               # reference MSCKF.py:519
             view_ptr=_ffi.i32(prob.view_ptr), obs_uv=_ffi.f64(prob.obs_uv).reshape(-1),
             obs_slot=_ffi.i32(prob.obs_slot), idp_base=_ffi.f64(prob.idp_base).reshape(-1),
             idp_m=_ffi.f64(prob.idp_m).reshape(-1), idp_rho=_ffi.f64(prob.idp_rho))

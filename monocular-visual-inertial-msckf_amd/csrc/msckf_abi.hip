@@ -127,6 +127,12 @@ struct msckf_ctx {
     std::vector<int> h_flush, h_flush_off;            // k_wsweep: per sweep node the rows final at the head of every macro step
     Buf dFlush, dFlushOff;
     Buf dFeatInfo;                        // k_lsweep: per sorted feature the block offset and the window-slot -> view map
+    // plan cache: the K5 plan is a function of (N, exchange mode, the sorted tracks' first slot / last slot / view count);
+    // a batch with the same key reuses the plan, its device tables and the zero pattern of the R workspace
+    bool plan_valid = false;
+    int plan_N = -1;
+    bool plan_xchg = false;
+    std::vector<int> plan_fmin, plan_fmax, plan_view;
     long long stack_elems = 0;            // scalars of the current batch's stack blocks (a zero word follows them)
     bool leaf_narrow = false, leaf_wide = false;      // band plan: leaf nodes with w + 1 <= 64 / > 64 exist
     size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
@@ -1094,6 +1100,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->F = 0;
         c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->band_plan = false; c->root = -1; c->perm.clear();
+        c->plan_valid = false;
         c->have_features = true;
         c->us_host_prep = (float)(now_us() - t0);
         return MSCKF_OK;
@@ -1218,12 +1225,18 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->feature_launched = true;
     }
     const double t2 = now_us();
-    plan_batch(c, h_fmin, h_fmax, h_view);
+    const bool plan_hit = c->plan_valid && c->plan_N == N && c->plan_xchg == c->xchg && c->plan_view == h_view &&
+                          c->plan_fmin == h_fmin && c->plan_fmax == h_fmax;
+    if (!plan_hit) {
+        c->plan_valid = false;
+        plan_batch(c, h_fmin, h_fmax, h_view);
+        c->plan_N = N; c->plan_xchg = c->xchg; c->plan_view = h_view;   // (h_fmin / h_fmax are stored below, after their last use)
+    }
     // room for gathered shard blocks behind the plan's blocks
     c->gather_off = c->rbuf_doubles;
     const double t3 = now_us();
     c->us_host_prep = (float)((t1 - t0) + (t3 - t2));
-    {
+    if (!plan_hit) {
         // the R workspace is zero-initialised once: entries below a block's diagonal are never written
         const size_t need = (c->rbuf_doubles + 16) * 8;
         if (c->dRbuf.bytes < need) {
@@ -1234,8 +1247,11 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             c->dRbuf.bytes = want;
         }
         HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
+        c->plan_valid = false;
+        if (int rcp = upload_plan(c)) return rcp;
+        c->plan_fmin = h_fmin; c->plan_fmax = h_fmax;
+        c->plan_valid = true;
     }
-    if (int rcp = upload_plan(c)) return rcp;
     if (!c->oneshot) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->us_h2d += (float)((t2 - t1) + (now_us() - t3));
     c->have_features = true;
@@ -1465,6 +1481,7 @@ int msckf_replan(msckf_ctx* c) {
     std::vector<unsigned char> flags(c->F);
     HIPCHK(c, hipMemcpyAsync(flags.data(), c->dSelFlags.p, c->F, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->plan_valid = false;                 // the plan no longer covers every candidate: the next upload plans afresh
     plan_batch(c, c->h_fmin, c->h_fmax, c->h_view_sorted, &flags);
     c->gather_off = c->rbuf_doubles;
     // the blocks moved inside the R workspace: entries below their diagonals must read as zero again

@@ -27,7 +27,8 @@ def test_header_symbols_are_bound_and_exported(engine_lib):
 def test_struct_sizes_match_header():
     import ctypes as C
     from msckf_amd import _ffi
-    assert C.sizeof(_ffi.Config) == 8 * 4
+    assert C.sizeof(_ffi.Config) == 10 * 4          # ABI v2: + dtype, reserved0
+    assert _ffi.Config.dtype.offset == 32 and _ffi.ABI_VERSION == 2
     assert C.sizeof(_ffi.Stats) == 8 * 4 + 8 * 4
     assert C.sizeof(_ffi.SelectParamsC) == 6 * 4 + 8 + 9 * 8
     assert _ffi.SelectParamsC.min_parallax_deg.offset == 24 and _ffi.SelectParamsC.K.offset == 32
