@@ -58,9 +58,11 @@ SEL_VALID, SEL_LOST, SEL_REFRESHED = 1, 2, 4
 
 _lib = None
 
-_dp = C.POINTER(C.c_double)
-_ip = C.POINTER(C.c_int32)
-_up = C.POINTER(C.c_uint8)
+# Array arguments travel as plain addresses (c_void_p): `ndarray.ctypes.data_as(POINTER(...))` costs 3-5 us per
+# argument, which was 60+ us of the 23-argument one-shot call.
+_dp = C.c_void_p
+_ip = C.c_void_p
+_up = C.c_void_p
 
 
 def load():
@@ -161,15 +163,11 @@ def i32(a):
 
 
 def dptr(a):
-    return a.ctypes.data_as(_dp)
+    return a.ctypes.data
 
 
-def iptr(a):
-    return a.ctypes.data_as(_ip)
-
-
-def uptr(a):
-    return a.ctypes.data_as(_up)
+iptr = dptr
+uptr = dptr
 
 
 class EngineError(RuntimeError):

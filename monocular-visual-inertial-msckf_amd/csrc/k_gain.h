@@ -91,6 +91,72 @@ __global__ __launch_bounds__(64) void k_gemm_f64(GemmArgs g) {
     }
 }
 
+// The same product on the f32 matrix cores (v_mfma_f32_16x16x4_f32) for MSCKF_DTYPE_F32: the Joseph covariance
+// update (MSCKF.py:612-614) with fp32 operands and fp32 accumulation.  Operands may be stored as double (the
+// fp64 state: P, K, Y, T -- rounded to float as they are loaded) or float (the update's own intermediates
+// B2, D, Pn); the result is stored as float or double.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct Gemm32Args {
+    const void* A; int lda; int a_f32;    // A[M][K]
+    const void* B; int ldb; int b_f32;    // transB ? B[N][K] : B[K][N]
+    const void* C0; int ldc0; int c0_f32; // optional addend
+    void* C; int ldc; int c_f32;
+    int M, N, K;
+    float alpha, beta;
+    int transB;
+    int tri;                              // 1: B[N][K] upper triangular (k >= n), transB only
+};
+
+__device__ __forceinline__ float ld32(const void* p, size_t i, int f32) {
+    return f32 ? static_cast<const float*>(p)[i] : (float)static_cast<const double*>(p)[i];
+}
+
+template <bool AF, bool C0F>      // A / C0 stored as float (else double); B is always one of the fp64 operands
+__global__ __launch_bounds__(64) void k_gemm_f32(Gemm32Args g) {
+    const int lane = threadIdx.x;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int r = lane & 15, grp = lane >> 4;
+    const int kbeg = (g.tri == 1) ? n0 : 0;
+    const int klen = g.K - kbeg;
+    const int kq = (klen + 3) / 4;
+    const int k_lo = kbeg + grp * kq;
+    const int k_hi = min(g.K, k_lo + kq);
+    const int arow = m0 + r, bcol = n0 + r;
+    const bool aok = arow < g.M, bok = bcol < g.N;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int TRIP = 16;
+    for (int s0 = 0; s0 < kq; s0 += TRIP) {
+        float av[TRIP], bv[TRIP];
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) {
+            const int k = k_lo + s0 + u;
+            const bool kok = (s0 + u < kq) && (k < k_hi);
+            av[u] = (aok && kok) ? ld32(g.A, (size_t)arow * g.lda + k, AF) : 0.f;
+            bv[u] = (bok && kok) ? ld32(g.B, (size_t)bcol * g.ldb + k, 0) : 0.f;      // B[N][K] (transB form), double
+        }
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
+    const int col = n0 + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + 4 * (lane >> 4) + i;
+        if (row < g.M && col < g.N) {
+            float x = g.alpha * acc[i];
+            if (g.C0) x += g.beta * ld32(g.C0, (size_t)row * g.ldc0 + col, C0F);
+            static_cast<float*>(g.C)[(size_t)row * g.ldc + col] = x;
+        }
+    }
+}
+
+// P_out = (Pn + Pn^T) / 2 from the fp32 Pn, stored as double  (reference MSCKF.py:614)
+__global__ void k_symmetrize_f32(const float* Pn, double* Pout, int d, int ld) {
+    const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
+    if (i < d && j < d) Pout[(size_t)i * ld + j] = (double)(0.5f * (Pn[(size_t)i * ld + j] + Pn[(size_t)j * ld + i]));
+}
+
 // Cholesky S = L L^T of an n x n SPD matrix by one workgroup.  Works on the
 // packed lower triangle in LDS when it fits (use_lds), else in place in HBM/L2.
 // Writes L (row-major, ld = n), U = L^T (row-major) and invd[j] = 1 / L[j][j].

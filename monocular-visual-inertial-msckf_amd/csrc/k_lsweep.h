@@ -155,7 +155,8 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
             cw[0] = pa_c[0]; cw[1] = pa_c[1]; cw[2] = pa_c[2]; cw[3] = pa_c[3];
         }
     };
-    auto gather = [&](auto& dst) __attribute__((always_inline)) {
+    auto gather_t = [&](auto& dst, auto tagf) __attribute__((always_inline)) {
+        constexpr bool F32 = decltype(tagf)::value != 0;
         const double* sd = static_cast<const double*>(p.stack);
         const float* sf = static_cast<const float*>(p.stack);
 #pragma unroll
@@ -173,12 +174,17 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
                 const bool ok = (Mr > 0) && (isr || v != 0xFF);
                 const int cc = isr ? 6 * Mr : 6 * v + aa;
                 const long long idx = ok ? (long long)(rb + cc) : p.zero_idx;
-                dst[rr][k] = p.stack_f32 ? (double)sf[idx] : sd[idx];
+                if constexpr (F32) dst[rr][k] = (double)sf[idx];
+                else dst[rr][k] = sd[idx];
             }
             // (keeps the address arithmetic of one row slot from being hoisted over the loads of all the others:
             //  without it the 90-column tile needs ~100 registers of addresses on top of the two blocks)
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto gather = [&](auto& dst) __attribute__((always_inline)) {
+        if (p.stack_f32) gather_t(dst, STag<1>{});
+        else gather_t(dst, STag<0>{});
     };
 
     auto publish = [&](auto tagk) {

@@ -843,6 +843,28 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         else hipLaunchKernelGGL(k_solve<5>, dim3(d), dim3(64), 0, c->stream, a);
     }
     }
+    if (c->cfg.dtype == MSCKF_DTYPE_F32) {
+        // Joseph form on the f32 matrix cores: fp32 operands (the fp64 P, K, Y, T are rounded as they are loaded),
+        // fp32 intermediates B2, D, Pn, fp32 accumulation; P_out leaves as double
+        auto gemm32 = [&](const void* A, int lda, int af, const void* B, int ldb, int bf, const void* C0, int ldc0, int c0f,
+                          void* C, int ldc, int M_, int N_, int K_, float alpha, float beta, int tri) {
+            Gemm32Args g{A, lda, af, B, ldb, bf, C0, ldc0, c0f, C, ldc, 1, M_, N_, K_, alpha, beta, 1, tri};
+            const dim3 grid((N_ + 15) / 16, (M_ + 15) / 16);
+            if (!af && !c0f) hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, dim3(64), 0, c->stream, g);
+            else if (af && !c0f) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, dim3(64), 0, c->stream, g);
+            else hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, dim3(64), 0, c->stream, g);
+        };
+        float* B2f = reinterpret_cast<float*>(B2);
+        float* Df = reinterpret_cast<float*>(D);
+        float* Pnf = reinterpret_cast<float*>(Pn);
+        gemm32(Kg, dc, 0, Y, dc, 0, P, d, 0, B2f, d, d, d, dc, -1.f, 1.f, 0);                     // B2 = P - K Y^T
+        gemm32(B2f + 15, d, 1, Tblk, ldt, 0, Kg, dc, 0, Df, dc, d, dc, dc, -1.f, (float)s2, 1);   // D = s2 K - B2[:,15:] T^T
+        gemm32(Df, dc, 1, Kg, dc, 0, B2f, d, 1, Pnf, d, d, d, dc, 1.f, 1.f, 0);                   // Pn = B2 + D K^T
+        hipLaunchKernelGGL(k_symmetrize_f32, dim3((d + 15) / 16, (d + 15) / 16), dim3(16, 16), 0, c->stream, Pnf,
+                           ptr<double>(c->dPout), d, d);
+        HIPCHK(c, hipGetLastError());
+        return MSCKF_OK;
+    }
     // Joseph form (MSCKF.py:613) with A = I - K T_H, T_H = [0 | T]:
     //   B2 = A P = P - K (T_H P) = P - K Y^T           (P symmetric)
     gemm(c, Kg, dc, Y, dc, P, d, B2, d, d, d, dc, -1.0, 1.0, 0.0, 1, 0);
