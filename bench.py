@@ -16,11 +16,12 @@ N = 1 : BASELINE.json configs[2] (headline: N=30 clones, 2000 features, track 10
         (30, 10000, 10), configs[3] on one GPU, configs[4] in fp64 and with fp32
         storage) with its own roofline fractions, `roofline` for the dominant
         kernel group (K5) and `cpu_baseline`.
-N > 1 : (launched by torch.distributed.run, one rank per GPU) the feature-sharded
-        update: `value` = weak scaling, 2000 features per rank (configs[3] at 4
-        GPUs), one gather of the compressed blocks to rank 0, serial gain there,
-        broadcast of dx / P+; the same line also carries configs[3] as written
-        (8000 features in all, split N ways: strong scaling).
+N > 1 : (launched by torch.distributed.run, one rank per GPU; only RANK / LOCAL_RANK /
+        WORLD_SIZE are read -- the exchange is librccl behind the C-ABI, no PyTorch)
+        the feature-sharded update: `value` = weak scaling, 2000 features per rank
+        (configs[3] at 4 GPUs), ONE RCCL gather of the compressed group records to
+        rank 0, serial gain there, ONE RCCL broadcast of dx / P+; the same line also
+        carries configs[3] as written (8000 features in all, split N ways: strong).
 
 Rank 0 prints ONE JSON line.  The oracle (oracle/msckf_oracle.py) is only timed
 as the CPU baseline; it is never on the measured GPU path.
@@ -170,8 +171,6 @@ def main():
     N, Fg, M = args.clones, args.features, args.track
 
     use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch  # noqa: F401  (must be imported before the library: both ship a libamdhip64)
     import msckf_amd  # noqa: F401
     from msckf_amd import synth
     from msckf_amd.api import UpdateEngine
@@ -322,87 +321,54 @@ def main():
 
 
 def bench_sharded(args, world, rank, local_rank):
-    """N > 1: one rank per GPU.  Weak scaling (2000 features per rank) is `value`; configs[3] as written (8000
-    features in all, split over the ranks) rides in the same line as `strong_scaling_configs3`."""
-    import torch                                           # plumbing: rendezvous + RCCL gather / broadcast
-    import torch.distributed as dist
+    """N > 1: one rank per GPU, exchange on librccl behind the C-ABI (msckf_comm_*, no PyTorch).  Weak scaling
+    (2000 features per rank) is `value`; configs[3] as written (8000 features in all, split over the ranks) rides
+    in the same line as `strong_scaling_configs3`."""
     from msckf_amd import synth
     from msckf_amd.api import UpdateEngine
-    from msckf_amd.shard import partition_features
-    torch.cuda.set_device(local_rank)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from msckf_amd.shard import RcclShardedUpdate, exchange_unique_id
     N, Fg, M = args.clones, args.features, args.track
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # RCCL's version banner must not land beside the JSON line
+    id_base = "/tmp/msckf_rccl_id_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "x"),
+                                               os.getppid())
 
-    def run_case(F_total, steps, warmup):
+    def run_case(F_total, steps, warmup, tag):
         prob = synth.make_problem(N, F_total, M, seed=0)
         eng = UpdateEngine(max_clones=N, max_features=F_total, max_track=max(M, 2), device=local_rank)
-        lo, hi = partition_features(prob.view_ptr, world)[rank]
-        local = prob.subset(lo, hi)
-        # exchange format (every rank sees the whole batch, so all agree): group triangles when the batch
-        # runs the band pipeline -- each rank stops in front of its root sweep, rank 0 folds the shards' groups
-        # and runs ONE root sweep -- else the root blocks [R | Q^T r] and the fold-tree merge
-        groups = eng.band_ok(prob)
-        eng.set_group_exchange(groups)
-        eng.load(local)
-        nblk = eng.group_record_doubles() if groups else eng.block_doubles()
-        d = prob.d
-        # send buffer: a group record carries the shard's accepted count itself; a root block [R | Q^T r] gets one
-        # trailing double for it (so the gather stays the only collective before the merge)
-        rec = nblk if groups else nblk + 1
-        mine = torch.zeros(rec, dtype=torch.float64, device="cuda")
-        gathered = torch.zeros(world * rec, dtype=torch.float64, device="cuda") if rank == 0 else None
-        glist = list(gathered.view(world, rec).unbind(0)) if rank == 0 else None
-        packed = torch.zeros(world * nblk, dtype=torch.float64, device="cuda") if rank == 0 and world > 1 and not groups else None
-        # broadcast buffer: on rank 0 the engine's own result range dx | P+ (zero copy), a plain tensor elsewhere
-        out = torch.as_tensor(eng.result_device_view(), device="cuda") if rank == 0 else \
-            torch.zeros(d + d * d, dtype=torch.float64, device="cuda")
+        uid = exchange_unique_id(eng, rank, world, id_base + tag)
+        drv = RcclShardedUpdate(eng, rank, world, uid)
+        drv.load(prob)                                       # every rank keeps its shard (and the state) resident
+        tbuf = eng.comm_buffer(drv.count * (world + 1) + 8) + 8 * drv.count * (world + 1)   # one double behind the exchange buffers
 
-        def step():
-            eng.run_compress()                                   # K1-K5 on the local shard (no root sweep with groups)
-            if groups:
-                eng.export_groups(dst_ptr=mine.data_ptr(), count=False)   # D2D into the torch-owned send buffer (syncs)
-            else:
-                _, n = eng.export_block(dst_ptr=mine.data_ptr())
-                mine[nblk] = float(n)
-            dist.gather(mine, gather_list=glist, dst=0)          # ONE RCCL gather
-            if rank == 0:
-                if groups:
-                    torch.cuda.current_stream().synchronize()    # the gather has landed (the engine has its own stream)
-                    eng.merge_groups(int(gathered.data_ptr()), -1, n_records=world)   # counts are in the records
-                else:
-                    g2 = gathered.view(world, rec)
-                    total = int(g2[:, nblk].sum().item())        # syncs: the gather has landed
-                    if world > 1:
-                        packed.view(world, nblk).copy_(g2[:, :nblk])   # contiguous blocks for the merge
-                        torch.cuda.current_stream().synchronize()
-                        src = packed
-                    else:
-                        src = gathered
-                    eng.merge_gain(int(src.data_ptr()), total, n_blocks=world)
-                eng.sync()                                       # dx | P+ are in the engine's result range = `out`
-            dist.broadcast(out, src=0)                           # state for the next update on every rank
+        def barrier():
+            eng.comm_allreduce(tbuf, 1, "sum")
+            eng.sync()
 
         for _ in range(warmup):
-            step()
-        torch.cuda.synchronize()
-        dist.barrier()
+            drv.step()
+        eng.sync()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dist.barrier()
+            drv.step()                                       # compress -> RCCL gather -> merge + K6-K7 on rank 0 -> RCCL broadcast
+        eng.sync()
+        barrier()
         wall = time.perf_counter() - t0
-        tmax = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        del out
+        eng.comm_put(tbuf, np.array([wall]))
+        eng.comm_allreduce(tbuf, 1, "max")
+        eng.sync()
+        seconds = float(eng.comm_get(tbuf, 1)[0])
+        status, dx, P = drv.result()
+        groups = drv.groups
+        drv.close()
         eng.close()
-        return float(tmax.item()), groups
+        if rank == 0 and os.path.exists(id_base + tag):
+            os.remove(id_base + tag)
+        return seconds, groups, status
 
-    seconds, groups = run_case(Fg * world, args.steps, args.warmup)
+    seconds, groups, st1 = run_case(Fg * world, args.steps, args.warmup, "_weak")
     strong_steps = max(10, min(args.steps, 100))
-    s_seconds, s_groups = run_case(8000, strong_steps, min(args.warmup, 10))
+    s_seconds, s_groups, st2 = run_case(8000, strong_steps, min(args.warmup, 10), "_strong")
     line = None
     if rank == 0:
         units = args.steps * world                               # 2000-feature update equivalents
@@ -420,17 +386,17 @@ def bench_sharded(args, world, rank, local_rank):
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"N={N} clones, F={Fg} features per GPU, track={M}, fp64, feature-sharded over {world} GPUs "
-                                   f"({Fg * world} features per update), 1 RCCL gather + broadcast per update",
+                                   f"({Fg * world} features per update), 1 RCCL gather + 1 RCCL broadcast per update "
+                                   "(librccl behind the C-ABI, no PyTorch)",
                        "exchange": "group triangles" if groups else "root blocks",
                        "unit_definition": "one 2000-feature measurement update (K1-K7)", "seed": 0},
             "sharded_updates_per_s": args.steps / seconds,
+            "status": [int(st1), int(st2)],
             "strong_scaling_configs3": {
                 "workload": f"BASELINE.json configs[3]: N={N} clones, 8000 features in all, track={M}, fp64, split over {world} GPUs",
                 "updates_per_s": strong_steps / s_seconds, "ms_per_update": 1e3 * s_seconds / strong_steps,
                 "steps": strong_steps, "exchange": "group triangles" if s_groups else "root blocks", "scaling": "strong"},
         }
-    dist.barrier()
-    dist.destroy_process_group()
     return line
 
 

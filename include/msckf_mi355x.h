@@ -253,6 +253,37 @@ int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_ac
 int msckf_run_merge_groups(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,
                            int32_t total_accepted /* < 0: the sum of the counts in the records */);
 
+/* Variant of msckf_run_merge_groups without any device-to-host traffic: `flags` (n_records x N bytes, host,
+ * nullable) says which first-slot groups each record carries -- every rank sees the whole batch, so the host
+ * side knows it (shard.py computes it from the partition) -- and the shards' accepted counts are summed on the
+ * device (msckf_get_result reads the sum with the results).  flags == NULL reads the record heads back like
+ * msckf_run_merge_groups. */
+int msckf_run_merge_groups_flags(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,
+                                 const uint8_t* flags);
+
+/* ---- RCCL exchange behind the C-ABI (one context = one rank = one GPU; no PyTorch on the data path) ---- *
+ * The one exchange of the sharded update (gather of the compressed blocks to rank 0,
+ * broadcast of dx | P+ back) on librccl, loaded with dlopen at the first call (a single-GPU process never
+ * loads it).  Bootstrap: rank 0 calls msckf_comm_unique_id and hands the 128 bytes to the other ranks by any
+ * side channel (shard.py uses a file); every rank then calls msckf_comm_init.  All collectives are enqueued on
+ * the context's stream, behind the kernels that produce their operands; buffers are HBM addresses. */
+#define MSCKF_COMM_ID_BYTES 128
+#define MSCKF_ERR_COMM (-7)         /* RCCL failure (msckf_last_error has the text)                      */
+int msckf_comm_unique_id(void* id_out /* MSCKF_COMM_ID_BYTES */);
+int msckf_comm_init(msckf_ctx* ctx, int32_t rank, int32_t world, const void* id);
+int msckf_comm_destroy(msckf_ctx* ctx);
+/* rank `root` receives world x count doubles (rank r's at recv + r * count); recv is ignored elsewhere. */
+int msckf_comm_gather(msckf_ctx* ctx, const void* send, void* recv, size_t count, int32_t root);
+int msckf_comm_broadcast(msckf_ctx* ctx, void* buf, size_t count, int32_t root);
+/* In-place all-reduce of `count` doubles; op 0 = sum, 1 = max. */
+int msckf_comm_allreduce(msckf_ctx* ctx, void* buf, size_t count, int32_t op);
+/* An HBM scratch buffer owned by the context (grown on demand, contents undefined): receive side of the gather. */
+void* msckf_comm_buffer(msckf_ctx* ctx, size_t bytes);
+/* Blocking copies between host memory and an HBM address, ordered on the context's stream (staging of the
+ * root-block fallback exchange; the group exchange needs neither). */
+int msckf_comm_put(msckf_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int msckf_comm_get(msckf_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+
 /* Copy dx[d] and P_out[d*d] of the last run into caller buffers that may live in HBM
  * (device_ptr != 0), e.g. the send buffer of the broadcast that follows the merge. */
 int msckf_export_result(msckf_ctx* ctx, void* dx_dst, void* P_dst, int device_ptr);
@@ -271,7 +302,8 @@ int msckf_debug_fold_stamps(msckf_ctx* ctx, long long* out, int32_t max_nodes);
 /* Average device time of the selection kernel (HIP events, `iters` re-launches of the last
  * msckf_run_select; the kernel is idempotent). */
 int msckf_debug_time_select(msckf_ctx* ctx, int32_t iters, float* us_per_launch);
-/* Raw device pointers (as integers) for zero-copy interop: which = 0 dx, 1 P_out, 2 block. */
+/* Raw device pointers (as integers) for zero-copy interop: which = 0 dx (dx | P_out are contiguous), 1 P_out,
+ * 2 root block [T | r_n], 3 the shard's group record (msckf_set_group_exchange), 4 the prior covariance P. */
 uint64_t msckf_device_pointer(msckf_ctx* ctx, int which);
 void* msckf_stream(msckf_ctx* ctx);                     /* hipStream_t of the context */
 

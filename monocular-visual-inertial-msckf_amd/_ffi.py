@@ -14,7 +14,8 @@ ABI_VERSION = 2
 DTYPE_F64, DTYPE_F32 = 0, 1
 
 OK, NOOP = 0, 1
-ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_SPD, ERR_STATE, ERR_DUP_SLOT = -1, -2, -3, -4, -5, -6
+ERR_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_NOT_SPD, ERR_STATE, ERR_DUP_SLOT, ERR_COMM = -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 MAX_TRACK = 31
 
 # every symbol include/msckf_mi355x.h declares
@@ -23,11 +24,13 @@ SYMBOLS = [
     "msckf_update", "msckf_set_state", "msckf_set_features", "msckf_run", "msckf_run_timed", "msckf_sync",
     "msckf_get_result", "msckf_commit_covariance", "msckf_run_compress", "msckf_block_doubles",
     "msckf_export_block", "msckf_run_merge_gain", "msckf_set_group_exchange", "msckf_band_rule", "msckf_group_record_doubles",
-    "msckf_export_groups", "msckf_run_merge_groups", "msckf_export_result", "msckf_import_covariance", "msckf_debug_gate", "msckf_debug_compressed", "msckf_debug_fold_stamps",
+    "msckf_export_groups", "msckf_run_merge_groups", "msckf_run_merge_groups_flags", "msckf_export_result", "msckf_import_covariance", "msckf_debug_gate", "msckf_debug_compressed", "msckf_debug_fold_stamps",
     "msckf_device_pointer", "msckf_stream",
     "msckf_set_tracks", "msckf_run_select", "msckf_clear_selection", "msckf_get_selection",
     "msckf_debug_time_select", "msckf_replan",
     "msckf_propagate", "msckf_augment", "msckf_remove_clones", "msckf_set_poses", "msckf_get_covariance",
+    "msckf_comm_unique_id", "msckf_comm_init", "msckf_comm_destroy", "msckf_comm_gather", "msckf_comm_broadcast",
+    "msckf_comm_allreduce", "msckf_comm_buffer", "msckf_comm_put", "msckf_comm_get",
 ]
 
 
@@ -116,6 +119,26 @@ def load():
     lib.msckf_export_groups.restype = C.c_int
     lib.msckf_run_merge_groups.argtypes = [vp, vp, C.c_int32, C.c_int, C.c_int32]
     lib.msckf_run_merge_groups.restype = C.c_int
+    lib.msckf_run_merge_groups_flags.argtypes = [vp, vp, C.c_int32, C.c_int, vp]
+    lib.msckf_run_merge_groups_flags.restype = C.c_int
+    lib.msckf_comm_unique_id.argtypes = [vp]
+    lib.msckf_comm_unique_id.restype = C.c_int
+    lib.msckf_comm_init.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.msckf_comm_init.restype = C.c_int
+    lib.msckf_comm_destroy.argtypes = [vp]
+    lib.msckf_comm_destroy.restype = C.c_int
+    lib.msckf_comm_gather.argtypes = [vp, vp, vp, C.c_size_t, C.c_int32]
+    lib.msckf_comm_gather.restype = C.c_int
+    lib.msckf_comm_broadcast.argtypes = [vp, vp, C.c_size_t, C.c_int32]
+    lib.msckf_comm_broadcast.restype = C.c_int
+    lib.msckf_comm_allreduce.argtypes = [vp, vp, C.c_size_t, C.c_int32]
+    lib.msckf_comm_allreduce.restype = C.c_int
+    lib.msckf_comm_put.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.msckf_comm_put.restype = C.c_int
+    lib.msckf_comm_get.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.msckf_comm_get.restype = C.c_int
+    lib.msckf_comm_buffer.argtypes = [vp, C.c_size_t]
+    lib.msckf_comm_buffer.restype = vp
     lib.msckf_export_result.argtypes = [vp, vp, vp, C.c_int]
     lib.msckf_export_result.restype = C.c_int
     lib.msckf_import_covariance.argtypes = [vp, vp, C.c_int]

@@ -118,7 +118,7 @@ class UpdateEngine:
         if rc == 0 or (allow_noop and rc == 1):
             return rc
         text = self._lib.msckf_strerror(rc).decode()
-        if rc == _ffi.ERR_HIP:
+        if rc in (_ffi.ERR_HIP, _ffi.ERR_COMM):
             text += ": " + self._lib.msckf_last_error(self._h).decode()
         raise _ffi.EngineError(rc, text)
 
@@ -408,6 +408,66 @@ class UpdateEngine:
             b = _ffi.f64(records)
             self._check(self._lib.msckf_run_merge_groups(self._h, b.ctypes.data_as(C.c_void_p), int(b.shape[0]), 0,
                                                          int(total_accepted)), allow_noop=False)
+
+    def merge_groups_flags(self, records_ptr: int, n_records: int, flags: np.ndarray):
+        """`merge_groups` without any device-to-host traffic: `flags` (n_records, N) uint8 says which first-slot
+        groups each shard's record carries (the caller partitioned the batch, so it knows); the accepted counts
+        are summed on the device.  `records_ptr` is an HBM address."""
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(self._lib.msckf_run_merge_groups_flags(self._h, C.c_void_p(int(records_ptr)), int(n_records), 1,
+                                                           fl.ctypes.data), allow_noop=False)
+
+    # -- RCCL exchange behind the C-ABI (no PyTorch) -----------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(_ffi.COMM_ID_BYTES)
+        self._check(self._lib.msckf_comm_unique_id(buf), allow_noop=False)
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, uid: bytes):
+        if len(uid) != _ffi.COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        self._check(self._lib.msckf_comm_init(self._h, int(rank), int(world), C.c_char_p(uid)), allow_noop=False)
+
+    def comm_destroy(self):
+        self._check(self._lib.msckf_comm_destroy(self._h), allow_noop=False)
+
+    def comm_buffer(self, n_doubles: int) -> int:
+        """HBM scratch of the engine (address), e.g. the receive side of the gather on the merging rank."""
+        p = self._lib.msckf_comm_buffer(self._h, int(n_doubles) * 8)
+        if not p:
+            raise _ffi.EngineError(_ffi.ERR_HIP, "comm buffer allocation failed")
+        return int(p)
+
+    def comm_gather(self, send_ptr: int, recv_ptr: int, count: int, root: int = 0):
+        self._check(self._lib.msckf_comm_gather(self._h, C.c_void_p(int(send_ptr)), C.c_void_p(int(recv_ptr) if recv_ptr else None),
+                                                int(count), int(root)), allow_noop=False)
+
+    def comm_broadcast(self, ptr: int, count: int, root: int = 0):
+        self._check(self._lib.msckf_comm_broadcast(self._h, C.c_void_p(int(ptr)), int(count), int(root)), allow_noop=False)
+
+    def comm_allreduce(self, ptr: int, count: int, op: str = "sum"):
+        self._check(self._lib.msckf_comm_allreduce(self._h, C.c_void_p(int(ptr)), int(count), 1 if op == "max" else 0),
+                    allow_noop=False)
+
+    def comm_put(self, dst_ptr: int, host: np.ndarray):
+        a = _ffi.f64(host)
+        self._check(self._lib.msckf_comm_put(self._h, C.c_void_p(int(dst_ptr)), a.ctypes.data, a.nbytes), allow_noop=False)
+
+    def comm_get(self, src_ptr: int, n_doubles: int) -> np.ndarray:
+        out = np.empty(int(n_doubles))
+        self._check(self._lib.msckf_comm_get(self._h, out.ctypes.data, C.c_void_p(int(src_ptr)), out.nbytes), allow_noop=False)
+        return out
+
+    def result_host(self):
+        """dx, P+ of the result range as host arrays without the gate bookkeeping (ranks that received them
+        through the broadcast)."""
+        d = 15 + 6 * self._N
+        o = self.comm_get(self.device_pointer(0), d + d * d)
+        return o[:d].copy(), o[d:].reshape(d, d).copy()
+
+    def device_pointer(self, which: int) -> int:
+        """0 dx | P_out (contiguous), 1 P_out, 2 root block, 3 group record of the shard, 4 prior covariance."""
+        return int(self._lib.msckf_device_pointer(self._h, int(which)))
 
     def result_device_view(self):
         """`dx | P+` of the last run as ONE contiguous HBM range (d + d*d doubles) exposed through

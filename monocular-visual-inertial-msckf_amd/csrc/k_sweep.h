@@ -104,6 +104,14 @@ __global__ __launch_bounds__(256) void k_count_accepted(const unsigned char* acc
     if (threadIdx.x == 0) *dst = (double)(part[0] + part[1] + part[2] + part[3]);
 }
 
+// Sum of the accepted counts the shards wrote into their group records (double N of every record) -> one int.
+__global__ __launch_bounds__(64) void k_sum_record_counts(const double* recs, long long rec_stride, int N, int n_rec, int* dst) {
+    double s = 0.0;
+    for (int r = threadIdx.x; r < n_rec; r += 64) s += recs[(size_t)r * rec_stride + N];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *dst = (int)(s + 0.5);
+}
+
 template <int KK> struct STag { static constexpr int value = KK; };
 
 #ifdef SWEEP_PROF

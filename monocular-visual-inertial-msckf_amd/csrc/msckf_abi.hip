@@ -2,6 +2,8 @@
 // feature sort + QR-tree plan, and the launch sequence K1..K7 on one HIP stream.
 // gfx950 only.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: librccl is loaded with dlopen at the first msckf_comm_* call
 
 #include <algorithm>
 #include <chrono>
@@ -102,6 +104,10 @@ struct msckf_ctx {
     // current problem
     int N = 0, d = 0, dc = 0, F = 0, sumM = 0, Mmax = 0;
     bool have_state = false, have_features = false, ran = false, ran_gain = false;
+    bool acc_from_dev = false;            // the accepted total of a merged update sits in status word 2 (summed on the device)
+    ncclComm_t comm = nullptr;            // RCCL communicator of the sharded update (msckf_comm_init)
+    int comm_rank = 0, comm_world = 1;
+    Buf dCommBuf;
     bool gain_blocked = false;            // the last K6 ran the two-block factorisation (second status word in use)
     double sigma = 0.0;
     double g[3]{}, Kinv[9]{};
@@ -184,6 +190,47 @@ namespace {
             return MSCKF_ERR_HIP;                                                               \
         }                                                                                       \
     } while (0)
+
+// ---- librccl, loaded on demand (the sharded update's one exchange; a single-GPU process never loads it) ----
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi& rccl() {
+    static RcclApi api;
+    if (api.lib || !api.err.empty()) return api;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
+    if (!api.lib) { api.err = std::string("dlopen librccl: ") + dlerror(); return api; }
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p) { ok = false; api.err = std::string("librccl has no ") + n; } return p; };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.Gather = reinterpret_cast<decltype(api.Gather)>(sym("ncclGather"));
+    api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(api.lib); api.lib = nullptr; }
+    return api;
+}
+#define NCCLCHK(ctx, call)                                                                      \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess) {                                                                \
+            (ctx)->last_error = std::string(#call) + ": " + rccl().GetErrorString(r_);          \
+            return MSCKF_ERR_COMM;                                                              \
+        }                                                                                       \
+    } while (0)
+
+
 
 int ensure(msckf_ctx* c, Buf& b, size_t bytes, bool zero = false) {
     if (b.bytes >= bytes && b.p) return MSCKF_OK;
@@ -926,6 +973,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     c->ran = true;
     c->ran_gain = with_gain;
     c->acc_override = -1;
+    c->acc_from_dev = false;
     return MSCKF_OK;
 }
 
@@ -943,6 +991,7 @@ const char* msckf_strerror(int code) {
         case MSCKF_ERR_NOT_SPD: return "innovation covariance not positive definite";
         case MSCKF_ERR_STATE: return "call order: set_state and set_features must precede run";
         case MSCKF_ERR_DUP_SLOT: return "a track observes the same clone slot twice";
+        case MSCKF_ERR_COMM: return "RCCL error";
         default: return "unknown";
     }
 }
@@ -1054,12 +1103,13 @@ void msckf_destroy(msckf_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
                   &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dSweepNodes, &c->dSweepFolds, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
-                  &c->dFlush, &c->dFlushOff, &c->dFeatInfo};
+                  &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
@@ -1347,8 +1397,9 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     int status[4] = {0};
     std::vector<unsigned char> acc_sorted;
     if (int rc0 = gate_counts(c, counters, &acc_sorted, true)) return rc0;
-    const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
-    if (c->ran_gain && n_acc > 0) std::memcpy(status, c->hRes, 16);
+    if (c->ran_gain) std::memcpy(status, c->hRes, 16);
+    const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
+    if (!(c->ran_gain && n_acc > 0)) status[0] = status[1] = 0;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || (c->gain_blocked && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
     if (accepted && c->F > 0) {
@@ -1386,12 +1437,12 @@ int msckf_commit_covariance(msckf_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     int counters[4] = {0, 0, 0, 0};
     if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
-    const int n_acc = (c->acc_override >= 0) ? c->acc_override : counters[0];
-    if (n_acc == 0) return MSCKF_NOOP;
     // a non-positive Cholesky pivot leaves garbage in P_out: keep the prior (msckf_get_result reports the same code)
-    int status[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(status, c->dStatus.p, 8, hipMemcpyDeviceToHost, c->stream));
+    int status[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(status, c->dStatus.p, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
+    if (n_acc == 0) return MSCKF_NOOP;
     if (status[0] != 0 || (c->gain_blocked && status[1] != 0)) return MSCKF_ERR_NOT_SPD;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1805,7 +1856,20 @@ int msckf_export_groups(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_acce
     return MSCKF_OK;
 }
 
+namespace {
+int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int device_ptr, int32_t total_accepted, const uint8_t* flags);
+}
+
 int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int device_ptr, int32_t total_accepted) {
+    return run_merge_groups(c, records, n_rec, device_ptr, total_accepted, nullptr);
+}
+
+int msckf_run_merge_groups_flags(msckf_ctx* c, const void* records, int32_t n_rec, int device_ptr, const uint8_t* flags) {
+    return run_merge_groups(c, records, n_rec, device_ptr, -1, flags);
+}
+
+namespace {
+int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int device_ptr, int32_t total_accepted, const uint8_t* flags) {
     if (!c || !records || n_rec < 1) return MSCKF_ERR_ARG;
     if (!c->have_state) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1835,16 +1899,28 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
     else HIPCHK(c, hipMemcpyAsync(rb + o_rec, records, (size_t)n_rec * rec * 8, hipMemcpyHostToDevice, c->stream));
     const long long rec_base = (long long)(recs - rb);
     // which groups does each record carry?  (N flags and the accepted count at the head of every record)
-    std::vector<double> head((size_t)n_rec * (N + 1)), key((size_t)n_rec * N);
-    HIPCHK(c, hipMemcpy2DAsync(head.data(), (size_t)(N + 1) * 8, recs, rec * 8, (size_t)(N + 1) * 8, n_rec,
-                               hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    double acc_sum = 0.0;
-    for (int r = 0; r < n_rec; ++r) {
-        std::copy(head.begin() + (size_t)r * (N + 1), head.begin() + (size_t)r * (N + 1) + N, key.begin() + (size_t)r * N);
-        acc_sum += head[(size_t)r * (N + 1) + N];
+    std::vector<double> key((size_t)n_rec * N);
+    bool count_on_device = false;
+    if (flags) {
+        // the caller knows the groups of every shard (it partitioned the batch): nothing is read back; the accepted
+        // counts of the records are summed on the device into status word 2
+        for (size_t i = 0; i < key.size(); ++i) key[i] = flags[i] ? 1.0 : 0.0;
+        hipLaunchKernelGGL(k_sum_record_counts, dim3(1), dim3(64), 0, c->stream, recs, (long long)rec, N, n_rec, ptr<int>(c->dStatus) + 2);
+        HIPCHK(c, hipGetLastError());
+        count_on_device = true;
+        total_accepted = -1;
+    } else {
+        std::vector<double> head((size_t)n_rec * (N + 1));
+        HIPCHK(c, hipMemcpy2DAsync(head.data(), (size_t)(N + 1) * 8, recs, rec * 8, (size_t)(N + 1) * 8, n_rec,
+                                   hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        double acc_sum = 0.0;
+        for (int r = 0; r < n_rec; ++r) {
+            std::copy(head.begin() + (size_t)r * (N + 1), head.begin() + (size_t)r * (N + 1) + N, key.begin() + (size_t)r * N);
+            acc_sum += head[(size_t)r * (N + 1) + N];
+        }
+        if (total_accepted < 0) total_accepted = (int32_t)(acc_sum + 0.5);    // the counts the shards wrote into their records
     }
-    if (total_accepted < 0) total_accepted = (int32_t)(acc_sum + 0.5);    // the counts the shards wrote into their records
     const bool reuse = c->x_plan_valid && c->x_nrec == n_rec && c->x_root_off == o_root && c->x_rec_base == rec_base &&
                        c->x_key == key;
     if (!reuse) {
@@ -1903,7 +1979,7 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
         c->x_plan_valid = true;
     }
     if (c->x_snodes.empty()) {            // no shard has a track: nothing to update
-        c->ran = true; c->ran_gain = false; c->acc_override = 0;
+        c->ran = true; c->ran_gain = false; c->acc_override = 0; c->acc_from_dev = false;
         return MSCKF_OK;
     }
     SweepArgs a{};
@@ -1926,6 +2002,92 @@ int msckf_run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int
     if (rc != MSCKF_OK) return rc;
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
+    c->acc_from_dev = count_on_device;
+    return MSCKF_OK;
+}
+}  // namespace
+
+// ---- RCCL exchange ---------------------------------------------------------------------
+int msckf_comm_unique_id(void* id_out) {
+    if (!id_out) return MSCKF_ERR_ARG;
+    RcclApi& a = rccl();
+    if (!a.lib) return MSCKF_ERR_COMM;
+    static_assert(sizeof(ncclUniqueId) == MSCKF_COMM_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    if (a.GetUniqueId(&id) != ncclSuccess) return MSCKF_ERR_COMM;
+    std::memcpy(id_out, &id, sizeof(id));
+    return MSCKF_OK;
+}
+
+int msckf_comm_init(msckf_ctx* c, int32_t rank, int32_t world, const void* id) {
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return MSCKF_ERR_ARG;
+    if (c->comm) return MSCKF_ERR_STATE;
+    RcclApi& a = rccl();
+    if (!a.lib) { c->last_error = a.err; return MSCKF_ERR_COMM; }
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    NCCLCHK(c, a.CommInitRank(&c->comm, world, uid, rank));
+    c->comm_rank = rank; c->comm_world = world;
+    return MSCKF_OK;
+}
+
+int msckf_comm_destroy(msckf_ctx* c) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    return MSCKF_OK;
+}
+
+int msckf_comm_gather(msckf_ctx* c, const void* send, void* recv, size_t count, int32_t root) {
+    if (!c || !send || (c->comm_rank == root && !recv)) return MSCKF_ERR_ARG;
+    if (!c->comm) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    NCCLCHK(c, rccl().Gather(send, recv, count, ncclDouble, root, c->comm, c->stream));
+    return MSCKF_OK;
+}
+
+int msckf_comm_broadcast(msckf_ctx* c, void* buf, size_t count, int32_t root) {
+    if (!c || !buf) return MSCKF_ERR_ARG;
+    if (!c->comm) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    NCCLCHK(c, rccl().Broadcast(buf, buf, count, ncclDouble, root, c->comm, c->stream));
+    return MSCKF_OK;
+}
+
+int msckf_comm_allreduce(msckf_ctx* c, void* buf, size_t count, int32_t op) {
+    if (!c || !buf || (op != 0 && op != 1)) return MSCKF_ERR_ARG;
+    if (!c->comm) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    NCCLCHK(c, rccl().AllReduce(buf, buf, count, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
+    return MSCKF_OK;
+}
+
+void* msckf_comm_buffer(msckf_ctx* c, size_t bytes) {
+    if (!c) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (c->dCommBuf.bytes < bytes) (void)hipStreamSynchronize(c->stream);       // a collective may still use the old buffer
+    if (ensure(c, c->dCommBuf, bytes) != MSCKF_OK) return nullptr;
+    return c->dCommBuf.p;
+}
+
+int msckf_comm_put(msckf_ctx* c, void* dst_device, const void* src_host, size_t bytes) {
+    if (!c || !dst_device || !src_host) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MSCKF_OK;
+}
+
+int msckf_comm_get(msckf_ctx* c, void* dst_host, const void* src_device, size_t bytes) {
+    if (!c || !dst_host || !src_device) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSCKF_OK;
 }
 
@@ -2010,6 +2172,8 @@ uint64_t msckf_device_pointer(msckf_ctx* c, int which) {
         case 0: return (uint64_t)c->dDx.p;
         case 1: return (uint64_t)c->dPout.p;
         case 2: return (c->root >= 0) ? (uint64_t)root_block(c) : 0;
+        case 3: return c->xchg_planned ? (uint64_t)c->dRbuf.p : 0;
+        case 4: return (uint64_t)c->dP.p;
         default: return 0;
     }
 }
