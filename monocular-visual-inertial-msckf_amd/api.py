@@ -563,3 +563,68 @@ class UpdateEngine:
             inject_state(filt.state, res.dx)                                          # :616-661
         filt.remove_features({k: ft for j, (k, ft) in enumerate(items) if sel.flags[j] & _ffi.SEL_LOST})   # :456
         return res.status
+
+    def prune_poorest_camera_states(self, filt) -> int:
+        """Drop-in for `MSCKF.prune_poorest_camera_states()` (reference `MSCKF.py:710-737`): the two clones seen by
+        the fewest features, the features seen by them -> `get_valid_features` -> `update` -> `remove_cameras`,
+        composed on the resident engine: selection, update, commit and the removal of the clones' rows / columns
+        (`:751-757`) run back to back in HBM; the covariance crosses PCIe once in each direction.  The dictionary
+        bookkeeping of `remove_cameras` (`:759-777`) stays on the host.  Returns 0 updated / 1 no update."""
+        from .pack import problem_from_reference, select_params_from_reference, tracks_from_reference
+        from .inject import inject_state
+        cams = filt.state.cameras
+        count = {}
+        for ft in filt.features.values():                                             # :712-716
+            for ci in ft.camera_indices:
+                count[ci] = count.get(ci, 0) + 1
+        poorest = [k for k, _ in sorted(count.items(), key=lambda kv: kv[1])][:2]     # :718-724 (stable sort, dict order)
+        drop = {k: cams[k] for k in poorest}
+        todo = {i: ft for i, ft in filt.features.items() if any(ci in drop for ci in ft.camera_indices)}   # :726-731
+        keys = list(cams.keys())
+        slots = [keys.index(k) for k in drop]
+        status = 1
+        if len(todo) > 0:
+            prob = problem_from_reference(filt, todo)
+            self.load(prob)
+            self.set_tracks(tracks_from_reference(todo))
+            self.run_select(select_params_from_reference(filt), prob.K)
+            sel = self.selection()
+            items = list(todo.items())
+            for j, (_, ft) in enumerate(items):
+                if sel.flags[j] & _ffi.SEL_REFRESHED:                                 # :488
+                    ft.inverse_depth_point.m = sel.idp_m[j].copy()
+                    ft.inverse_depth_point.rho = float(sel.idp_rho[j])
+                    if hasattr(filt, "estimated_world_points"):
+                        filt.estimated_world_points.append(sel.world[j].copy())
+            if sel.valid.any():                                                       # :733-735
+                self.run()
+                d = 15 + 6 * self._N
+                dx = np.zeros(d)
+                acc = np.zeros(max(self._F, 1), dtype=np.uint8)
+                st = _ffi.Stats()
+                status = self._check(self._lib.msckf_get_result(self._h, _ffi.dptr(dx), None, _ffi.uptr(acc), C.byref(st)))
+                filt.number_of_residuals_discarded_for_gasting_test += int(st.n_rejected)     # :578
+                if status == 0:
+                    self.commit_covariance()                                          # :614, P+ stays in HBM
+                    inject_state(filt.state, dx)                                      # :616-661 (before the clones go)
+        else:
+            self.set_prior(filt.state.covariance, filt.state.imu.W_gravity, filt.K, filt.sigma_image,
+                           [c.T_W_Ci.R for c in cams.values()], [c.T_W_Ci.t for c in cams.values()])
+        self.remove_clones(slots)                                                     # :751-757 on the resident P
+        filt.state.covariance = self.covariance()
+        for k in drop:                                                                # :758-777
+            del cams[k]
+        gone = []
+        for i, ft in filt.features.items():
+            for k in drop:
+                if k in ft.camera_indices:
+                    v = ft.camera_indices.index(k)
+                    for name in ("keypoints", "descriptors", "scores", "camera_indices", "lines"):
+                        lst = getattr(ft, name, None)
+                        if lst is not None and len(lst) > v:
+                            del lst[v]
+            if len(ft.camera_indices) == 0:
+                gone.append(i)
+        for i in gone:
+            del filt.features[i]
+        return status

@@ -361,6 +361,136 @@ def run_reference_sequence(seed, frames=6, imu_per_frame=8, F=40, M=5, max_clone
     return arrays
 
 
+def coincident_clone_problem(seed):
+    """SURVEY.md section 7 hard part 4: rank(H_f) < 3.  Clones 0..3 share one position (pure rotation), so a track
+    seen only from them has H_f w = 0 for the common ray w: scipy's null_space returns 2M - 2 columns there
+    (`MSCKF.py:554-559`), dof = 2M - 2 at the gate (`:564`).  Tracks starting later are ordinary."""
+    rng = np.random.default_rng(seed)
+    N = 10
+    cam_R, cam_t = synth.clone_poses(N, rng)
+    cam_t[1:4] = cam_t[0]
+    prob = synth.make_problem(N, 70, 4, seed=seed, poses=(cam_R, cam_t), variable_tracks=True, min_track=2)
+    return prob
+
+
+def gate_threshold_problem(seed, rel=1e-4):
+    """SURVEY.md section 7 hard part 1: features whose gate statistic sits within `rel` of the critical value, one
+    on either side.  A pixel offset on one view of two features is tuned by bisection on the REFERENCE's own
+    gamma (`compute_residual_and_jacobians` + the expression of `gating_test`, `MSCKF.py:561-568`)."""
+    prob = synth.make_problem(12, 60, 6, seed=seed)
+
+    def gamma_of(j, s):
+        uv = prob.obs_uv.copy()
+        a = int(prob.view_ptr[j])
+        uv[a] = uv[a] + s * np.array([1.0, -0.6])
+        q = synth.UpdateProblem(**{**prob.__dict__, "obs_uv": uv})
+        f, feats, _ = build_filter(q)
+        ft = list(feats.values())[j]
+        r_o, H_o = f.compute_residual_and_jacobians(ft)
+        S = H_o @ f.state.covariance @ H_o.T + f.sigma_image ** 2 * np.eye(H_o.shape[0])
+        return float((r_o.T @ np.linalg.inv(S) @ r_o).flatten()[0]), float(chi2.ppf(0.95, r_o.shape[0]))
+
+    uv = prob.obs_uv.copy()
+    for j, side in ((7, -1.0), (23, +1.0)):
+        lo, hi = 0.0, 400.0
+        g_hi, crit = gamma_of(j, hi)
+        assert g_hi > crit
+        target = crit * (1.0 + side * rel)
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            g, _ = gamma_of(j, mid)
+            if g < target:
+                lo = mid
+            else:
+                hi = mid
+            if abs(g - target) < 0.02 * rel * crit:
+                break
+        a = int(prob.view_ptr[j])
+        uv[a] = uv[a] + mid * np.array([1.0, -0.6])
+    return synth.UpdateProblem(**{**prob.__dict__, "obs_uv": uv})
+
+
+def build_filter(prob, keys=None):
+    """The reference filter and its Feature dict for a flat problem (state as in run_reference, default IMU)."""
+    params = MSCKFParameters()
+    params.K = prob.K
+    params.sigma_image = prob.sigma
+    params.W_gravity = prob.gravity.copy()
+    f = MSCKF(params)
+    if keys is None:
+        keys = [10 * (i + 1) for i in range(prob.N)]
+    for i, k in enumerate(keys):
+        f.state.cameras[k] = Camera(prob.K, 640, 480, Isometry3D(prob.cam_R[i].copy(), prob.cam_t[i].copy()))
+    f.state.covariance = prob.P.copy()
+    feats = {}
+    for j in range(prob.F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        ft = Feature()
+        ft.keypoints = [prob.obs_uv[i].copy() for i in range(a, b)]
+        ft.camera_indices = [keys[int(prob.obs_slot[i])] for i in range(a, b)]
+        idp = InverseDepthPoint()
+        idp.base, idp.m, idp.rho = prob.idp_base[j].copy(), prob.idp_m[j].copy(), float(prob.idp_rho[j])
+        ft.inverse_depth_point = idp
+        feats[100 + j] = ft
+    return f, feats, keys
+
+
+def run_reference_prune(prob, tracks, sp):
+    """`MSCKF.prune_poorest_camera_states` (`MSCKF.py:710-737`): the two clones seen by the fewest features, the
+    features seen by them -> get_valid_features -> update -> remove_cameras.  Returns what it left behind."""
+    params = MSCKFParameters()
+    params.K = prob.K
+    params.sigma_image = prob.sigma
+    params.W_gravity = prob.gravity.copy()
+    params.width, params.height = sp.width, sp.height
+    params.use_parallax = sp.use_parallax
+    params.min_parallax = sp.min_parallax_deg
+    params.min_number_of_frames_to_be_lost = sp.min_frames_lost
+    params.min_number_of_frames_to_be_tracked = sp.min_frames_tracked
+    f = MSCKF(params)
+    keys = [10 * (i + 1) for i in range(prob.N)]
+    for i, k in enumerate(keys):
+        f.state.cameras[k] = Camera(prob.K, sp.width, sp.height, Isometry3D(prob.cam_R[i].copy(), prob.cam_t[i].copy()))
+    f.state.covariance = prob.P.copy()
+    feats = {}
+    for j in range(prob.F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        ft = Feature()
+        ft.keypoints = [prob.obs_uv[i].copy() for i in range(a, b)]
+        ft.camera_indices = [keys[int(prob.obs_slot[i])] for i in range(a, b)]
+        ft.lines = [Line(tracks.line_base[i].copy(), tracks.line_dir[i].copy(), float(tracks.line_conf[i])) for i in range(a, b)]
+        ft.descriptors = [None] * (b - a)
+        ft.scores = [0.0] * (b - a)
+        ft.lost_for_n_frames = int(tracks.lost_for[j])
+        ft.tracked_for_n_frames = int(tracks.tracked_for[j])
+        idp = InverseDepthPoint()
+        idp.base, idp.m, idp.rho = prob.idp_base[j].copy(), prob.idp_m[j].copy(), float(prob.idp_rho[j])
+        ft.inverse_depth_point = idp
+        feats[100 + j] = ft
+    f.features = feats
+    f.estimated_world_points = []
+    f.currently_processed_world_points = []
+    cap = {}
+    orig_correct = f.correct
+
+    def wrapped(Kg, T_H, R_n, delta_x):
+        cap["dx"] = np.array(delta_x).flatten()
+        return orig_correct(Kg, T_H, R_n, delta_x)
+
+    f.correct = wrapped
+    rej0 = f.number_of_residuals_discarded_for_gasting_test
+    f.prune_poorest_camera_states()
+    left = list(f.state.cameras.keys())
+    removed = [i for i, k in enumerate(keys) if k not in left]
+    views_left = np.array([len(feats[100 + j].camera_indices) if (100 + j) in f.features else 0 for j in range(prob.F)], dtype=np.int32)
+    return dict(prune_removed_slots=np.array(removed, dtype=np.int32), prune_P_after=f.state.covariance.copy(),
+                prune_dx=cap.get("dx", np.zeros(prob.d)), prune_status=np.int32(0 if "dx" in cap else 1),
+                prune_n_rejected=np.int32(f.number_of_residuals_discarded_for_gasting_test - rej0),
+                prune_post_cam_R=np.stack([f.state.cameras[k].T_W_Ci.R for k in left]),
+                prune_post_cam_t=np.stack([f.state.cameras[k].T_W_Ci.t for k in left]),
+                prune_views_left=views_left, prune_features_left=np.int32(len(f.features)))
+
+
 def save(name, prob, out):
     arrays = dict(
         P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
@@ -405,6 +535,8 @@ def main():
     cases["edge_sigma_01"] = lambda: (synth.make_problem(15, 150, 7, seed=11, sigma=0.1, outlier_fraction=0.1, outlier_px=300.0), None)
     cases["edge_single_feature"] = lambda: (synth.make_problem(6, 1, 4, seed=12), None)
     cases["edge_full_window_tracks"] = lambda: (synth.make_problem(8, 40, 8, seed=13), None)      # every track spans all clones
+    cases["edge_rank2_Hf"] = lambda: (coincident_clone_problem(14), None)                         # tracks with rank(H_f) = 2
+    cases["edge_gate_threshold"] = lambda: (gate_threshold_problem(15), None)                     # gamma within 1e-4 of crit, both sides
     if args.headline:
         cases["cfg3_A"] = lambda: (synth.make_problem(30, 2000, 10, seed=0), None)
 
@@ -452,6 +584,19 @@ def main():
         prob, tk, sp, keys = mk()
         tracks = synth.make_tracks(prob, **tk)
         save_select(name, prob, tracks, sp, run_reference_select(prob, tracks, sp, keys))
+
+    # prune_poorest_camera_states (MSCKF.py:710-737): select -> update -> remove_cameras back to back.  Stored like a
+    # sel_* case (the selection outputs are those of the features the prune hands to get_valid_features).
+    if not args.only or args.only == "sel_prune_poorest":
+        prob = synth.make_problem(10, 90, 6, seed=30, variable_tracks=True, min_track=2)
+        sp = SP(min_parallax_deg=3.0, min_frames_tracked=2)
+        tracks = synth.make_tracks(prob, seed=30, lost_fraction=0.7)
+        out = run_reference_prune(prob, tracks, sp)
+        sel = run_reference_select(prob, tracks, sp, None)        # (for the loader: the whole-dict selection + update)
+        sel.update(out)
+        save_select("sel_prune_poorest", prob, tracks, sp, sel)
+        print("    prune removed slots", out["prune_removed_slots"], "status", int(out["prune_status"]),
+              "features left", int(out["prune_features_left"]))
 
     if not args.only:
         table = np.array([0.0] + [chi2.ppf(0.95, k) for k in range(1, 513)])

@@ -18,36 +18,40 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-8
 
 
-def test_rccl_collectives_through_the_abi():
-    from msckf_amd.api import UpdateEngine
-    with UpdateEngine(max_clones=4, max_features=8, max_track=4) as e:
-        uid = e.comm_unique_id()
-        assert len(uid) == 128 and any(uid)
-        e.comm_init(0, 1, uid)
-        buf = e.comm_buffer(3 * 1000)
-        x = np.arange(1000, dtype=np.float64) * 0.5 - 7.0
-        e.comm_put(buf, x)
-        e.comm_gather(buf, buf + 8 * 1000, 1000, 0)              # world 1: the root receives its own block
-        e.sync()
-        assert np.array_equal(e.comm_get(buf + 8 * 1000, 1000), x)
-        e.comm_allreduce(buf, 1000, "sum")
-        e.comm_allreduce(buf, 1000, "max")
-        e.comm_broadcast(buf, 1000, 0)
-        e.sync()
-        assert np.array_equal(e.comm_get(buf, 1000), x)
-        e.comm_destroy()
-        e.comm_destroy()                                          # idempotent
+_RCCL_CODE = r"""
+import os, sys, tempfile
+sys.path.insert(0, %(root)r)
+import numpy as np
+import msckf_amd
+from msckf_amd import synth
+from msckf_amd.api import UpdateEngine
+from msckf_amd.shard import RcclShardedUpdate, exchange_unique_id
+from oracle import msckf_oracle as oracle
+assert "torch" not in sys.modules                 # the product exchange runs without PyTorch
 
+# every collective of the C-ABI on a one-rank communicator
+with UpdateEngine(max_clones=4, max_features=8, max_track=4) as e:
+    uid = e.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    e.comm_init(0, 1, uid)
+    buf = e.comm_buffer(3 * 1000)
+    x = np.arange(1000, dtype=np.float64) * 0.5 - 7.0
+    e.comm_put(buf, x)
+    e.comm_gather(buf, buf + 8 * 1000, 1000, 0)              # world 1: the root receives its own block
+    e.sync()
+    assert np.array_equal(e.comm_get(buf + 8 * 1000, 1000), x)
+    e.comm_allreduce(buf, 1000, "sum")
+    e.comm_allreduce(buf, 1000, "max")
+    e.comm_broadcast(buf, 1000, 0)
+    e.sync()
+    assert np.array_equal(e.comm_get(buf, 1000), x)
+    e.comm_destroy()
+    e.comm_destroy()                                          # idempotent
+print("RCCL_ABI_OK", flush=True)
 
-@pytest.mark.parametrize("N,F,M,groups", [(30, 2000, 10, True), (16, 120, 14, False)])
-def test_rccl_sharded_step_world1(N, F, M, groups):
-    """RcclShardedUpdate (the driver bench.py --gpus N runs): compress -> RCCL gather -> merge + gain ->
-    RCCL broadcast, all on the engine's stream; group records where the batch runs the 60-column band pipeline,
-    root blocks otherwise."""
-    from msckf_amd import synth
-    from msckf_amd.api import UpdateEngine
-    from msckf_amd.shard import RcclShardedUpdate, exchange_unique_id
-    from oracle import msckf_oracle as oracle
+# RcclShardedUpdate (the driver bench.py --gpus N runs): compress -> RCCL gather -> merge + gain -> RCCL broadcast, all on
+# the engine's stream; group records where the batch runs the 60-column band pipeline, root blocks otherwise
+for (N, F, M, groups) in [(30, 2000, 10, True), (16, 120, 14, False)]:
     prob = synth.make_problem(N, F, M, seed=81)
     ref = oracle.update(prob, dense_noise=False)
     with tempfile.TemporaryDirectory() as td, UpdateEngine(max_clones=N, max_features=F, max_track=M) as e:
@@ -59,11 +63,22 @@ def test_rccl_sharded_step_world1(N, F, M, groups):
         for _ in range(3):                                        # steps chain on the stream, no sync in between
             drv.step()
         status, dx, P = drv.result()
-        assert status == 0
-        assert rel_err(dx, ref["dx"]) < TOL and rel_err(P, ref["P_new"]) < TOL
+        e_dx = np.linalg.norm(dx - ref["dx"]) / np.linalg.norm(ref["dx"])
+        e_P = np.linalg.norm(P - ref["P_new"]) / np.linalg.norm(ref["P_new"])
+        assert status == 0 and e_dx < 1e-8 and e_P < 1e-8, (status, e_dx, e_P)
         dx2, P2 = e.result_host()                                 # what a non-root rank reads after the broadcast
         assert np.array_equal(dx2, dx) and np.array_equal(P2, P)
         drv.close()
+    print("RCCL_STEP_OK", N, F, M, flush=True)
+"""
+
+
+def test_rccl_exchange_through_the_abi():
+    """In a fresh interpreter (this pytest process may have imported PyTorch, whose bundled HIP / RCCL runtimes do
+    not mix with the system ones inside one process; the product path never imports it)."""
+    r = subprocess.run([sys.executable, "-c", _RCCL_CODE % {"root": ROOT}], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert "RCCL_ABI_OK" in out and out.count("RCCL_STEP_OK") == 2, out[-3000:]
 
 
 _WORKER = r"""

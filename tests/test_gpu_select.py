@@ -193,3 +193,48 @@ def test_process_features_on_reference_shaped_objects(eng):
     assert len(filt.estimated_world_points) == int(((ref["sel_flags"] & 4) > 0).sum())
     rho = np.array([ft.inverse_depth_point.rho for ft in feats.values()])
     np.testing.assert_allclose(rho, ref["sel_idp_rho"], rtol=1e-8)
+
+
+def test_prune_poorest_camera_states_composed_on_the_device(eng):
+    """`UpdateEngine.prune_poorest_camera_states(filt)` against the reference's own run of
+    `MSCKF.prune_poorest_camera_states` (MSCKF.py:710-737; fixture sel_prune_poorest): same clones removed, same
+    covariance after update + removal, same poses of the remaining clones, same feature bookkeeping."""
+    prob, tracks, params, ref = load_golden_select("sel_prune_poorest")
+    keys = [10 * (i + 1) for i in range(prob.N)]
+    cams = OrderedDict()
+    for i, k in enumerate(keys):
+        pose = SimpleNamespace(R=prob.cam_R[i].copy(), t=prob.cam_t[i].copy())
+        cams[k] = SimpleNamespace(T_W_Ci=pose, T_W_Ci_null=pose, width=params.width, height=params.height)
+    imu = SimpleNamespace(W_gravity=prob.gravity.copy(), T_W_Ii=SimpleNamespace(R=np.eye(3), t=np.zeros(3)),
+                          v_W_Ii=np.zeros(3), gyroscope_bias=np.zeros(3), accelerometer_bias=np.zeros(3))
+    feats = OrderedDict()
+    for j in range(prob.F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        feats[100 + j] = SimpleNamespace(
+            keypoints=[prob.obs_uv[i].copy() for i in range(a, b)],
+            camera_indices=[keys[int(prob.obs_slot[i])] for i in range(a, b)],
+            descriptors=[None] * (b - a), scores=[0.0] * (b - a),
+            lines=[SimpleNamespace(base=tracks.line_base[i], direction=tracks.line_dir[i], confidence=tracks.line_conf[i])
+                   for i in range(a, b)],
+            lost_for_n_frames=int(tracks.lost_for[j]), tracked_for_n_frames=int(tracks.tracked_for[j]),
+            inverse_depth_point=SimpleNamespace(base=prob.idp_base[j].copy(), m=prob.idp_m[j].copy(),
+                                                rho=float(prob.idp_rho[j])))
+    filt = SimpleNamespace(
+        state=SimpleNamespace(cameras=cams, covariance=prob.P.copy(), imu=imu), K=prob.K, sigma_image=prob.sigma,
+        features=feats, number_of_residuals_discarded_for_gasting_test=0, estimated_world_points=[],
+        min_number_of_frames_to_be_lost=params.min_frames_lost, min_number_of_frames_to_be_tracked=max(params.min_frames_tracked, 2),
+        use_parallax=params.use_parallax, min_parallax=params.min_parallax_deg)
+    status = eng.prune_poorest_camera_states(filt)
+    assert status == int(ref["prune_status"])
+    left = list(filt.state.cameras.keys())
+    assert [i for i, k in enumerate(keys) if k not in left] == list(ref["prune_removed_slots"])
+    assert filt.state.covariance.shape == ref["prune_P_after"].shape
+    assert rel_err(filt.state.covariance, ref["prune_P_after"]) < TOL
+    for i, k in enumerate(left):
+        np.testing.assert_allclose(filt.state.cameras[k].T_W_Ci.R, ref["prune_post_cam_R"][i], atol=1e-9)
+        np.testing.assert_allclose(filt.state.cameras[k].T_W_Ci.t, ref["prune_post_cam_t"][i], atol=1e-9)
+    assert filt.number_of_residuals_discarded_for_gasting_test == int(ref["prune_n_rejected"])
+    assert len(filt.features) == int(ref["prune_features_left"])
+    views = np.array([len(feats[100 + j].camera_indices) if (100 + j) in filt.features else 0 for j in range(prob.F)])
+    assert np.array_equal(views, ref["prune_views_left"])
+    assert eng.n_clones == prob.N - 2                        # the engine's resident state lost the two clones as well

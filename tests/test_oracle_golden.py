@@ -127,3 +127,31 @@ def test_oracle_sequence_matches_reference(case):
             n_clones -= len(op["slots"])
         assert P.shape == op["P_after"].shape == (15 + 6 * n_clones,) * 2
         assert rel_err(P, op["P_after"]) < 1e-9, (op["kind"], rel_err(P, op["P_after"]))
+
+
+def test_oracle_prune_poorest_composition():
+    """`MSCKF.prune_poorest_camera_states` (MSCKF.py:710-737) restated with the oracle's pieces -- feature counts per
+    clone, the two poorest, their features -> select -> update -> remove_cameras -- against the reference's own
+    run (fixture sel_prune_poorest)."""
+    from msckf_amd import synth
+    prob, tracks, params, ref = load_golden_select("sel_prune_poorest")
+    count = {}
+    for s in prob.obs_slot:                                   # dict insertion order = first appearance (:712-716)
+        count[int(s)] = count.get(int(s), 0) + 1
+    poorest = [k for k, _ in sorted(count.items(), key=lambda kv: kv[1])][:2]
+    assert sorted(poorest) == sorted(ref["prune_removed_slots"])
+    vp = prob.view_ptr
+    todo = [j for j in range(prob.F) if any(int(s) in poorest for s in prob.obs_slot[vp[j]:vp[j + 1]])]
+    sub = prob.take(todo)
+    rows = np.concatenate([np.arange(vp[j], vp[j + 1]) for j in todo])
+    tsub = synth.TrackTable(line_base=tracks.line_base[rows], line_dir=tracks.line_dir[rows], line_conf=tracks.line_conf[rows],
+                            lost_for=tracks.lost_for[todo], tracked_for=tracks.tracked_for[todo])
+    sel = oracle.select_features(sub, tsub, params)
+    valid = np.nonzero(sel["flags"] & 1)[0]
+    upd = sub.take(valid)
+    upd.idp_m, upd.idp_rho = sel["idp_m"][valid], sel["idp_rho"][valid]
+    out = oracle.update(upd, dense_noise=True)
+    assert out["status"] == int(ref["prune_status"])
+    assert rel_err(out["dx"], ref["prune_dx"]) < 1e-9
+    P_after = oracle.remove_clones_covariance(out["P_new"], sorted(poorest))
+    assert rel_err(P_after, ref["prune_P_after"]) < 1e-11
