@@ -199,6 +199,25 @@ int msckf_clear_selection(msckf_ctx* ctx);
  * feature was not triangulated; the reference's estimated_world_points, MSCKF.py:489). */
 int msckf_get_selection(msckf_ctx* ctx, uint8_t* flags, double* idp_m, double* idp_rho, double* world);
 
+/* ---- f4: geometric consistency tests of the front end's matches ----------------- *
+ * Replaces the per-(match, earlier view) loop of MSCKF.add_camera_measurements (MSCKF.py:332-412): the
+ * epipolar test against every earlier view of the matched feature, or the homography test where the two
+ * clones are closer than 1 cm.  Candidates are the batch of msckf_set_features (the tracks as they stand
+ * BEFORE the new view); matched_uv[2 F] is the keypoint of the newest image matched to each of them (NaN for
+ * a feature without a match), R_cur / t_cur the pose T_W_C of the newest clone, K the intrinsics.
+ * result[F]: 0 the match is kept (the caller appends the view, :415-421), 1 it failed the epipolar test
+ * (number_of_features_discarded_for_epipolar_test, :396), 2 the homography test
+ * (number_of_features_discarder_for_homography_test, :378), 3 no match; fail_view[F] (nullable) the index of
+ * the view that failed it, -1 otherwise.  Input order.  Blocking. */
+typedef struct msckf_assoc_params {
+    double K[9];                    /* Camera intrinsics, row-major                                   */
+    double R_cur[9], t_cur[3];      /* T_W_Ci of state.cameras[state.imu.id]          (MSCKF.py:288-289) */
+    double epipolar_threshold;      /* MSCKFParameters.epipolar_rejection_threshold   (:41)              */
+    double homography_threshold;    /* MSCKFParameters.homography_rejection_threshold (:42)              */
+} msckf_assoc_params;
+int msckf_run_associate(msckf_ctx* ctx, const msckf_assoc_params* params, const double* matched_uv,
+                        uint8_t* result, int32_t* fail_view);
+
 /* ---- f2 / f3: the covariance steps either side of the update --------------- *
  * With these the covariance never leaves HBM between frames: msckf_set_state once
  * (N = 0 is allowed: the 15x15 IMU prior), then per IMU sample msckf_propagate, per

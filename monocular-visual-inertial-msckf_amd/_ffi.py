@@ -27,7 +27,7 @@ SYMBOLS = [
     "msckf_export_groups", "msckf_run_merge_groups", "msckf_run_merge_groups_flags", "msckf_export_result", "msckf_import_covariance", "msckf_debug_gate", "msckf_debug_compressed", "msckf_debug_fold_stamps",
     "msckf_device_pointer", "msckf_stream",
     "msckf_set_tracks", "msckf_run_select", "msckf_clear_selection", "msckf_get_selection",
-    "msckf_debug_time_select", "msckf_replan",
+    "msckf_debug_time_select", "msckf_replan", "msckf_run_associate",
     "msckf_propagate", "msckf_augment", "msckf_remove_clones", "msckf_set_poses", "msckf_get_covariance",
     "msckf_comm_unique_id", "msckf_comm_init", "msckf_comm_destroy", "msckf_comm_gather", "msckf_comm_broadcast",
     "msckf_comm_allreduce", "msckf_comm_buffer", "msckf_comm_put", "msckf_comm_get",
@@ -49,6 +49,11 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if not k.startswith("reserved")}
+
+
+class AssocParamsC(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("R_cur", C.c_double * 9), ("t_cur", C.c_double * 3),
+                ("epipolar_threshold", C.c_double), ("homography_threshold", C.c_double)]
 
 
 class SelectParamsC(C.Structure):
@@ -161,6 +166,8 @@ def load():
     lib.msckf_clear_selection.restype = C.c_int
     lib.msckf_get_selection.argtypes = [vp, _up, _dp, _dp, _dp]
     lib.msckf_get_selection.restype = C.c_int
+    lib.msckf_run_associate.argtypes = [vp, C.POINTER(AssocParamsC), _dp, _up, _ip]
+    lib.msckf_run_associate.restype = C.c_int
     lib.msckf_propagate.argtypes = [vp, _dp, _dp]
     lib.msckf_propagate.restype = C.c_int
     lib.msckf_augment.argtypes = [vp, _dp, _dp, _dp]

@@ -261,6 +261,27 @@ class UpdateEngine:
         self.run_select(params, prob.K)
         return self.selection()
 
+    # -- f4: geometric consistency tests of the front end's matches ------------------
+    def associate(self, matched_uv, R_cur, t_cur, K, epipolar_threshold: float = 5.0, homography_threshold: float = 5.0):
+        """The per-(match, earlier view) tests of `add_camera_measurements` (reference `MSCKF.py:332-412`) for the
+        loaded batch (the tracks BEFORE the new view) against one matched keypoint each (`matched_uv` (F, 2) pixels,
+        NaN rows = no match).  Returns (result (F,) uint8: 0 kept, 1 epipolar failure, 2 homography failure,
+        3 no match; fail_view (F,) int32)."""
+        F = self._F
+        ap = _ffi.AssocParamsC()
+        ap.K = (C.c_double * 9)(*np.asarray(K, dtype=np.float64).reshape(9))
+        ap.R_cur = (C.c_double * 9)(*np.asarray(R_cur, dtype=np.float64).reshape(9))
+        ap.t_cur = (C.c_double * 3)(*np.asarray(t_cur, dtype=np.float64).reshape(3))
+        ap.epipolar_threshold, ap.homography_threshold = float(epipolar_threshold), float(homography_threshold)
+        uv = _ffi.f64(matched_uv).reshape(-1)
+        if uv.size != 2 * F:
+            raise ValueError("matched_uv must be (F, 2)")
+        res = np.zeros(max(F, 1), dtype=np.uint8)
+        fv = np.zeros(max(F, 1), dtype=np.int32)
+        self._check(self._lib.msckf_run_associate(self._h, C.byref(ap), _ffi.dptr(uv), _ffi.uptr(res), _ffi.iptr(fv)),
+                    allow_noop=False)
+        return res[:F].copy(), fv[:F].copy()
+
     # -- f2 / f3: covariance resident in HBM between frames ---------------------
     def set_prior(self, P, gravity, K, sigma, cam_R=None, cam_t=None, cam_R0=None, cam_t0=None):
         """Upload the filter state once; N = 0 (the 15x15 IMU prior, no clone yet) is allowed."""

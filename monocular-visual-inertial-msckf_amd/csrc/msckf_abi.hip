@@ -23,6 +23,7 @@
 #include "k_wsweep.h"
 #include "k_lsweep.h"
 #include "k_state.h"
+#include "k_assoc.h"
 
 using namespace msckf;
 
@@ -132,6 +133,7 @@ struct msckf_ctx {
     int sweep_mode = 0;                   // 0 k_sweep (60-column tiles, whole band R in LDS), 1 k_wsweep<4> (ring), 2 k_wsweep<6> (90-column tiles, ring)
     std::vector<int> h_flush, h_flush_off;            // k_wsweep: per sweep node the rows final at the head of every macro step
     Buf dFlush, dFlushOff;
+    Buf dAssocUV, dAssocRes;              // f4 (k_assoc)
     Buf dFeatInfo;                        // k_lsweep: per sorted feature the block offset and the window-slot -> view map
     // plan cache: the K5 plan is a function of (N, exchange mode, the sorted tracks' first slot / last slot / view count);
     // a batch with the same key reuses the plan, its device tables and the zero pattern of the R workspace
@@ -1109,7 +1111,7 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dSweepNodes, &c->dSweepFolds, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
-                  &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf};
+                  &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf, &c->dAssocUV, &c->dAssocRes};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
@@ -1620,6 +1622,54 @@ int msckf_get_selection(msckf_ctx* c, uint8_t* flags, double* idp_m, double* idp
         if (idp_rho) idp_rho[f] = hr[s];
         if (idp_m) std::memcpy(&idp_m[(size_t)f * 3], &hm[(size_t)s * 3], 24);
         if (world) std::memcpy(&world[(size_t)f * 3], &hw[(size_t)s * 3], 24);
+    }
+    return MSCKF_OK;
+}
+
+// ---- f4: geometric consistency tests of the matches --------------------------------
+int msckf_run_associate(msckf_ctx* c, const msckf_assoc_params* ap, const double* matched_uv, uint8_t* result,
+                        int32_t* fail_view) {
+    if (!c || !ap) return MSCKF_ERR_ARG;
+    if (!c->have_state || !c->have_features) return MSCKF_ERR_STATE;
+    const int F = c->F;
+    if (F == 0) return MSCKF_OK;
+    if (!matched_uv || !result) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    // inverse of K as the reference forms it for these tests (np.linalg.inv(self.K), MSCKF.py:345)
+    const double* K = ap->K;
+    const double det = K[0] * (K[4] * K[8] - K[5] * K[7]) - K[1] * (K[3] * K[8] - K[5] * K[6]) + K[2] * (K[3] * K[7] - K[4] * K[6]);
+    if (det == 0.0) return MSCKF_ERR_ARG;
+    AssocArgs a{};
+    a.F = F;
+    a.view_ptr = ptr<int>(c->dViewPtr); a.obs_uv = ptr<double>(c->dObsUV); a.obs_slot = ptr<int>(c->dObsSlot);
+    a.cam_R = ptr<double>(c->dCamR); a.cam_t = ptr<double>(c->dCamT);
+    std::memcpy(a.K, K, 72);
+    const double id = 1.0 / det;
+    a.Kinv[0] = (K[4] * K[8] - K[5] * K[7]) * id; a.Kinv[1] = (K[2] * K[7] - K[1] * K[8]) * id; a.Kinv[2] = (K[1] * K[5] - K[2] * K[4]) * id;
+    a.Kinv[3] = (K[5] * K[6] - K[3] * K[8]) * id; a.Kinv[4] = (K[0] * K[8] - K[2] * K[6]) * id; a.Kinv[5] = (K[2] * K[3] - K[0] * K[5]) * id;
+    a.Kinv[6] = (K[3] * K[7] - K[4] * K[6]) * id; a.Kinv[7] = (K[1] * K[6] - K[0] * K[7]) * id; a.Kinv[8] = (K[0] * K[4] - K[1] * K[3]) * id;
+    std::memcpy(a.R2, ap->R_cur, 72); std::memcpy(a.t2, ap->t_cur, 24);
+    a.thr_epipolar = ap->epipolar_threshold; a.thr_homography = ap->homography_threshold;
+    // matched keypoints in sorted feature order; results come back through the same permutation
+    std::vector<double> muv((size_t)F * 2);
+    for (int s = 0; s < F; ++s) { muv[2 * s] = matched_uv[2 * c->perm[s]]; muv[2 * s + 1] = matched_uv[2 * c->perm[s] + 1]; }
+    int rc = MSCKF_OK;
+    auto E = [&](Buf& b, size_t bytes) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes); };
+    E(c->dAssocUV, (size_t)F * 16); E(c->dAssocRes, (size_t)F * 8);
+    if (rc != MSCKF_OK) return rc;
+    a.matched_uv = ptr<double>(c->dAssocUV);
+    a.fail_view = ptr<int>(c->dAssocRes);
+    a.result = ptr<unsigned char>(c->dAssocRes) + (size_t)F * 4;
+    HIPCHK(c, hipMemcpyAsync(c->dAssocUV.p, muv.data(), (size_t)F * 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_assoc, dim3((F + 255) / 256), dim3(256), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    std::vector<unsigned char> back((size_t)F * 5);
+    HIPCHK(c, hipMemcpyAsync(back.data(), c->dAssocRes.p, (size_t)F * 5, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int* fv = reinterpret_cast<const int*>(back.data());
+    for (int s = 0; s < F; ++s) {
+        result[c->perm[s]] = back[(size_t)F * 4 + s];
+        if (fail_view) fail_view[c->perm[s]] = fv[s];
     }
     return MSCKF_OK;
 }

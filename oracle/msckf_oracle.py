@@ -222,6 +222,48 @@ def select_features(prob, tracks, params):
     return dict(flags=flags, idp_m=idp_m, idp_rho=idp_rho, world=world, cond=cond)
 
 
+# ---- f4: the geometric consistency tests of add_camera_measurements ----------------------------
+def associate(prob, matched_uv, R_cur, t_cur, K, thr_epipolar=5.0, thr_homography=5.0):
+    """The per-(match, earlier view) loop of `MSCKF.add_camera_measurements` (`MSCKF.py:345-412`) on the flat
+    arrays: result 0 kept / 1 epipolar failure (:392-397) / 2 homography failure (:368-379) / 3 no match, and
+    the index of the view that failed (-1)."""
+    K = np.asarray(K, dtype=np.float64)
+    invK = np.linalg.inv(K)                                      # :345
+    F = prob.F
+    res = np.zeros(F, dtype=np.uint8)
+    fail = -np.ones(F, dtype=np.int32)
+    T2 = np.eye(4); T2[:3, :3], T2[:3, 3] = R_cur, t_cur
+    for i in range(F):
+        mk = np.asarray(matched_uv[i], dtype=np.float64)
+        if np.isnan(mk).any():
+            res[i] = 3
+            continue
+        a, b = int(prob.view_ptr[i]), int(prob.view_ptr[i + 1])
+        for j in range(a, b):                                    # :361
+            fk = prob.obs_uv[j]
+            s = int(prob.obs_slot[j])
+            T1 = np.eye(4); T1[:3, :3], T1[:3, 3] = prob.cam_R[s], prob.cam_t[s]
+            T12 = np.linalg.inv(T1) @ T2                         # :366
+            R12, t12 = T12[:3, :3], T12[:3, 3]
+            if np.linalg.norm(t12) < 0.01:                       # :368
+                H = K @ R12 @ invK
+                x1 = np.linalg.inv(H) @ np.array([mk[0], mk[1], 1.0])
+                x1 = x1[:2] / x1[2]
+                x2 = H @ np.array([fk[0], fk[1], 1.0])
+                x2 = x2[:2] / x2[2]
+                score = (np.linalg.norm(mk - x1) + np.linalg.norm(fk - x2)) / 2      # :374
+                if score > thr_homography:
+                    res[i], fail[i] = 2, j - a
+                    break
+            else:
+                Fm = invK.T @ skew(t12) @ R12 @ invK             # :392
+                score = np.append(mk, 1.0) @ Fm @ np.append(fk, 1.0)                  # :393 (signed)
+                if score > thr_epipolar:
+                    res[i], fail[i] = 1, j - a
+                    break
+    return res, fail
+
+
 # ---- f2 / f3: the covariance steps either side of update -------------------------------------
 def imu_transition(R, t, v, R0, t0, v0, gyro, acc, dt, gravity, w_planet, Qc):
     """Phi (15x15) and the discrete noise Q of `MSCKF.process_imu` (`MSCKF.py:179-237`).

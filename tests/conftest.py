@@ -22,7 +22,7 @@ def _fixture_names():
 
 def golden_cases():
     """Fixtures of the update path (MSCKF.update)."""
-    return [n for n in _fixture_names() if not n.startswith(("sel_", "seq_"))]
+    return [n for n in _fixture_names() if not n.startswith(("sel_", "seq_", "assoc_"))]
 
 
 def select_cases():

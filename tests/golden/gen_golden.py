@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 for name in ["cv2", "rerun", "IPython", "IPython.display", "modules", "modules.xfeat"]:
     sys.modules[name] = types.ModuleType(name)
 sys.modules["cv2"].Mat = object
+sys.modules["cv2"].addWeighted = lambda a, wa, b, wb, g: a      # debug overlay of add_camera_measurements (MSCKF.py:336), not arithmetic
 sys.modules["IPython.display"].display = lambda *a, **k: None
 sys.modules["IPython.display"].clear_output = lambda *a, **k: None
 
@@ -491,6 +492,75 @@ def run_reference_prune(prob, tracks, sp):
                 prune_views_left=views_left, prune_features_left=np.int32(len(f.features)))
 
 
+def run_reference_associate(seed):
+    """f4: the reference's own `add_camera_measurements` (`MSCKF.py:268-448`) on prepared matches.  The tracks live
+    in clones 0..N-2, the newest clone N-1 is `state.cameras[state.imu.id]`; the descriptor matcher (XFeat, absent
+    here) is replaced by a function that returns the prepared (feature, keypoint) pairs, everything else -- the
+    per-view epipolar / homography tests, the counters, the appended views -- is the reference's code."""
+    from src.msckf.FeatureExtractor import CameraMeasurement, ExtractedFeature
+    rng = np.random.default_rng(seed)
+    N = 9
+    cam_R, cam_t = synth.clone_poses(N, rng)
+    cam_t[N - 1] = cam_t[3] + 1e-3 * rng.standard_normal(3)            # the newest clone sits 1 mm from clone 3: homography test there
+    prob = synth.make_problem(N - 1, 160, 6, seed=seed, poses=(cam_R[:N - 1], cam_t[:N - 1]), variable_tracks=True, min_track=1)
+    params = MSCKFParameters()
+    params.K = prob.K
+    # thresholds in the units of the reference's scores (normalised epipolar form, pixels for the homography)
+    params.epipolar_rejection_threshold = 2e-4
+    params.homography_rejection_threshold = 1.5
+    f = MSCKF(params)
+    keys = [10 * (i + 1) for i in range(N)]
+    for i, k in enumerate(keys):
+        f.state.cameras[k] = Camera(prob.K, 640, 480, Isometry3D(cam_R[i].copy(), cam_t[i].copy()))
+    f.state.imu.id = keys[-1]
+    feats = {}
+    matched_uv = np.full((prob.F, 2), np.nan)
+    Kf = np.asarray(prob.K, dtype=np.float64)
+    for j in range(prob.F):
+        a, b = int(prob.view_ptr[j]), int(prob.view_ptr[j + 1])
+        ft = Feature()
+        ft.keypoints = [prob.obs_uv[i].copy() for i in range(a, b)]
+        ft.camera_indices = [keys[int(prob.obs_slot[i])] for i in range(a, b)]
+        ft.descriptors = [rng.standard_normal(4) for _ in range(a, b)]
+        ft.scores = [1.0] * (b - a)
+        ft.lines = [Line(cam_t[int(prob.obs_slot[i])], np.array([0.0, 0.0, 1.0]), 1.0) for i in range(a, b)]
+        ft.tracked_for_n_frames = b - a
+        feats[100 + j] = ft
+        if rng.uniform() < 0.85:                                       # 15 % of the features find no match in the new image
+            pw = prob.idp_base[j] + prob.idp_m[j] / prob.idp_rho[j]    # a 3-D point consistent with the track (up to its noise)
+            q = cam_R[N - 1].T @ (pw - cam_t[N - 1])
+            px = Kf @ q
+            px = px[:2] / px[2]
+            px = px + 0.3 * rng.standard_normal(2)
+            if rng.uniform() < 0.3:
+                px = px + rng.uniform(-40, 40, 2)                      # wrong matches
+            matched_uv[j] = px
+    f.features = feats
+    ids = [100 + j for j in range(prob.F) if not np.isnan(matched_uv[j, 0])]
+    lost_ids = [100 + j for j in range(prob.F) if np.isnan(matched_uv[j, 0])]
+
+    def match(last, cur, min_cos):
+        m = CameraMeasurement(keypoints=[matched_uv[i - 100].copy() for i in ids], descriptors=[rng.standard_normal(4) for _ in ids],
+                              scores=[1.0] * len(ids), features_indices=list(ids))
+        nm = CameraMeasurement(keypoints=[], descriptors=[], scores=[], features_indices=list(lost_ids))
+        return m, nm, None
+
+    f.feature_extractor = types.SimpleNamespace(match=match)
+    f.last_camera_measurement = CameraMeasurement()
+    f.current_image = np.zeros((4, 4, 3), dtype=np.uint8)
+    n_views0 = np.array([len(feats[100 + j].keypoints) for j in range(prob.F)])
+    kp = [matched_uv[i - 100].copy() for i in ids]
+    f.add_camera_measurements(np.zeros((4, 4, 3), dtype=np.uint8),
+                              ExtractedFeature(keypoints=kp, descriptors=[rng.standard_normal(4) for _ in ids], scores=[1.0] * len(ids)))
+    kept = np.array([len(feats[100 + j].keypoints) - n_views0[j] for j in range(prob.F)], dtype=np.uint8)
+    out = dict(assoc_matched_uv=matched_uv, assoc_R_cur=cam_R[N - 1], assoc_t_cur=cam_t[N - 1],
+               assoc_thr=np.array([params.epipolar_rejection_threshold, params.homography_rejection_threshold]),
+               assoc_kept=kept, assoc_n_epipolar=np.int32(f.number_of_features_discarded_for_epipolar_test),
+               assoc_n_homography=np.int32(f.number_of_features_discarder_for_homography_test),
+               assoc_lost_for=np.array([feats[100 + j].lost_for_n_frames for j in range(prob.F)], dtype=np.int32))
+    return prob, out
+
+
 def save(name, prob, out):
     arrays = dict(
         P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0,
@@ -597,6 +667,20 @@ def main():
         save_select("sel_prune_poorest", prob, tracks, sp, sel)
         print("    prune removed slots", out["prune_removed_slots"], "status", int(out["prune_status"]),
               "features left", int(out["prune_features_left"]))
+
+    # f4: the per-view consistency tests of add_camera_measurements (MSCKF.py:332-412)
+    if not args.only or args.only == "assoc_tests":
+        prob, out = run_reference_associate(40)
+        arrays = dict(P=prob.P, cam_R=prob.cam_R, cam_t=prob.cam_t, cam_R0=prob.cam_R0, cam_t0=prob.cam_t0, gravity=prob.gravity,
+                      K=prob.K, sigma=np.float64(prob.sigma), view_ptr=prob.view_ptr, obs_uv=prob.obs_uv, obs_slot=prob.obs_slot,
+                      idp_base=prob.idp_base, idp_m=prob.idp_m, idp_rho=prob.idp_rho,
+                      versions=np.array([np.__version__, scipy.__version__, sys.version.split()[0]]))
+        arrays.update(out)
+        path = os.path.join(HERE, "assoc_tests.npz")
+        np.savez_compressed(path, **arrays)
+        k = out["assoc_kept"]
+        print(f"{'assoc_tests':28s} N={prob.N:3d} F={prob.F:5d} matched={int((~np.isnan(out['assoc_matched_uv'][:, 0])).sum())} kept={int(k.sum())} "
+              f"epipolar={int(out['assoc_n_epipolar'])} homography={int(out['assoc_n_homography'])} size={os.path.getsize(path) / 1024:.0f} KiB")
 
     if not args.only:
         table = np.array([0.0] + [chi2.ppf(0.95, k) for k in range(1, 513)])

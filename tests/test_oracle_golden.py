@@ -155,3 +155,18 @@ def test_oracle_prune_poorest_composition():
     assert rel_err(out["dx"], ref["prune_dx"]) < 1e-9
     P_after = oracle.remove_clones_covariance(out["P_new"], sorted(poorest))
     assert rel_err(P_after, ref["prune_P_after"]) < 1e-11
+
+
+def test_oracle_association_tests_match_reference():
+    """f4: `oracle.associate` against the reference's own `add_camera_measurements` loop (MSCKF.py:332-412; fixture
+    assoc_tests): which matches were appended, how many failed each test."""
+    from conftest import load_golden
+    prob, z = load_golden("assoc_tests")
+    res, fail = oracle.associate(prob, z["assoc_matched_uv"], z["assoc_R_cur"], z["assoc_t_cur"], prob.K,
+                                 float(z["assoc_thr"][0]), float(z["assoc_thr"][1]))
+    assert np.array_equal((res == 0).astype(np.uint8), z["assoc_kept"])
+    assert int((res == 1).sum()) == int(z["assoc_n_epipolar"]) and int((res == 2).sum()) == int(z["assoc_n_homography"])
+    assert np.array_equal(res == 3, np.isnan(z["assoc_matched_uv"][:, 0]))
+    # lost_for_n_frames: +1 for a failed test (:411) and +1 for a feature without a match (:437)
+    assert np.array_equal(z["assoc_lost_for"], ((res == 1) | (res == 2) | (res == 3)).astype(np.int32))
+    assert ((fail >= 0) == ((res == 1) | (res == 2))).all()
