@@ -76,7 +76,7 @@ constexpr double SWEEP_TINY = 1e-290;  // |column|^2 under this is treated as an
 constexpr int SWEEP_VB = 72;           // per-wavefront published column: [rq][16] rows + |column|^2 at [64]
 
 __host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nf, int wpf) {
-    return ((size_t)wtot * SWEEP_RS + (size_t)nf * SWEEP_VB + (size_t)nf * wpf * 64 + 2) * 8;   // R | published columns | dumps | zero
+    return ((size_t)wtot * SWEEP_RS + (size_t)nf * SWEEP_VB + (size_t)nf * wpf * 64 + 2 + (size_t)nf) * 8;   // R | published columns | dumps | zero | progress
 }
 
 // Sum over the 4 lanes of a DPP quad; every lane of the quad gets the sum.
@@ -123,7 +123,14 @@ template <int KK> struct STag { static constexpr int value = KK; };
 // NF concurrent folds, WPF wavefronts per fold (only 1 is enabled: splitting a fold's columns over two wavefronts
 // -- 16 per workgroup, half the FMAs each -- measured the same 0.83 us per step: the step is a dependent chain
 // barrier -> LDS -> reflector scalars / dots -> tau -> update -> column norm -> LDS, not an issue-rate limit).
-template <int NF, int WPF>
+// P2P: no workgroup barrier per macro step.  A fold's step for R row c only needs every EARLIER fold to be past
+// row c; consecutive folds of the root are 7 rows apart, so there are 6 steps of slack between them.  Every fold
+// slot publishes (fold index, rows done) in one LDS word after each step; before a step a wavefront makes sure
+// the (up to NF - 1) folds in front of it have started and are past its row (a cached bound, re-read only when it
+// is reached).  Heavy and light chunks then average out instead of every step costing the slowest wavefront's
+// (the barrier wait was 660 of 1830 cycles per step).  Nodes whose folds share one first column (lag 1, no
+// slack) keep the barrier form.
+template <int NF, int WPF, bool P2P = false>
 __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     static_assert(WPF == 1, "with two wavefronts per fold the pivot R(c,c) is rewritten by one while the other may still read it");
     constexpr int NW = NF * WPF;        // wavefronts
@@ -145,6 +152,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     if (p.stamps) tk0 = wall_clock64();
 
     for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
+    if (t < NF) reinterpret_cast<long long*>(smem + (size_t)nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + 2)[t] = -1LL << 32;   // fold index -1
     if (t < 2) smem[nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + t] = 0.0;
     // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
     const SweepFold f0 = p.folds[nd.fold_begin];
@@ -224,6 +232,63 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     const int dump_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + wv * 64 + lane;
     const int zero_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64;
     const int lco = cq + CL * rq;
+    // ---- P2P progress words: [slot] = (fold index << 32) | rows done (first row not yet done by that fold) --------
+    volatile long long* prog = reinterpret_cast<volatile long long*>(smem + (size_t)nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + 2);
+    const int fbeg = nd.fold_begin + ((nd.fold_end > nd.fold_begin && f0.t0 == 0) ? 1 : 0);   // first fold that runs steps
+    int cur_fi = 0;                      // fold this wavefront is running
+    int safe_row = 0;                    // rows < safe_row are clear of every earlier fold (as of the last look)
+    auto publish_prog = [&](int done) {
+        if constexpr (P2P) {
+            // rows < the published bound are clear of THIS fold and (transitively, through its own cached bound) of every
+            // earlier one, so a follower normally looks at one word only.  LDS operations of a wavefront execute in
+            // issue order: the word lands behind this step's R entries.
+            asm volatile("" ::: "memory");
+            const int bound = (done == 0x7fffffff) ? done : min(done, safe_row);
+            if (lane == 0) prog[fs] = ((long long)cur_fi << 32) | (unsigned int)bound;
+        }
+    };
+    auto peek_prev = [&]() -> long long {        // the word of the fold right in front (issued early, used after the dots)
+        if constexpr (P2P) {
+            const int pf = cur_fi - 1;
+            return (pf >= fbeg) ? prog[(pf - fbeg) % NF] : (((long long)0x7fffffff) << 32);
+        }
+        return 0;
+    };
+    auto wait_row = [&](int c, long long w) {    // every earlier fold has left row c behind
+        if constexpr (P2P) {
+            int spins = 0;
+            while (c >= safe_row) {
+                const int pf = cur_fi - 1;
+                int safe;
+                const int idx1 = (int)(w >> 32), done1 = (int)(w & 0xffffffffLL);
+                if (pf < fbeg) {
+                    safe = 0x7fffffff;
+                } else if (idx1 == pf) {
+                    safe = done1;                                          // running: its bound is transitive
+                } else {
+                    // the fold in front has finished (or its slot has not started it yet): look at all of them
+                    safe = 0x7fffffff;
+#pragma unroll
+                    for (int j = 1; j < NF; ++j) {
+                        const int qf = cur_fi - j;
+                        if (qf >= fbeg) {
+                            const long long wj = prog[(qf - fbeg) % NF];
+                            const int idx = (int)(wj >> 32), done = (int)(wj & 0xffffffffLL);
+                            const int lim = (idx > qf) ? 0x7fffffff : (idx == qf ? done : 0);   // finished / running / not started
+                            safe = min(safe, lim);
+                        }
+                    }
+                }
+                safe_row = __builtin_amdgcn_readfirstlane(safe);
+                if (c >= safe_row) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1 << 22)) break;                        // (bounded: never hang the GPU)
+                    w = peek_prev();
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+    };
     auto init_addr = [&]() {
         const bool isr = (rq == CS - 1) && (cq == CL - 1);
         const bool valid = isr || lco < f_ew;
@@ -244,8 +309,14 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
 #pragma unroll
             for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
         }
-        const double x0 = smem[rrow];
-        const double rck = smem[ra];                       // R(c, off + lco)
+        long long wprev = 0;
+        double x0 = 0.0, rck = 0.0;
+        if constexpr (P2P) {
+            wprev = peek_prev();                           // looked at behind the dots, which need no R
+        } else {
+            x0 = smem[rrow];
+            rck = smem[ra];                                // R(c, off + lco)
+        }
         const bool on = (lco > i) || (rq == CS - 1 && cq == CL - 1);   // left of / at the pivot: retired (the rhs never is)
         // ---- dots (one partial sum per live slot), reduce-scattered over the quad ---------------------
         double sp[CS];
@@ -270,6 +341,11 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
                 tot = pB + quad_move<0x4E>(pB);           // slots 0, 1 are retired: lanes 0, 1 hold a copy nobody uses
                 (void)b1;
             }
+        }
+        if constexpr (P2P) {
+            wait_row(f_off + i, wprev);                    // the earlier folds are past this row of R
+            x0 = smem[rrow];
+            rck = smem[ra];
         }
         // |column i|^2 = the pivot column's dot with itself: the lanes that published v hold a[.][K0] == v
         const double sg = readlane_d(tot, 4 * (i - CL * K0) + K0);
@@ -341,7 +417,11 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the tick sees the LDS writes out
 #endif
             SWEEP_TICK(4);                                 // updates, R writes, publish issued
-            __syncthreads();
+            if constexpr (P2P) {
+                publish_prog(i + 1 < f_ew ? f_off + i + 1 : 0x7fffffff);
+            } else {
+                __syncthreads();
+            }
             SWEEP_TICK(5);                                 // barrier wait
             ++tcur;
         }
@@ -356,15 +436,23 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     }
     while (have) {
         f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
-        while (tcur < f_t0 - 1) { __syncthreads(); ++tcur; }
+        if constexpr (P2P) {
+            cur_fi = fi;
+            safe_row = 0;
+            publish_prog(f_off);                           // started: nothing done yet
+        } else {
+            while (tcur < f_t0 - 1) { __syncthreads(); ++tcur; }
+        }
         init_addr();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
         if (cq == 0) publish(STag<0>{}, STag<1>{});
-        __syncthreads();                                   // column 0 is visible to the fold's other wavefront
-        ++tcur;                                            // (the host schedules t0 >= 1 and one spare step per slot reuse)
+        if constexpr (!P2P) {
+            __syncthreads();                               // column 0 is visible to the fold's other wavefront
+            ++tcur;                                        // (the host schedules t0 >= 1 and one spare step per slot reuse)
+        }
         fi += NF;
         const bool have_next = fi < fold_end;
         if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
@@ -378,7 +466,9 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         chunk(STag<7>{}, have_next);
         have = have_next;
     }
-    while (tcur < nsteps) { __syncthreads(); ++tcur; }
+    if constexpr (!P2P) {
+        while (tcur < nsteps) { __syncthreads(); ++tcur; }
+    }
 
     // ---- flush R: row-major wtot x (wtot+1), entries at and right of the diagonal ----
     __syncthreads();
