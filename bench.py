@@ -210,12 +210,12 @@ def main():
                                         "host_sort_plan": head["host_prep_us"], "h2d": head["h2d_us"], "d2h": head["d2h_us"]},
     }
     line["roofline"] = {
-        "kernel": "K5 QR compression: k_fold leaves + k_sweep group merges and root sweep (%d launches per update)" % n_lv,
+        "kernel": "K5 QR compression: k_lsweep leaves + k_sweep group merges and root sweep (%d launches per update)" % n_lv,
         "bound": "fp64_valu", "unit": "TFLOP/s",
         "achieved": costs["flops_B"] / (us_qr * 1e-6) / 1e12,
         "peak": FP64_PEAK_TFLOPS,
         "frac": costs["flops_B"] / (us_qr * 1e-6) / 1e12 / FP64_PEAK_TFLOPS,
-        "traffic": pmc_traffic(("k_fold<", "k_sweep<", "k_wsweep<")),
+        "traffic": pmc_traffic(("k_lsweep<", "k_sweep<", "k_wsweep<")),
         "flops_per_launch": costs["flops_B"] / n_lv,
         "avg_launch_us": us_qr / n_lv,
         "flops_model": "canonical dense Householder QR of the m x 6N stack (SURVEY 8d: 2 m dc^2 - 2/3 dc^3 + 4 m dc), NOT the "
