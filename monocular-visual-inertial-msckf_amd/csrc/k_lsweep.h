@@ -57,7 +57,7 @@ __host__ __device__ inline size_t lsweep_lds_bytes(int nf) {
            (size_t)nf * G::RB * (4 + 4 + 16);
 }
 
-template <int NF, int CS, int RSLOTS>
+template <int NF, int CS, int RSLOTS, bool PREF_ = (CS == 4)>
 __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
     using G = LSweepGeom<CS, RSLOTS>;
     constexpr int W = G::W, RB = G::RB, VB = G::VB;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
     // PREF: a wavefront gathers its next block into a second register tile during the last chunk of the current
     // one.  The 90-column tile has no room for that: there the rounds are aligned (every wavefront finishes its
     // block, 7 idle steps), then all gather at the same time straight into the tile -- one load latency per round.
-    constexpr bool PREF = (CS == 4);
+    constexpr bool PREF = PREF_;
     constexpr int RGAP = PREF ? 1 : NF;             // macro steps between two rounds of a fold slot beyond the w of the fold itself
     constexpr int KGMIN = 1;                        // first chunk whose instance may hold the gathered next block beside the tile
     static_assert(CS >= 4 && CS <= 6, "column slots 4..6");
@@ -267,20 +267,12 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
         if constexpr (K0 <= 3) sg = readlane_d(tot1, 4 * (i - CL * K0) + K0);
         else sg = readlane_d(tot2, 4 * (i - CL * K0) + (K0 - 4));
         const bool live = sg > SWEEP_TINY;
-        double alpha = x0, beta = 0.0;
-        if (live) {
-            const double ss = fma(x0, x0, sg);
-            double nrm;
-            if (ss > 1e-200 && ss < 1e200) {
-                const double y = fast_rsqrt(ss);
-                nrm = ss * y;
-                beta = y * fast_rcp(nrm + fabs(x0));
-            } else {
-                nrm = sqrt(ss);
-                beta = 1.0 / (nrm * (nrm + fabs(x0)));
-            }
-            alpha = (x0 > 0.0) ? -nrm : nrm;
-        }
+        // branch-free (k_sweep.h): sg > 1e-290 keeps ss normal; nothing to eliminate -> beta = 0, alpha = x0
+        const double ss = live ? fma(x0, x0, sg) : 1.0;
+        const double y = fast_rsqrt(ss);
+        const double nrm = ss * y;
+        const double beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;
+        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
         const double v0 = x0 - alpha;
         const double tau1 = (on1 ? beta : 0.0) * fma(v0, rck1, tot1);
         smem[on1 ? wa1 : dump_i] = fma(-tau1, v0, rck1);

@@ -351,20 +351,15 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         const double sg = readlane_d(tot, 4 * (i - CL * K0) + K0);
         const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
         // ---- reflector scalars (every lane, uniform values) ---------------------------
-        double alpha = x0, beta = 0.0;
-        if (live) {
-            const double ss = fma(x0, x0, sg);
-            double nrm;
-            if (ss > 1e-200 && ss < 1e200) {
-                const double y = fast_rsqrt(ss);
-                nrm = ss * y;                             // a few 1e-16 relative: the reflector stays orthogonal to that level
-                beta = y * fast_rcp(nrm + fabs(x0));      // 1 / (nrm (nrm + |x0|))
-            } else {
-                nrm = sqrt(ss);
-                beta = 1.0 / (nrm * (nrm + fabs(x0)));
-            }
-            alpha = (x0 > 0.0) ? -nrm : nrm;
-        }
+        // Branch-free: sg > 1e-290 keeps ss = x0^2 + sg a normal number whose rsqrt / rcp seeds + one Newton step
+        // are good to a few 1e-16 (the reflector stays orthogonal to that level); a column with nothing to
+        // eliminate gets beta = 0, alpha = x0 (identity).  |x0| > 1e150 does not occur (R entries are bounded by
+        // the column norms of a normalised-coordinate Jacobian stack).
+        const double ss = live ? fma(x0, x0, sg) : 1.0;
+        const double y = fast_rsqrt(ss);
+        const double nrm = ss * y;
+        const double beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;      // 1 / (nrm (nrm + |x0|))
+        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
         const double v0 = x0 - alpha;
         // ---- tau of this lane's column, its R entry, then the rank-1 update of every slot ----------
         const double tau_own = (on ? beta : 0.0) * fma(v0, rck, tot);

@@ -254,20 +254,12 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
         else sg = readlane_d(tot2, 4 * (i - CL * K0) + (K0 - 4));
         const bool live = sg > SWEEP_TINY;
         // ---- reflector scalars (every lane, uniform values) ---------------------------
-        double alpha = x0, beta = 0.0;
-        if (live) {
-            const double ss = fma(x0, x0, sg);
-            double nrm;
-            if (ss > 1e-200 && ss < 1e200) {
-                const double y = fast_rsqrt(ss);
-                nrm = ss * y;
-                beta = y * fast_rcp(nrm + fabs(x0));
-            } else {
-                nrm = sqrt(ss);
-                beta = 1.0 / (nrm * (nrm + fabs(x0)));
-            }
-            alpha = (x0 > 0.0) ? -nrm : nrm;
-        }
+        // branch-free (k_sweep.h): sg > 1e-290 keeps ss normal; nothing to eliminate -> beta = 0, alpha = x0
+        const double ss = live ? fma(x0, x0, sg) : 1.0;
+        const double y = fast_rsqrt(ss);
+        const double nrm = ss * y;
+        const double beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;
+        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
         const double v0 = x0 - alpha;
         // ---- tau of this lane's column(s), its R entries, then the rank-1 update of every slot ----------
         const double tau1 = (on1 ? beta : 0.0) * fma(v0, rck1, tot1);

@@ -65,6 +65,7 @@ constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgrou
 #ifndef MSCKF_SWEEP_WPF
 #define MSCKF_SWEEP_WPF 1
 #endif
+constexpr int LS_BIG_BATCH = 4000;               // from this many features on the 60-column leaves run twelve row blocks at a time
 #ifndef MSCKF_SWEEP_P2P
 #define MSCKF_SWEEP_P2P 0      // measured: root 159 us with progress words vs 148 us with the barrier per macro step (headline)
 #endif
@@ -146,6 +147,7 @@ struct msckf_ctx {
     bool plan_xchg = false;
     std::vector<int> plan_fmin, plan_fmax, plan_view;
     long long stack_elems = 0;            // scalars of the current batch's stack blocks (a zero word follows them)
+    int leaf_nf = 8;                      // row blocks in flight per 60-column leaf workgroup (8 or 12)
     bool leaf_narrow = false, leaf_wide = false;      // band plan: leaf nodes with w + 1 <= 64 / > 64 exist
     size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
     size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
@@ -445,7 +447,8 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         const bool wide_leaf = 6 * max_span + 1 > 64;
         const int rb = wide_leaf ? LSweepGeom<6, LS_RS6>::RB : LSweepGeom<4, LS_RS4>::RB;
         const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
-        const int unit = SWEEP_NW * fpb;
+        c->leaf_nf = (!wide_leaf && F >= LS_BIG_BATCH) ? 12 : 8;
+        const int unit = c->leaf_nf * fpb;
         int want = (F + 239) / 240;
         want = ((want + unit - 1) / unit) * unit;
         leaf_feats = std::max(std::min(unit, 128), std::min(want, 128));
@@ -658,8 +661,13 @@ int launch_leaves_band(msckf_ctx* c) {
     const dim3 grid(c->n_leaves), block(64 * SWEEP_NW);
     if (c->leaf_narrow) {
         a.wide = 0;
-        const size_t lds = lsweep_lds_bytes<4, LS_RS4>(SWEEP_NW);
-        hipLaunchKernelGGL((k_lsweep<SWEEP_NW, 4, LS_RS4>), grid, block, lds, c->stream, a);
+        if (c->leaf_nf == 12) {          // large batches: twelve row blocks in flight (three wavefronts per SIMD), aligned rounds
+            const size_t lds = lsweep_lds_bytes<4, LS_RS4>(12);
+            hipLaunchKernelGGL((k_lsweep<12, 4, LS_RS4, false>), grid, dim3(64 * 12), lds, c->stream, a);
+        } else {                         // eight, the next block prefetched into registers
+            const size_t lds = lsweep_lds_bytes<4, LS_RS4>(8);
+            hipLaunchKernelGGL((k_lsweep<8, 4, LS_RS4, true>), grid, dim3(64 * 8), lds, c->stream, a);
+        }
     }
     if (c->leaf_wide) {
         a.wide = 1;
@@ -1058,7 +1066,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF, true>), FOLD_LDS_BYTES, "k_sweep (p2p) LDS attribute");
-    lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 4, LS_RS4>), FOLD_LDS_BYTES, "k_lsweep<4> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 4, LS_RS4, false>), FOLD_LDS_BYTES, "k_lsweep<12,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 6, LS_RS6>), FOLD_LDS_BYTES, "k_lsweep<6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 4>), FOLD_LDS_BYTES, "k_wsweep<4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 6>), FOLD_LDS_BYTES, "k_wsweep<6> LDS attribute");
