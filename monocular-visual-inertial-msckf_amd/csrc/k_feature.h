@@ -51,30 +51,36 @@ struct FeatureArgs {
     long long* stamps;           // optional diagnostics (8 per feature), may be null
 };
 
-// LDS doubles needed for a track of M views.
-__host__ __device__ inline int feature_lds_doubles(int M) {
+// The 6M columns of a track's clone block are worked on in chunks of whole views, at most 64 columns each (one
+// lane per column): views per chunk / chunks for a track of M views.
+__host__ __device__ inline int feature_chunk_views(int M) {
+    const int nch = (6 * M + 63) / 64;
+    return (M + nch - 1) / nch;
+}
+// LDS doubles needed for a track of M views.  Two layouts (k_feature<RMAX>):
+//   all columns at once (launches whose tracks have at most 11 views): slots, D rows, V, Z, Z P_sub, E (R2 x (6M+1)), S;
+//   column chunks (longer tracks): slots, D rows, V, Z, one chunk of E / H_o (+ the rhs column), r_o -- S lives in registers.
+__host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
     const int R2 = 2 * M, C6 = 6 * M;
-    const int ldE = C6 + 1, ldS = R2 + 2;
-    return R2 * 6 + R2 * 3 + 3 * C6 + 3 * C6 + R2 * ldE + (R2 + 1) * ldS + M /*slots as doubles*/ + 8;
+    const int head = (M + 2) / 2 + R2 * 6 + R2 * 3 + 3 * C6;
+    if (!chunked) return head + 3 * C6 + R2 * (C6 + 1) + (R2 + 1) * (R2 + 2) + 8;
+    return head + R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2) + 8;
 }
 
 // RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
 template <int RMAX>
-__global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
+__global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs p) {      // (tracks of 12-15 views: 3 wavefronts per SIMD, the LDS footprint allows 9 per CU)
+    constexpr bool CHUNKED = RMAX > 24;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
     const int v0 = p.view_ptr[f];
     const int M = p.view_ptr[f + 1] - v0;
     const int R2 = 2 * M, C6 = 6 * M;
-    const int ldE = C6 + 1, ldS = R2 + 2;
-    double* sA = smem;                     // [R2][6]   OC-projected clone block rows (D)
+    int* sSlot = reinterpret_cast<int*>(smem);                  // [M] clone slot of every view
+    double* sA = smem + (M + 2) / 2;       // [R2][6]   OC-projected clone block rows (D)
     double* sV = sA + R2 * 6;              // [R2][3]   Householder vectors
     double* sZ = sV + R2 * 3;              // [3][C6]
-    double* sZP = sZ + 3 * C6;             // [3][C6]   Z * P_sub
-    double* sE = sZP + 3 * C6;             // [R2][ldE] H_o * P_sub
-    double* sS = sE + R2 * ldE;            // [R2+1][ldS]
-    int* sSlot = reinterpret_cast<int*>(sS + (R2 + 1) * ldS);   // [M]
 
     if (p.select && !(p.select[f] & 1)) {      // not in valid_features (MSCKF.py:453-455): no rows, not a rejection
         if (lane == 0) { p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3; }
@@ -230,10 +236,17 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
     __syncthreads();
 
     if (p.stamps) tq[2] = wall_clock64();
+    const int q = R2 - rank;
+    double srow[RMAX];
+    if constexpr (!CHUNKED) {
+    // (tracks of up to 11 views: all 6M columns at once, S staged in LDS -- the faster form while it fits)
+    const int ldE = C6 + 1, ldS = R2 + 2;
+    double* sZP = sZ + 3 * C6;             // [3][C6]   Z * P_sub
+    double* sE = sZP + 3 * C6;             // [R2][ldE] H_o * P_sub
+    double* sS = sE + R2 * ldE;            // [R2+1][ldS]
     // ---------------- K4: write the compact block [H_o | r_o] ----------------
     // The rows are staged in sE (free until the gate's first pass) and leave as ONE contiguous range: the q
     // projected rows, row-major with 6M + 1 columns, every lane storing consecutive scalars.
-    const int q = R2 - rank;
     {
         if (lane < R2) {
             const double av[6] = {a0, a1, a2, a3, a4, a5};
@@ -326,12 +339,137 @@ __global__ __launch_bounds__(64) void k_feature(FeatureArgs p) {
     if (lane == 0) sS[R2 * ldS + R2] = 0.0;
     __syncthreads();
     if (p.stamps) tq[5] = wall_clock64();
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) srow[j] = (j <= R2 && lane <= R2) ? sS[lane * ldS + j] : 0.0;
+    } else {
+    const int CV = feature_chunk_views(M);   // views per column chunk
+    const int ldE = 6 * CV + 1;
+    double* sE = sZ + 3 * C6;              // [R2][ldE] one column chunk of H_o (K4 staging) / of E = H_o P_sub (gate)
+    double* sRo = sE + R2 * ldE;           // [R2]      r_o
+    // ---------------- K4 + K3, one column chunk (whole views, <= 64 columns) at a time -------------------
+    // K4: the chunk's columns of H_o = D - V Z (and r_o with the last chunk) are staged in sE and leave as
+    //     contiguous row segments of the stack block (row-major q x (6M+1), the q projected rows only).
+    // K3: E = H_o P_sub for the chunk's columns (one lane per column; each P entry is read once per feature),
+    //     then every lane (= row L of S) adds the chunk's part of S[L][:] = E[L,:] H_o^T to its REGISTER row:
+    //     S never exists in LDS and sE holds one chunk only (17 KB per wavefront at 15 views instead of 36).
+    const int ldb = C6 + 1;
+    if (lane < R2) sRo[lane] = ro;
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) srow[j] = 0.0;
+    double ez0 = 0.0, ez1 = 0.0, ez2 = 0.0;            // E[L,:] Z^T, over all chunks
+    for (int vc0 = 0; vc0 < M; vc0 += CV) {
+        const int nv = min(CV, M - vc0);                // views of this chunk
+        const int c0 = 6 * vc0, cw = 6 * nv;
+        const bool last = vc0 + nv >= M;
+        const int cwp = cw + (last ? 1 : 0);            // + the rhs column
+        // ---- K4 ----
+        if (lane < R2) {
+            const double av[6] = {a0, a1, a2, a3, a4, a5};
+            double* erow = sE + lane * ldE;
+            for (int vw = vc0; vw < vc0 + nv; ++vw) {
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int c = 6 * vw + a;
+                    double x = -(vv0 * sZ[c] + vv1 * sZ[C6 + c] + vv2 * sZ[2 * C6 + c]);
+                    if (vw == view) x += av[a];
+                    erow[c - c0] = x;
+                }
+            }
+            if (last) erow[cw] = ro;
+        }
+        __syncthreads();
+        {
+            const int nel = q * cwp;
+            const float inv_cwp = 1.0f / (float)cwp;
+            for (int e = lane; e < nel; e += 64) {
+                const int L = (int)(((float)e + 0.5f) * inv_cwp), cc = e - L * cwp;      // e / cwp, exact for e < 2^20
+                const double x = sE[(rank + L) * ldE + cc];
+                const long long dst = p.blk_off[f] + (long long)L * ldb + c0 + cc;
+                if (p.stack_f32) static_cast<float*>(p.stack)[dst] = (float)x;
+                else static_cast<double*>(p.stack)[dst] = x;
+            }
+        }
+        __syncthreads();                                 // sE is rewritten by the gate's first pass
+        // ---- K3 pass 1, lanes over the chunk's columns c of P_sub: E = D P_sub (block rows) - V (Z P_sub) ----
+        if (lane < cw) {
+            const int c = c0 + lane;
+            const int colg = 15 + 6 * sSlot[c / 6] + (c % 6);
+            double zp0 = 0, zp1 = 0, zp2 = 0;
+            double pv[6], pn[6];
+            {
+                const double* prow = p.P + (size_t)(15 + 6 * sSlot[0]) * p.ldp + colg;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pv[a] = prow[(size_t)a * p.ldp];
+            }
+            for (int vw = 0; vw < M; ++vw) {
+                // prefetch the next 6 rows of this P_sub column while the current ones are consumed
+                if (vw + 1 < M) {
+                    const double* prow = p.P + (size_t)(15 + 6 * sSlot[vw + 1]) * p.ldp + colg;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) pn[a] = prow[(size_t)a * p.ldp];
+                }
+                double e0 = 0, e1 = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const int cc = 6 * vw + a;
+                    zp0 += sZ[cc] * pv[a];
+                    zp1 += sZ[C6 + cc] * pv[a];
+                    zp2 += sZ[2 * C6 + cc] * pv[a];
+                    e0 += sA[(2 * vw) * 6 + a] * pv[a];
+                    e1 += sA[(2 * vw + 1) * 6 + a] * pv[a];
+                }
+                sE[(2 * vw) * ldE + lane] = e0;
+                sE[(2 * vw + 1) * ldE + lane] = e1;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pv[a] = pn[a];
+            }
+            // E -= V ZP  (same column, all rows)
+            for (int L = 0; L < R2; ++L) {
+                sE[L * ldE + lane] -= sV[L * 3 + 0] * zp0 + sV[L * 3 + 1] * zp1 + sV[L * 3 + 2] * zp2;
+            }
+        }
+        __syncthreads();
+        // ---- K3 pass 2, lanes over rows L: this chunk's part of S[L][L2] = E[L,:] H_o[L2,:]^T ----
+        if (lane < R2) {
+            const double* erow = sE + lane * ldE;
+            for (int cc = 0; cc < cw; ++cc) {
+                const double e = erow[cc];
+                ez0 += e * sZ[c0 + cc]; ez1 += e * sZ[C6 + c0 + cc]; ez2 += e * sZ[2 * C6 + c0 + cc];
+            }
+#pragma unroll
+            for (int j = 0; j < RMAX - 1; ++j) {
+                const int vw = j >> 1;
+                if (j < R2 && vw >= vc0 && vw < vc0 + nv) {       // the D part of H_o row j lies in this chunk
+                    double sacc = srow[j];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) sacc += erow[6 * (vw - vc0) + a] * sA[j * 6 + a];
+                    srow[j] = sacc;
+                }
+            }
+        }
+        __syncthreads();                                 // the next chunk restages sE
+    }
+    if (p.stamps) tq[3] = tq[4] = tq[5] = wall_clock64();
+    // S row of this lane: the -V Z part, sigma^2 on the diagonal, the rhs column r_o; lane R2 holds the extra row r_o^T
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+        double x = 0.0;
+        if (lane < R2) {
+            if (j < R2) {
+                x = srow[j] - (ez0 * sV[j * 3 + 0] + ez1 * sV[j * 3 + 1] + ez2 * sV[j * 3 + 2]);
+                if (j == lane) x += p.sigma2;
+            } else if (j == R2) {
+                x = ro;
+            }
+        } else if (lane == R2) {
+            if (j < R2) x = sRo[j];
+        }
+        srow[j] = x;
+    }
+    }
     // elimination over rows/cols rank..R2-1 with one matrix row per lane in REGISTERS (pivot row
     // entries travel by v_readlane, no LDS round trip per step); the extra row R2 ends with
     // -gamma in the corner
-    double srow[RMAX];
-#pragma unroll
-    for (int j = 0; j < RMAX; ++j) srow[j] = (j <= R2 && lane <= R2) ? sS[lane * ldS + j] : 0.0;
     int bad = 0;
 #pragma unroll
     for (int k = 0; k < RMAX - 1; ++k) {
