@@ -166,6 +166,7 @@ struct CholArgs {
     int use_lds;
     double* work;                 // n*(n+1)/2 doubles when !use_lds
     int* status;                  // [0] set to 1 when a pivot is not positive
+    long long* stamps;            // debug builds (CHOL16_STAMPS) only: s_memtime stamps per step and wavefront
 };
 
 template <int T>
@@ -599,6 +600,283 @@ __global__ __launch_bounds__(256) void k_matvec(const double* K, int ldk, int n,
 __global__ void k_symmetrize(const double* Pn, double* Pout, int d, int ld) {
     const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
     if (i < d && j < d) Pout[(size_t)i * ld + j] = 0.5 * (Pn[(size_t)i * ld + j] + Pn[(size_t)j * ld + i]);
+}
+
+}  // namespace msckf
+
+namespace msckf {
+
+// ---------------------------------------------------------------------------------------------------
+// Cholesky S = L L^T for n <= 16 * CHOL16_MAX_NB on 16 x 16 blocks held as FP64 matrix-core accumulators
+// (v_mfma_f64_16x16x4_f64: lane (g, c) = (lane >> 4, lane & 15) holds rows {g + 4 i}, i < 4, of column c).
+// One workgroup of CHOL16_W = 12 wavefronts.  A wavefront owns at most ONE diagonal block (a dedicated register
+// block: no selection on the critical path) and up to CHOL16_NS off-diagonal blocks, which are enumerated block
+// column by block column from the LAST column backwards (live blocks pack into the lowest register slots) and
+// dealt round-robin; a block column has at most 11 panel blocks, so every wavefront has at most one of them and
+// the table CHOL16_DIAG_OWNER picks, per column, a wavefront that has none for the diagonal block.
+// Step k:
+//   D  the owner of block (k, k) eliminates it in-wave, one pivot at a time, in the square-root-free form
+//      a_rc -= a_rp a_cp / a_pp: the pivot comes by v_readlane, its reciprocal (rcp seed + one Newton step) is the
+//      only thing on the dependent chain -- column p travels along the 16-lane rows by DPP row broadcast and to
+//      the other row groups through LDS while the reciprocal is being formed.  Column p and 1 / a_pp are
+//      published in LDS and a progress word counts the pivots.  The 16 square roots are ONE v_rsq_f64 at the
+//      end (lane c scales column c);
+//   P  the owners of the panel blocks (i, k) FOLLOW pivot by pivot (no barrier: they poll the progress word) with
+//      the same rank-1 step on their block, scale by 1 / l_cc at the end, write X = A L_kk^-T to LDS in the
+//      matrix-core operand layout (double-buffered over k) and to the outputs;               ONE barrier
+//   T  every block (i, j), j > k, subtracts X_i X_j^T with four MFMAs (two blocks interleaved); the diagonal
+//      blocks first, so the owner of (k+1, k+1) reaches D of the next step early.
+// The per-column dependent chain is readlane -> rcp -> 2 fma -> fma instead of the ~1100 cycles per column of the
+// 4 x 4 register-tile kernel, and there is one barrier per 16 columns.
+// Outputs as k_chol_tile: L, U = L^T, 1 / l_jj, and the packed copy with unit diagonal for k_solve_lds.
+constexpr int CHOL16_MAX_NB = 12;            // n <= 192
+constexpr int CHOL16_W = 12;                 // wavefronts
+constexpr int CHOL16_NS = 6;                 // off-diagonal blocks per wavefront: 66 / 12
+// owner of the diagonal block of the column with m = nb - 1 - j columns behind it: not among the owners
+// (m (m - 1) / 2 + q) % 12, q < m, of that column's panel blocks, and all different
+__device__ constexpr int CHOL16_DIAG_OWNER[CHOL16_MAX_NB] = {5, 2, 4, 1, 11, 3, 10, 8, 0, 9, 7, 6};
+template <int V> struct CTag { static constexpr int value = V; };
+#ifdef CHOL16_STAMPS
+#define CHOL16_STAMP(i) do { if (c.stamps && lane == 0) c.stamps[(k * W + wv) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CHOL16_STAMP(i) do { } while (0)
+#endif
+
+template <int P>
+__device__ __forceinline__ double row_bcast16(double x) {      // lane P of every 16-lane row, to all lanes of the row
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + P, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + P, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// d += (lane P of the 16-lane row of src) * w: one DP instruction with the row broadcast folded in (64-bit DPP knows
+// row_newbcast only, which is exactly this).  The s_nop covers the VALU-write -> DPP-read hazard, which the compiler's
+// hazard recogniser does not see inside inline assembly.
+template <int P>
+__device__ __forceinline__ void fmac_row_bcast16(double& d, double src, double w) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(w), "i"(P));
+}
+__device__ __forceinline__ unsigned lds_addr(const volatile void* p) { return (unsigned)(size_t)p; }
+
+__global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
+    constexpr int NBM = CHOL16_MAX_NB, W = CHOL16_W, NS = CHOL16_NS;
+    __shared__ __attribute__((aligned(16))) double sL[16 * 16];              // column p of the diagonal block at [p][r] (unscaled)
+    // 1 / a_pp and 1 / l_cc of the diagonal block of step k in half k & 1.  They double as the progress words: zero
+    // until published (the owner of the diagonal block clears the other half for the next step).
+    __shared__ __attribute__((aligned(16))) double sRp[2][16];
+    __shared__ __attribute__((aligned(16))) double sRi[2][16];
+    __shared__ __attribute__((aligned(16))) double sX[2][NBM][256];          // X_i of step k: [column][row], operand order
+    __shared__ int sBad;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = lane >> 4, cc = lane & 15;
+    const int n = c.n, nb = (n + 15) >> 4, noff = nb * (nb - 1) / 2;
+    const unsigned slcc_addr = lds_addr(&sL[cc]);
+    auto load_block = [&](int bi_, int bj_) {
+        v4d a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * bi_ + g + 4 * i, col = 16 * bj_ + cc;
+            double x = (r == col) ? 1.0 : 0.0;                               // identity padding beyond n
+            if (bi_ >= 0 && r < n && col < n) x = c.S[(size_t)r * c.lds_ + col];
+            a[i] = x;
+        }
+        return a;
+    };
+    // outputs of a finished block (scaled by ri = 1 / l_cc of its columns)
+    auto store_block = [&](const v4d& a, int bi_, int bj_, double ri) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * bi_ + g + 4 * i, col = 16 * bj_ + cc;
+            if (r < n && col <= r) {
+                const double x = a[i];
+                c.L[(size_t)r * n + col] = x;
+                c.U[(size_t)col * n + r] = x;
+                if (c.work) c.work[r * (r + 1) / 2 + col] = (r == col) ? 1.0 : x * ri;
+                if (r == col) c.invd[col] = ri;
+            }
+        }
+    };
+    int jd = -1;                                                             // my diagonal block
+#pragma unroll
+    for (int m = 0; m < NBM; ++m)
+        if (m < nb && CHOL16_DIAG_OWNER[m] == wv) jd = nb - 1 - m;
+    v4d dg = load_block(jd, jd);
+    int bi[NS], bj[NS];
+    v4d acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int e = wv + W * s;
+        bi[s] = -1; bj[s] = -1;
+        if (e < noff) {
+            int m = (int)((sqrtf(8.0f * (float)e + 1.0f) + 1.0f) * 0.5f);   // m (m - 1) / 2 <= e < m (m + 1) / 2
+            while (m * (m - 1) / 2 > e) --m;
+            while (m * (m + 1) / 2 <= e) ++m;
+            bj[s] = nb - 1 - m; bi[s] = bj[s] + 1 + (e - m * (m - 1) / 2);
+        }
+        acc[s] = load_block(bi[s], bj[s]);
+    }
+    if (t == 0) { sBad = 0; c.status[0] = 0; }
+    if (t < 32) { (&sRp[0][0])[t] = 0.0; (&sRi[0][0])[t] = 0.0; }
+    __syncthreads();
+
+    const int oo = g * 16 + cc;                  // operand element (row cc, column 4 q + g) of a block at [q * 64 + oo]
+    for (int k = 0; k < nb; ++k) {
+        CHOL16_STAMP(0);
+        // The trailing update of step k - 1 (X blocks in sX[(k - 1) & 1]) is split: T1 = my diagonal block and my block
+        // of column k, right here; T2 = the rest, ahead of following THIS step's pivots or, for the owner of the diagonal block, behind its
+        // elimination (it must only be done by this step's barrier, behind which that buffer is written again).
+        const double* xb = &sX[(k + 1) & 1][0][0];
+        auto update = [&](v4d& a, int i_, int j_) {
+            const double* xi = xb + i_ * 256 + oo;
+            const double* xj = xb + j_ * 256 + oo;
+            double av[4], bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = -xi[q * 64]; bv[q] = xj[q * 64]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], a, 0, 0, 0);
+        };
+        auto update2 = [&](v4d& a, int ia, int ja, v4d& b, int ib, int jb) {
+            const double* xi = xb + ia * 256 + oo;
+            const double* xj = xb + ja * 256 + oo;
+            const double* yi = xb + ib * 256 + oo;
+            const double* yj = xb + jb * 256 + oo;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                                    // two halves: 8 operand registers less
+                double av[2], bv[2], cv[2], dv[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    av[q] = -xi[(2 * h + q) * 64]; bv[q] = xj[(2 * h + q) * 64];
+                    cv[q] = -yi[(2 * h + q) * 64]; dv[q] = yj[(2 * h + q) * 64];
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    a = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], a, 0, 0, 0);
+                    b = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[q], dv[q], b, 0, 0, 0);
+                }
+            }
+        };
+        auto t2 = [&](auto tagp) {                                           // slots 2 pr, 2 pr + 1
+            constexpr int PR = decltype(tagp)::value;
+            const bool l0 = k > 0 && bj[2 * PR] > k, l1 = k > 0 && bj[2 * PR + 1] > k;
+            if (l0 && l1) update2(acc[2 * PR + 1], bi[2 * PR + 1], bj[2 * PR + 1], acc[2 * PR], bi[2 * PR], bj[2 * PR]);
+            else if (l0) update(acc[2 * PR], bi[2 * PR], bj[2 * PR]);
+            else if (l1) update(acc[2 * PR + 1], bi[2 * PR + 1], bj[2 * PR + 1]);
+        };
+        int sp = -1;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) if (bj[s] == k) sp = s;
+        if (k > 0) {
+            if (jd >= k) update(dg, jd, jd);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) if (s == sp) update(acc[s], bi[s], k);
+        }
+        v4d asel = acc[0];
+        int i0 = -1;
+        double ri_out = 1.0;
+        if (jd != k) { t2(CTag<2>{}); t2(CTag<1>{}); t2(CTag<0>{}); }     // (the followers catch up: a pivot costs them less)
+        if (jd == k) {
+            // ---- D: the diagonal block -----------------------------------------------------------------------------
+            double d[4] = {dg[0], dg[1], dg[2], dg[3]};
+            double pivs = 1.0;
+            bool bad = false;
+            if (lane < 16) { sRp[(k + 1) & 1][lane] = 0.0; sRi[(k + 1) & 1][lane] = 0.0; }
+            double* rp_out = &sRp[k & 1][0];
+            auto pivot = [&](auto tagp) {
+                constexpr int P = decltype(tagp)::value;
+                constexpr int GP = P & 3, IP = P >> 2;
+                int ccl = cc;
+                asm volatile("" : "+v"(ccl));                                // (keeps 32 lane masks from being hoisted into SGPRs)
+                double piv = readlane_d(d[IP], 16 * GP + P);
+                if (ccl == P) {
+                    pivs = piv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sL[P * 16 + g + 4 * i] = d[i];
+                }
+                double lc = 0.0;                                             // a[cc][P]: asked for here, waited for behind the reciprocal
+                if constexpr (P < 15)                                        // (piv passes through: the reciprocal is formed BEHIND the request)
+                    asm volatile("ds_read_b64 %0, %2 offset:%3" : "=v"(lc), "+s"(piv) : "v"(slcc_addr), "i"(P * 128) : "memory");
+                const bool ok = piv > 1e-200 && piv < 1e200;
+                bad = bad || !ok;
+                double rp = ok ? fast_rcp(piv) : 1.0;
+                if constexpr (P < 15) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lc), "+v"(rp)::"memory");
+                    const double w = (ccl > P) ? -(lc * rp) : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fmac_row_bcast16<P>(d[i], d[i], w);   // a[r][c] -= a[r][P] a[c][P] / a[P][P]
+                }
+                // published behind the update: the followers see it a little later, the chain above does not wait for it
+                asm volatile("" ::"v"(d[0]), "v"(d[3]) : "memory");
+                if (lane == 0) rp_out[P] = rp;                               // (LDS operations of a wavefront execute in order)
+            };
+            __builtin_amdgcn_s_setprio(3);
+            pivot(CTag<0>{}); pivot(CTag<1>{}); pivot(CTag<2>{}); pivot(CTag<3>{});
+            t2(CTag<2>{});
+            pivot(CTag<4>{}); pivot(CTag<5>{}); pivot(CTag<6>{}); pivot(CTag<7>{});
+            t2(CTag<1>{});
+            pivot(CTag<8>{}); pivot(CTag<9>{}); pivot(CTag<10>{}); pivot(CTag<11>{});
+            t2(CTag<0>{});
+            pivot(CTag<12>{}); pivot(CTag<13>{}); pivot(CTag<14>{}); pivot(CTag<15>{});
+            const double ri = bad ? 1.0 : fast_rsqrt(pivs);                  // lane c: 1 / l_cc -- sixteen roots in one go
+            if (bad && lane == 0) sBad = 1;
+            asm volatile("" ::: "memory");
+            if (g == 0) sRi[k & 1][cc] = ri;
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dg[i] = d[i] * ri;
+            CHOL16_STAMP(1);
+            store_block(dg, k, k, ri);
+        } else if (sp >= 0) {
+            // ---- P: the panel block of this wavefront (at most one) follows the pivots -------------------------------
+            CHOL16_STAMP(1);
+            i0 = bi[0];
+#pragma unroll
+            for (int s = 1; s < NS; ++s) if (s == sp) { asel = acc[s]; i0 = bi[s]; }
+            double a0[4] = {asel[0], asel[1], asel[2], asel[3]};
+            const unsigned rp_addr = lds_addr(&sRp[k & 1][0]);
+            auto follow = [&](auto tagp) {
+                constexpr int P = decltype(tagp)::value;
+                int ccl = cc;
+                asm volatile("" : "+v"(ccl));
+                double rp, lc;
+                int spins = 0;
+                do {                                                         // rp first, then the column: in order, as they were written
+                    asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(rp), "=&v"(lc) : "v"(rp_addr), "v"(slcc_addr), "i"(P * 8), "i"(P * 128) : "memory");
+                    if (rp != 0.0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++spins < (1 << 22));
+                const double w = (ccl > P) ? -(lc * rp) : 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fmac_row_bcast16<P>(a0[i], a0[i], w);
+            };
+            follow(CTag<0>{}); follow(CTag<1>{}); follow(CTag<2>{}); follow(CTag<3>{}); follow(CTag<4>{}); follow(CTag<5>{});
+            follow(CTag<6>{}); follow(CTag<7>{}); follow(CTag<8>{}); follow(CTag<9>{}); follow(CTag<10>{}); follow(CTag<11>{});
+            follow(CTag<12>{}); follow(CTag<13>{}); follow(CTag<14>{});
+            {
+                const unsigned ri_addr = lds_addr(&sRi[k & 1][cc]);
+                int spins = 0;
+                do {
+                    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ri_out) : "v"(ri_addr) : "memory");
+                    if (ri_out != 0.0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                } while (++spins < (1 << 22));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asel[i] = a0[i] * ri_out;
+            double* dst = &sX[k & 1][i0][cc * 16 + g];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[4 * i] = asel[i];                // [column][row]
+        } else {
+            CHOL16_STAMP(1);
+        }
+        CHOL16_STAMP(2);
+        __syncthreads();
+        CHOL16_STAMP(3);
+        if (sBad) break;                                   // uniform: read after a barrier
+        if (i0 >= 0) store_block(asel, i0, k, ri_out);     // the finished panel block, off the critical path
+    }
+    __syncthreads();
+    if (sBad && t == 0) c.status[0] = 1;
 }
 
 }  // namespace msckf

@@ -49,6 +49,9 @@ constexpr int FOLD_RPT_W3 = 192 / FOLD_RL;                      // 192-row batch
 #define MSCKF_CHOL_T 768
 #endif
 constexpr int CHOL_T = MSCKF_CHOL_T;             // threads of the register-tiled Cholesky
+#ifndef MSCKF_CHOL16
+#define MSCKF_CHOL16 1                           // 1: k_chol16 (16 x 16 matrix-core blocks), 0: k_chol_tile (4 x 4 register tiles)
+#endif
 #ifndef MSCKF_SOLVE_WAVES
 #define MSCKF_SOLVE_WAVES 8
 #endif
@@ -812,6 +815,15 @@ void launch_tri_sweep(msckf_ctx* c, double* X, int ldx, int rows, const double* 
 // diagonal factors come from k_chol_tile, everything else is triangular sweeps with the factor in LDS and MFMA
 // GEMMs.  K = Y S^-1 row by row:  X1 = Y1 L11^-T,  K2 = (Y2 - X1 W^T) L22^-T L22^-1,  K1 = (X1 - K2 W) L11^-1.
 constexpr int GAIN_BLK = 160;
+// Cholesky of a matrix of at most 4 * CHOL_TILE_MAX_NT rows, one workgroup.
+void launch_chol_small(msckf_ctx* c, const CholArgs& a) {
+#if MSCKF_CHOL16
+    hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * CHOL16_W), 0, c->stream, a);
+#else
+    hipLaunchKernelGGL((k_chol_tile<CHOL_T>), dim3(1), dim3(CHOL_T), 0, c->stream, a);
+#endif
+}
+
 int launch_chol_solve_blocked(msckf_ctx* c, double* S, const double* Y, double* Kg, const double* z, int zstride) {
     const int d = c->d, dc = c->dc, n1 = GAIN_BLK, n2 = dc - GAIN_BLK;
     double* work1 = ptr<double>(c->dCholWork);
@@ -824,7 +836,7 @@ int launch_chol_solve_blocked(msckf_ctx* c, double* S, const double* Y, double* 
         CholArgs a{};
         a.S = S; a.lds_ = dc; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = invd; a.n = n1;
         a.work = work1; a.status = status;
-        hipLaunchKernelGGL((k_chol_tile<CHOL_T>), dim3(1), dim3(CHOL_T), 0, c->stream, a);
+        launch_chol_small(c, a);
     }
     // W = B L11^-T  (rows n1.. of S, first n1 columns), then the Schur complement C2 = C - W W^T
     HIPCHK(c, hipMemcpy2DAsync(W, (size_t)n1 * 8, S + (size_t)n1 * dc, (size_t)dc * 8, (size_t)n1 * 8, n2, hipMemcpyDeviceToDevice,
@@ -835,7 +847,7 @@ int launch_chol_solve_blocked(msckf_ctx* c, double* S, const double* Y, double* 
         CholArgs a{};
         a.S = C2; a.lds_ = n2; a.L = ptr<double>(c->dL); a.U = ptr<double>(c->dU); a.invd = invd + n1; a.n = n2;
         a.work = work2; a.status = status + 1;
-        hipLaunchKernelGGL((k_chol_tile<CHOL_T>), dim3(1), dim3(CHOL_T), 0, c->stream, a);
+        launch_chol_small(c, a);
     }
     // X1 = Y1 L11^-T (into K)
     HIPCHK(c, hipMemcpy2DAsync(Kg, (size_t)dc * 8, Y, (size_t)dc * 8, (size_t)n1 * 8, d, hipMemcpyDeviceToDevice, c->stream));
@@ -879,7 +891,7 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         a.n = dc; a.work = ptr<double>(c->dCholWork); a.status = ptr<int>(c->dStatus);
         if (dc <= 4 * CHOL_TILE_MAX_NT) {
             packed_L = true;
-            hipLaunchKernelGGL((k_chol_tile<CHOL_T>), dim3(1), dim3(CHOL_T), 0, c->stream, a);   // matrix in registers
+            launch_chol_small(c, a);   // matrix in registers
         } else {
             const size_t need = (size_t)dc * (dc + 1) / 2 * 8;
             a.use_lds = need <= (size_t)(LDS_MAX_BYTES - 1024) ? 1 : 0;
