@@ -665,12 +665,15 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
     // until published (the owner of the diagonal block clears the other half for the next step).
     __shared__ __attribute__((aligned(16))) double sRp[2][16];
     __shared__ __attribute__((aligned(16))) double sRi[2][16];
+    __shared__ __attribute__((aligned(16))) double sDump[64 + 256];          // where the lanes with nothing to publish write
     __shared__ __attribute__((aligned(16))) double sX[2][NBM][256];          // X_i of step k: [column][row], operand order
     __shared__ int sBad;
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int g = lane >> 4, cc = lane & 15;
     const int n = c.n, nb = (n + 15) >> 4, noff = nb * (nb - 1) / 2;
-    const unsigned slcc_addr = lds_addr(&sL[cc]);
+    const unsigned slcc_addr = lds_addr(&sL[cc]), srp_addr = lds_addr(&sRp[0][0]);
+    const int cc4 = cc * 4;
+    const unsigned sl_g_addr = lds_addr(&sL[g]), dump_addr = lds_addr(&sDump[0]) + lane * 8;
     auto load_block = [&](int bi_, int bj_) {
         v4d a;
 #pragma unroll
@@ -780,33 +783,56 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
             double pivs = 1.0;
             bool bad = false;
             if (lane < 16) { sRp[(k + 1) & 1][lane] = 0.0; sRi[(k + 1) & 1][lane] = 0.0; }
-            double* rp_out = &sRp[k & 1][0];
+            const unsigned rp_out = srp_addr + (k & 1) * 128;
+            // Software pipeline over the pivots.  Entering pivot P, row P of the (symmetric) trailing square -- a[cc][P] for
+            // the lanes of column cc, which sits in register IP of row group GP -- is already on its way by ds_bpermute
+            // and the pivot by v_readlane: both were issued in pivot P - 1 right behind the update of THAT register, ahead
+            // of the other three.  The exact chain is fmac -> readlane -> rcp -> fma -> fma -> fmac.  All LDS traffic is
+            // issued by every lane (the lanes that have nothing to say write to a dump row): no exec juggling, and the
+            // order of the LDS instructions is fixed, [column P][1 / a_PP][row P + 1], so that one s_waitcnt lgkmcnt(0)
+            // in the next pivot covers exactly the ds_bpermute pair.
+            int rlo, rhi;                                                    // row P in flight
+            double piv;
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"                 // (matrix-core write -> read, unseen by the hazard recogniser)
+                         "ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4"
+                         : "=&v"(rlo), "=&v"(rhi) : "v"(cc4), "v"(__double2loint(d[0])), "v"(__double2hiint(d[0])) : "memory");
+            piv = readlane_d(d[0], 0);
             auto pivot = [&](auto tagp) {
                 constexpr int P = decltype(tagp)::value;
-                constexpr int GP = P & 3, IP = P >> 2;
+                constexpr int GN = (P + 1) & 3, IN = ((P + 1) >> 2) & 3;     // where row / pivot P + 1 live
                 int ccl = cc;
                 asm volatile("" : "+v"(ccl));                                // (keeps 32 lane masks from being hoisted into SGPRs)
-                double piv = readlane_d(d[IP], 16 * GP + P);
-                if (ccl == P) {
-                    pivs = piv;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sL[P * 16 + g + 4 * i] = d[i];
+                double r = __builtin_amdgcn_rcp(piv);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rlo), "+v"(rhi), "+v"(r)::"memory");   // (behind the v_rcp_f64)
+                const double lc = __hiloint2double(rhi, rlo);
+                const double lcm = (ccl > P) ? -lc : 0.0;
+                pivs = (ccl == P) ? piv : pivs;
+                {   // column P for the followers
+                    const unsigned ca = (ccl == P) ? sl_g_addr : dump_addr;
+                    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%5 offset1:%6\n\tds_write2_b64 %0, %3, %4 offset0:%7 offset1:%8"
+                                 ::"v"(ca), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "i"(P * 16), "i"(P * 16 + 4), "i"(P * 16 + 8), "i"(P * 16 + 12)
+                                 : "memory");
                 }
-                double lc = 0.0;                                             // a[cc][P]: asked for here, waited for behind the reciprocal
-                if constexpr (P < 15)                                        // (piv passes through: the reciprocal is formed BEHIND the request)
-                    asm volatile("ds_read_b64 %0, %2 offset:%3" : "=v"(lc), "+s"(piv) : "v"(slcc_addr), "i"(P * 128) : "memory");
-                const bool ok = piv > 1e-200 && piv < 1e200;
-                bad = bad || !ok;
-                double rp = ok ? fast_rcp(piv) : 1.0;
+                const double e = fma(-piv, r, 1.0);                          // one Newton step, folded into the multiplier
+                const double w = lcm * r;
+                const double w2 = fma(w, e, w);
+                {   // 1 / a_PP for the followers (nonzero: it doubles as their progress word)
+                    const double rp = fma(r, e, r);
+                    const unsigned ra = (lane == 0) ? rp_out : dump_addr;
+                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ra), "v"(rp), "i"(P * 8) : "memory");
+                }
                 if constexpr (P < 15) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lc), "+v"(rp)::"memory");
-                    const double w = (ccl > P) ? -(lc * rp) : 0.0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fmac_row_bcast16<P>(d[i], d[i], w);   // a[r][c] -= a[r][P] a[c][P] / a[P][P]
+                    // a[r][c] -= a[r][P] a[c][P] / a[P][P]: the register of row P + 1 first, and its row and pivot go on their way
+                    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d[IN]) : "v"(w2), "i"(P));
+                    asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%5\n\tds_bpermute_b32 %1, %2, %4 offset:%5"
+                                 : "=&v"(rlo), "=&v"(rhi) : "v"(cc4), "v"(__double2loint(d[IN])), "v"(__double2hiint(d[IN])), "i"(64 * GN) : "memory");
+                    piv = readlane_d(d[IN], 16 * GN + P + 1);
+                    asm volatile("s_nop 1\n\t"
+                                 "v_fmac_f64_dpp %0, %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %1, %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_fmac_f64_dpp %2, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(d[(IN + 1) & 3]), "+v"(d[(IN + 2) & 3]), "+v"(d[(IN + 3) & 3]) : "v"(w2), "i"(P));
                 }
-                // published behind the update: the followers see it a little later, the chain above does not wait for it
-                asm volatile("" ::"v"(d[0]), "v"(d[3]) : "memory");
-                if (lane == 0) rp_out[P] = rp;                               // (LDS operations of a wavefront execute in order)
             };
             __builtin_amdgcn_s_setprio(3);
             pivot(CTag<0>{}); pivot(CTag<1>{}); pivot(CTag<2>{}); pivot(CTag<3>{});
@@ -816,6 +842,7 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
             pivot(CTag<8>{}); pivot(CTag<9>{}); pivot(CTag<10>{}); pivot(CTag<11>{});
             t2(CTag<0>{});
             pivot(CTag<12>{}); pivot(CTag<13>{}); pivot(CTag<14>{}); pivot(CTag<15>{});
+            bad = __ballot(!(pivs > 1e-200 && pivs < 1e200)) != 0ull;       // (a NaN pivot carries through to the later ones)
             const double ri = bad ? 1.0 : fast_rsqrt(pivs);                  // lane c: 1 / l_cc -- sixteen roots in one go
             if (bad && lane == 0) sBad = 1;
             asm volatile("" ::: "memory");
