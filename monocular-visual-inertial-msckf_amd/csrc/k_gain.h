@@ -632,6 +632,7 @@ namespace msckf {
 constexpr int CHOL16_MAX_NB = 12;            // n <= 192
 constexpr int CHOL16_W = 12;                 // wavefronts
 constexpr int CHOL16_NS = 6;                 // off-diagonal blocks per wavefront: 66 / 12
+constexpr long long CHOL16_UNSET = 0x7ff8dead0000beefLL;   // a NaN no arithmetic produces
 // owner of the diagonal block of the column with m = nb - 1 - j columns behind it: not among the owners
 // (m (m - 1) / 2 + q) % 12, q < m, of that column's panel blocks, and all different
 __device__ constexpr int CHOL16_DIAG_OWNER[CHOL16_MAX_NB] = {5, 2, 4, 1, 11, 3, 10, 8, 0, 9, 7, 6};
@@ -660,20 +661,21 @@ __device__ __forceinline__ unsigned lds_addr(const volatile void* p) { return (u
 
 __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
     constexpr int NBM = CHOL16_MAX_NB, W = CHOL16_W, NS = CHOL16_NS;
-    __shared__ __attribute__((aligned(16))) double sL[16 * 16];              // column p of the diagonal block at [p][r] (unscaled)
-    // 1 / a_pp and 1 / l_cc of the diagonal block of step k in half k & 1.  They double as the progress words: zero
-    // until published (the owner of the diagonal block clears the other half for the next step).
-    __shared__ __attribute__((aligned(16))) double sRp[2][16];
+    // What the followers of step k need, in half k & 1: per pivot p the row of multipliers m_c = -a_cp / a_pp (zero
+    // for c <= p) in [p][0..15], with [p][16] as the progress word -- it holds CHOL16_UNSET until the row is there
+    // (one 17-lane ds_write_b64: lane 16's own multiplier is a zero) -- and 1 / l_cc in sRi (zero until published).
+    // The owner of the diagonal block resets the other half for the next step.
+    __shared__ __attribute__((aligned(16))) double sW[2][16][17];
     __shared__ __attribute__((aligned(16))) double sRi[2][16];
-    __shared__ __attribute__((aligned(16))) double sDump[64 + 256];          // where the lanes with nothing to publish write
-    __shared__ __attribute__((aligned(16))) double sX[2][NBM][256];          // X_i of step k: [column][row], operand order
+    // X_i of step k in buffer k & 1: [block row][column][row], the matrix-core operand order
+    __shared__ __attribute__((aligned(16))) double sX[2 * NBM * 256];
+    constexpr int XB = NBM * 256;
     __shared__ int sBad;
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int g = lane >> 4, cc = lane & 15;
     const int n = c.n, nb = (n + 15) >> 4, noff = nb * (nb - 1) / 2;
-    const unsigned slcc_addr = lds_addr(&sL[cc]), srp_addr = lds_addr(&sRp[0][0]);
+    const unsigned sw_addr = lds_addr(&sW[0][0][0]);
     const int cc4 = cc * 4;
-    const unsigned sl_g_addr = lds_addr(&sL[g]), dump_addr = lds_addr(&sDump[0]) + lane * 8;
     auto load_block = [&](int bi_, int bj_) {
         v4d a;
 #pragma unroll
@@ -719,16 +721,18 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
         acc[s] = load_block(bi[s], bj[s]);
     }
     if (t == 0) { sBad = 0; c.status[0] = 0; }
-    if (t < 32) { (&sRp[0][0])[t] = 0.0; (&sRi[0][0])[t] = 0.0; }
+    if (t < 32) { (&sRi[0][0])[t] = 0.0; sW[t >> 4][t & 15][16] = __longlong_as_double(CHOL16_UNSET); }
     __syncthreads();
 
     const int oo = g * 16 + cc;                  // operand element (row cc, column 4 q + g) of a block at [q * 64 + oo]
     for (int k = 0; k < nb; ++k) {
         CHOL16_STAMP(0);
-        // The trailing update of step k - 1 (X blocks in sX[(k - 1) & 1]) is split: T1 = my diagonal block and my block
-        // of column k, right here; T2 = the rest, ahead of following THIS step's pivots or, for the owner of the diagonal block, behind its
-        // elimination (it must only be done by this step's barrier, behind which that buffer is written again).
-        const double* xb = &sX[(k + 1) & 1][0][0];
+        // The trailing update of step k - 1 (X blocks in buffer (k - 1) & 1) is split: T1 = my diagonal block and my block
+        // of column k, right here; T2 = the rest, ahead of following THIS step's pivots -- a pivot costs the followers
+        // less than its owner, they catch up -- or, for the owner of the diagonal block, behind its elimination (T2 must
+        // only be done by this step's barrier, behind which that buffer is written again).  Leaving the owner's T2 for
+        // the NEXT step (three buffers) was tried: no faster.
+        const double* xb = sX + ((k + 1) & 1) * XB;
         auto update = [&](v4d& a, int i_, int j_) {
             const double* xi = xb + i_ * 256 + oo;
             const double* xj = xb + j_ * 256 + oo;
@@ -758,9 +762,10 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
                 }
             }
         };
-        auto t2 = [&](auto tagp) {                                           // slots 2 pr, 2 pr + 1
+        const int thr = k;
+        auto t2 = [&](auto tagp) {                                           // slots 2 pr, 2 pr + 1: blocks right of column thr
             constexpr int PR = decltype(tagp)::value;
-            const bool l0 = k > 0 && bj[2 * PR] > k, l1 = k > 0 && bj[2 * PR + 1] > k;
+            const bool l0 = bj[2 * PR] > thr, l1 = bj[2 * PR + 1] > thr;
             if (l0 && l1) update2(acc[2 * PR + 1], bi[2 * PR + 1], bj[2 * PR + 1], acc[2 * PR], bi[2 * PR], bj[2 * PR]);
             else if (l0) update(acc[2 * PR], bi[2 * PR], bj[2 * PR]);
             else if (l1) update(acc[2 * PR + 1], bi[2 * PR + 1], bj[2 * PR + 1]);
@@ -776,21 +781,18 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
         v4d asel = acc[0];
         int i0 = -1;
         double ri_out = 1.0;
-        if (jd != k) { t2(CTag<2>{}); t2(CTag<1>{}); t2(CTag<0>{}); }     // (the followers catch up: a pivot costs them less)
+        if (jd != k && k > 0) { t2(CTag<2>{}); t2(CTag<1>{}); t2(CTag<0>{}); }
         if (jd == k) {
             // ---- D: the diagonal block -----------------------------------------------------------------------------
             double d[4] = {dg[0], dg[1], dg[2], dg[3]};
-            double pivs = 1.0;
-            bool bad = false;
-            if (lane < 16) { sRp[(k + 1) & 1][lane] = 0.0; sRi[(k + 1) & 1][lane] = 0.0; }
-            const unsigned rp_out = srp_addr + (k & 1) * 128;
+            if (lane < 16) { sW[(k + 1) & 1][lane][16] = __longlong_as_double(CHOL16_UNSET); sRi[(k + 1) & 1][lane] = 0.0; }
+            const unsigned w_out = sw_addr + (k & 1) * (16 * 17 * 8) + lane * 8;
             // Software pipeline over the pivots.  Entering pivot P, row P of the (symmetric) trailing square -- a[cc][P] for
             // the lanes of column cc, which sits in register IP of row group GP -- is already on its way by ds_bpermute
             // and the pivot by v_readlane: both were issued in pivot P - 1 right behind the update of THAT register, ahead
-            // of the other three.  The exact chain is fmac -> readlane -> rcp -> fma -> fma -> fmac.  All LDS traffic is
-            // issued by every lane (the lanes that have nothing to say write to a dump row): no exec juggling, and the
-            // order of the LDS instructions is fixed, [column P][1 / a_PP][row P + 1], so that one s_waitcnt lgkmcnt(0)
-            // in the next pivot covers exactly the ds_bpermute pair.
+            // of the other three.  The exact chain is fmac -> readlane -> rcp -> fma -> fma -> fmac.  The order of the LDS
+            // instructions is fixed, [multipliers of P][row P + 1], so that one s_waitcnt lgkmcnt(0) in the next pivot
+            // covers exactly the ds_bpermute pair.
             int rlo, rhi;                                                    // row P in flight
             double piv;
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"                 // (matrix-core write -> read, unseen by the hazard recogniser)
@@ -806,26 +808,18 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rlo), "+v"(rhi), "+v"(r)::"memory");   // (behind the v_rcp_f64)
                 const double lc = __hiloint2double(rhi, rlo);
                 const double lcm = (ccl > P) ? -lc : 0.0;
-                pivs = (ccl == P) ? piv : pivs;
-                {   // column P for the followers
-                    const unsigned ca = (ccl == P) ? sl_g_addr : dump_addr;
-                    asm volatile("ds_write2_b64 %0, %1, %2 offset0:%5 offset1:%6\n\tds_write2_b64 %0, %3, %4 offset0:%7 offset1:%8"
-                                 ::"v"(ca), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "i"(P * 16), "i"(P * 16 + 4), "i"(P * 16 + 8), "i"(P * 16 + 12)
-                                 : "memory");
-                }
                 const double e = fma(-piv, r, 1.0);                          // one Newton step, folded into the multiplier
                 const double w = lcm * r;
                 const double w2 = fma(w, e, w);
-                {   // 1 / a_PP for the followers (nonzero: it doubles as their progress word)
-                    const double rp = fma(r, e, r);
-                    const unsigned ra = (lane == 0) ? rp_out : dump_addr;
-                    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(ra), "v"(rp), "i"(P * 8) : "memory");
-                }
                 if constexpr (P < 15) {
                     // a[r][c] -= a[r][P] a[c][P] / a[P][P]: the register of row P + 1 first, and its row and pivot go on their way
                     asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d[IN]) : "v"(w2), "i"(P));
-                    asm volatile("ds_bpermute_b32 %0, %2, %3 offset:%5\n\tds_bpermute_b32 %1, %2, %4 offset:%5"
-                                 : "=&v"(rlo), "=&v"(rhi) : "v"(cc4), "v"(__double2loint(d[IN])), "v"(__double2hiint(d[IN])), "i"(64 * GN) : "memory");
+                    // the multipliers for the followers (lanes 0..15: columns; lane 16: a zero, the progress word), then row P + 1
+                    asm volatile("s_mov_b64 exec, 0x1ffff\n\tds_write_b64 %2, %3 offset:%4\n\ts_mov_b64 exec, -1\n\t"
+                                 "ds_bpermute_b32 %0, %5, %6 offset:%8\n\tds_bpermute_b32 %1, %5, %7 offset:%8"
+                                 : "=&v"(rlo), "=&v"(rhi)
+                                 : "v"(w_out), "v"(w2), "i"(P * 17 * 8), "v"(cc4), "v"(__double2loint(d[IN])), "v"(__double2hiint(d[IN])), "i"(64 * GN)
+                                 : "memory");
                     piv = readlane_d(d[IN], 16 * GN + P + 1);
                     asm volatile("s_nop 1\n\t"
                                  "v_fmac_f64_dpp %0, %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
@@ -836,13 +830,19 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
             };
             __builtin_amdgcn_s_setprio(3);
             pivot(CTag<0>{}); pivot(CTag<1>{}); pivot(CTag<2>{}); pivot(CTag<3>{});
-            t2(CTag<2>{});
             pivot(CTag<4>{}); pivot(CTag<5>{}); pivot(CTag<6>{}); pivot(CTag<7>{});
-            t2(CTag<1>{});
             pivot(CTag<8>{}); pivot(CTag<9>{}); pivot(CTag<10>{}); pivot(CTag<11>{});
-            t2(CTag<0>{});
             pivot(CTag<12>{}); pivot(CTag<13>{}); pivot(CTag<14>{}); pivot(CTag<15>{});
-            bad = __ballot(!(pivs > 1e-200 && pivs < 1e200)) != 0ull;       // (a NaN pivot carries through to the later ones)
+            // the pivots are the diagonal as it stands now (entry (c, c) is final once column c is eliminated): lane (g, c)
+            // picks register c >> 2 and takes it from row group c & 3
+            double pivs;
+            {
+                const double sel = (cc < 8) ? ((cc < 4) ? d[0] : d[1]) : ((cc < 12) ? d[2] : d[3]);
+                const int src4 = (16 * (cc & 3) + cc) * 4;
+                const int plo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(sel)), phi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(sel));
+                pivs = __hiloint2double(phi, plo);
+            }
+            const bool bad = __ballot(!(pivs > 1e-200 && pivs < 1e200)) != 0ull;   // (a NaN pivot carries through to the later ones)
             const double ri = bad ? 1.0 : fast_rsqrt(pivs);                  // lane c: 1 / l_cc -- sixteen roots in one go
             if (bad && lane == 0) sBad = 1;
             asm volatile("" ::: "memory");
@@ -851,6 +851,7 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dg[i] = d[i] * ri;
             CHOL16_STAMP(1);
+            if (k > 0) { t2(CTag<2>{}); t2(CTag<1>{}); t2(CTag<0>{}); }
             store_block(dg, k, k, ri);
         } else if (sp >= 0) {
             // ---- P: the panel block of this wavefront (at most one) follows the pivots -------------------------------
@@ -859,26 +860,52 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
 #pragma unroll
             for (int s = 1; s < NS; ++s) if (s == sp) { asel = acc[s]; i0 = bi[s]; }
             double a0[4] = {asel[0], asel[1], asel[2], asel[3]};
-            const unsigned rp_addr = lds_addr(&sRp[k & 1][0]);
-            auto follow = [&](auto tagp) {
-                constexpr int P = decltype(tagp)::value;
-                int ccl = cc;
-                asm volatile("" : "+v"(ccl));
-                double rp, lc;
+            const unsigned w_in = sw_addr + (k & 1) * (16 * 17 * 8);
+            const unsigned w_cc = w_in + cc * 8;
+            // Four pivots at a time: one poll (the progress word of the chunk's last pivot, by ONE lane -- eleven wavefronts
+            // polling with all 64 keep the LDS busy and hold up the owner of the diagonal block), four rows of
+            // multipliers read back to back, sixteen updates from registers.
+            auto follow4 = [&](auto tagp) {
+                constexpr int P0 = decltype(tagp)::value;
+                constexpr int PL = (P0 + 3 < 14) ? P0 + 3 : 14;              // the last pivot with multipliers
+                double* ap = a0;                                             // (a variable named only in asm operands is not captured)
+                const unsigned win_l = w_in, wcc_l = w_cc;
                 int spins = 0;
-                do {                                                         // rp first, then the column: in order, as they were written
-                    asm volatile("ds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(rp), "=&v"(lc) : "v"(rp_addr), "v"(slcc_addr), "i"(P * 8), "i"(P * 128) : "memory");
-                    if (rp != 0.0) break;
-                    __builtin_amdgcn_s_sleep(1);
+                do {
+                    double flag;
+                    asm volatile("s_mov_b64 exec, 1\n\tds_read_b64 %0, %1 offset:%2\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=v"(flag) : "v"(win_l), "i"(PL * 17 * 8 + 128) : "memory");
+                    const int flo = __builtin_amdgcn_readfirstlane(__double2loint(flag));
+                    const int fhi = __builtin_amdgcn_readfirstlane(__double2hiint(flag));
+                    if (flo != (int)(CHOL16_UNSET & 0xffffffffLL) || fhi != (int)(CHOL16_UNSET >> 32)) break;
+                    __builtin_amdgcn_s_sleep(2);
                 } while (++spins < (1 << 22));
-                const double w = (ccl > P) ? -(lc * rp) : 0.0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fmac_row_bcast16<P>(a0[i], a0[i], w);
+                double m0, m1, m2, m3 = 0.0;
+                asm volatile("ds_read_b64 %0, %3 offset:%4\n\tds_read_b64 %1, %3 offset:%5\n\tds_read_b64 %2, %3 offset:%6"
+                             : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(wcc_l), "i"(P0 * 17 * 8), "i"((P0 + 1) * 17 * 8), "i"((P0 + 2) * 17 * 8) : "memory");
+                if constexpr (P0 + 3 < 15) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m3) : "v"(wcc_l), "i"((P0 + 3) * 17 * 8) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)::"memory");
+#define CHOL16_FOLLOW1(PP, M)                                                                                            \
+    asm volatile("s_nop 1\n\t"                                                                                          \
+                 "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"                                 \
+                 : "+v"(ap[0]), "+v"(ap[1]), "+v"(ap[2]), "+v"(ap[3]) : "v"(M), "i"(PP))
+                CHOL16_FOLLOW1(P0, m0);
+                CHOL16_FOLLOW1(P0 + 1, m1);
+                CHOL16_FOLLOW1(P0 + 2, m2);
+                if constexpr (P0 + 3 < 15) CHOL16_FOLLOW1(P0 + 3, m3);
+#undef CHOL16_FOLLOW1
             };
-            follow(CTag<0>{}); follow(CTag<1>{}); follow(CTag<2>{}); follow(CTag<3>{}); follow(CTag<4>{}); follow(CTag<5>{});
-            follow(CTag<6>{}); follow(CTag<7>{}); follow(CTag<8>{}); follow(CTag<9>{}); follow(CTag<10>{}); follow(CTag<11>{});
-            follow(CTag<12>{}); follow(CTag<13>{}); follow(CTag<14>{});
+#ifdef CHOL16_STAMPS
+#define CHOL16_CSTAMP(i) do { if (c.stamps && lane == 0 && k == 0) c.stamps[12 * W * 4 + wv * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CHOL16_CSTAMP(i) do { } while (0)
+#endif
+            CHOL16_CSTAMP(0);
+            follow4(CTag<0>{}); CHOL16_CSTAMP(1); follow4(CTag<4>{}); CHOL16_CSTAMP(2); follow4(CTag<8>{}); CHOL16_CSTAMP(3); follow4(CTag<12>{});
+            CHOL16_CSTAMP(4);
             {
                 const unsigned ri_addr = lds_addr(&sRi[k & 1][cc]);
                 int spins = 0;
@@ -890,9 +917,10 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) asel[i] = a0[i] * ri_out;
-            double* dst = &sX[k & 1][i0][cc * 16 + g];
+            double* dst = sX + (k & 1) * XB + i0 * 256 + cc * 16 + g;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[4 * i] = asel[i];                // [column][row]
+            CHOL16_CSTAMP(5);
         } else {
             CHOL16_STAMP(1);
         }

@@ -20,9 +20,9 @@ int main(int argc, char** argv) {
     }
     double *dS, *dL, *dU, *dinv, *dwork; int* dst; long long* dstamp;
     hipMalloc(&dS, n * n * 8); hipMalloc(&dL, n * n * 8); hipMalloc(&dU, n * n * 8); hipMalloc(&dinv, n * 8);
-    hipMalloc(&dwork, n * (n + 1) / 2 * 8); hipMalloc(&dst, 16); hipMalloc(&dstamp, 12 * WV * 4 * 8);
+    hipMalloc(&dwork, n * (n + 1) / 2 * 8); hipMalloc(&dst, 16); hipMalloc(&dstamp, (12 * WV * 4 + WV * 8) * 8);
     hipMemcpy(dS, S.data(), n * n * 8, hipMemcpyHostToDevice);
-    hipMemset(dL, 0, n * n * 8); hipMemset(dstamp, 0, 12 * WV * 4 * 8);
+    hipMemset(dL, 0, n * n * 8); hipMemset(dstamp, 0, (12 * WV * 4 + WV * 8) * 8);
     CholArgs a{}; a.S = dS; a.lds_ = n; a.L = dL; a.U = dU; a.invd = dinv; a.n = n; a.work = dwork; a.status = dst; a.stamps = dstamp;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * WV), 0, 0, a);
@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * WV), 0, 0, a);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<double> L(n * n); std::vector<long long> st(12 * WV * 4);
+    std::vector<double> L(n * n); std::vector<long long> st(12 * WV * 4 + WV * 8);
     hipMemcpy(L.data(), dL, n * n * 8, hipMemcpyDeviceToHost); hipMemcpy(st.data(), dstamp, st.size() * 8, hipMemcpyDeviceToHost);
     double err = 0;
     for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {
@@ -49,5 +49,7 @@ int main(int argc, char** argv) {
         }
         printf("\n");
     }
+    printf("followers of step 0 (cycles from t0): start, after chunk 0..3, X published\n");
+    for (int w = 0; w < WV; ++w) { long long* q = &st[12 * WV * 4 + w * 8]; if (q[0]) printf("  w%-2d %6lld %6lld %6lld %6lld %6lld %6lld\n", w, q[0] - t0, q[1] - t0, q[2] - t0, q[3] - t0, q[4] - t0, q[5] - t0); }
     return 0;
 }
