@@ -700,6 +700,11 @@ void launch_wsweep(msckf_ctx* c, int node_base, int count, int rc_log2) {
 }
 
 int launch_sweeps(msckf_ctx* c, bool with_root = true) {
+    // the sweep kernels address the workspace with 32-bit byte offsets
+    if ((c->rbuf_doubles + 16) * 8 >= (size_t)0xffffffffu) {
+        c->last_error = "band plan workspace over 4 GB";
+        return MSCKF_ERR_ARG;
+    }
     if (c->snodes.empty()) return MSCKF_OK;
     if (c->sweep_mode > 0) {
         auto go = [&](int base, int count) {
@@ -1274,10 +1279,14 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         const int f = c->perm[sidx];
         const int a = view_ptr[f], M = view_ptr[f + 1] - a;
         h_view[sidx] = pos;
-        std::memcpy(&h_slot[pos], &obs_slot[a], (size_t)M * 4);
-        std::memcpy(&h_uv[(size_t)pos * 2], &obs_uv[(size_t)a * 2], (size_t)M * 16);
-        std::memcpy(&h_base[(size_t)sidx * 3], &idp_base[(size_t)f * 3], 24);
-        std::memcpy(&h_m[(size_t)sidx * 3], &idp_m[(size_t)f * 3], 24);
+        {   // (short, variable-length runs: plain loops beat the memcpy calls)
+            const int* ss = obs_slot + a; int* sd = h_slot + pos;
+            const double* us = obs_uv + (size_t)a * 2; double* ud = h_uv + (size_t)pos * 2;
+            for (int v = 0; v < M; ++v) { sd[v] = ss[v]; ud[2 * v] = us[2 * v]; ud[2 * v + 1] = us[2 * v + 1]; }
+            const double* bs = idp_base + (size_t)f * 3; double* bd = h_base + (size_t)sidx * 3;
+            const double* ms = idp_m + (size_t)f * 3; double* md = h_m + (size_t)sidx * 3;
+            bd[0] = bs[0]; bd[1] = bs[1]; bd[2] = bs[2]; md[0] = ms[0]; md[1] = ms[1]; md[2] = ms[2];
+        }
         h_rho[sidx] = idp_rho[f];
         h_fmin[sidx] = fmin_in[f]; h_fmax[sidx] = fmax_in[f];
         h_fminp[sidx] = fmin_in[f];
@@ -1285,11 +1294,13 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         {
             FeatInfo& fi = h_info[sidx];
             fi.blk_off = blk; fi.M = M; fi.pad = 0;
-            std::memset(fi.col, 0xFF, 16);
+            unsigned long long c8[2] = {~0ull, ~0ull};
+            unsigned char* colb = reinterpret_cast<unsigned char*>(c8);
             for (int v = 0; v < M; ++v) {
                 const int j = obs_slot[a + v] - fmin_in[f];
-                if (j < 16) fi.col[j] = (unsigned char)v;
+                if (j < 16) colb[j] = (unsigned char)v;
             }
+            std::memcpy(fi.col, c8, 16);
         }
         blk += (long long)(6 * M + 1) * (2 * M);
         pos += M;
@@ -1506,11 +1517,13 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
     rc = run_pipeline(c, true, nullptr);               // K1-K4 is already in the stream (ev[6] sits in front of it)
     if (rc != MSCKF_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
-    HIPCHK(c, hipEventSynchronize(c->ev[7]));
+    // the result copies go into the stream right behind the kernels: ONE host wait for kernels + copies
+    rc = msckf_get_result(c, dx, P_out, accepted, stats);
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
     c->us_total = ms * 1000.0f;
-    return msckf_get_result(c, dx, P_out, accepted, stats);
+    if (stats) stats->us_total = c->us_total;
+    return rc;
 }
 
 // ---- f1: get_valid_features -------------------------------------------------
