@@ -472,6 +472,8 @@ __global__ __launch_bounds__(T) void k_chol_tile(CholArgs c) {
 // MODE: 3 = both sweeps (K = Y S^-1), 1 = forward only (X = Y L^-T), 2 = backward only (K = X L^-1); the
 // one-sided forms serve the two-block factorisation of windows wider than one register-tiled Cholesky
 // (launch_gain_blocked) and need the unit-diagonal packed factor.  Rows may be updated in place (Kg == Y).
+template <int V> struct CTagS { static constexpr int value = V; };
+
 template <int NREG, int WAVES, int ROWS = 1, bool UNIT = false, int MODE = 3>
 __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
     static_assert(MODE == 3 || UNIT, "one-sided sweeps use the unit-diagonal packed factor");
@@ -480,10 +482,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
     double* lp = smem;                          // packed lower: (i, j) at i(i+1)/2 + j
     double* sinv = smem + (size_t)n * (n + 1) / 2;
     constexpr bool unit = UNIT;                 // the packed copy s.Lp has unit diagonal (columns scaled by 1/L_jj)
-    if (UNIT) {                                 // flat copy, many loads in flight
+    if (UNIT) {                                 // flat copy, ALL loads of a thread in flight at once: one trip to L2, not four
         const int np = n * (n + 1) / 2;
+        constexpr int PER = (64 * 3 * (64 * 3 + 1) / 2 + 64 * WAVES - 1) / (64 * WAVES);   // n <= 192
+        if (NREG <= 3 && np <= PER * 64 * WAVES) {
+            double r[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int idx = t + q * 64 * WAVES; r[q] = (idx < np) ? s.Lp[idx] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int idx = t + q * 64 * WAVES; if (idx < np) lp[idx] = r[q]; }
+        } else {
 #pragma unroll 8
-        for (int idx = t; idx < np; idx += 64 * WAVES) lp[idx] = s.Lp[idx];
+            for (int idx = t; idx < np; idx += 64 * WAVES) lp[idx] = s.Lp[idx];
+        }
     } else {
         for (int i = wv; i < n; i += WAVES)
             for (int j = lane; j <= i; j += 64) lp[i * (i + 1) / 2 + j] = s.L[(size_t)i * n + j];
@@ -502,31 +513,47 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
             const int i = lane + 64 * m;
             x[r][m] = (row0 + r < s.d && i < n) ? s.Y[(size_t)(row0 + r) * s.ldy + i] : 0.0;
         }
-    // forward sweep  L x = y
+    // Both sweeps are FULLY unrolled: with the step index a compile-time constant the LDS reads carry their column /
+    // row in the instruction's immediate offset (no address arithmetic per step), the pivot lane of v_readlane is an
+    // immediate, and only the register that holds the diagonal needs a lane mask.  A step is ~13 instructions.
+    int pb[NREG], pcol[NREG];                   // packed row starts i (i + 1) / 2 of this lane's rows (rows >= n: row 0, never used); columns
+#pragma unroll
+    for (int m = 0; m < NREG; ++m) { const int i = lane + 64 * m; pb[m] = (i < n) ? i * (i + 1) / 2 : 0; pcol[m] = (i < n) ? i : 0; }
+    // forward sweep  L x = y  (column j + 2 is requested before step j's readlane -> FMA chain runs)
     if constexpr ((MODE & 1) != 0) {
+        auto colf = [&](auto tagm, int j, double (&lv)[NREG]) {             // rows of column j, unmasked
+            constexpr int mj = decltype(tagm)::value;
 #pragma unroll
-    for (int mj = 0; mj < NREG; ++mj) {
-#pragma unroll 4
-        for (int jj = 0; jj < 64; ++jj) {
-            const int j = mj * 64 + jj;
-            if (j >= n) break;
-            double lv[NREG];
+            for (int m = 0; m < NREG; ++m) lv[m] = (m >= mj) ? lp[pb[m] + j] : 0.0;
+        };
+        auto fwd_seg = [&](auto tagm) {
+            constexpr int mj = decltype(tagm)::value;
+            double lb[3][NREG];                                              // columns j, j + 1, j + 2 in slots j % 3, ... (no register moves)
+            colf(tagm, mj * 64, lb[0]); colf(tagm, mj * 64 + 1, lb[1]);
 #pragma unroll
-            for (int m = 0; m < NREG; ++m) {
-                const int i = lane + 64 * m;
-                lv[m] = (m >= mj && i > j && i < n) ? lp[i * (i + 1) / 2 + j] : 0.0;
+            for (int jj = 0; jj < 64; ++jj) {
+                const int j = mj * 64 + jj;
+                if (j < n) {
+                    colf(tagm, j + 2, lb[(jj + 2) % 3]);                     // (past column n - 1: words of the factor's tail, never used)
+                    double lv[NREG];
+#pragma unroll
+                    for (int m = 0; m < NREG; ++m) lv[m] = (m == mj) ? ((lane > jj) ? lb[jj % 3][m] : 0.0) : lb[jj % 3][m];
+                    const double sj = unit ? 1.0 : sinv[j];
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) {
+                        const double xj = unit ? readlane_d(x[r][mj], jj) : readlane_d(x[r][mj], jj) * sj;
+                        if (!unit && lane == jj) x[r][mj] = xj;
+#pragma unroll
+                        for (int m = 0; m < NREG; ++m)
+                            if (m >= mj) x[r][m] -= lv[m] * xj;
+                    }
+                }
             }
-            const double sj = unit ? 1.0 : sinv[j];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const double xj = unit ? readlane_d(x[r][mj], jj) : readlane_d(x[r][mj], jj) * sj;
-                if (!unit && lane == jj) x[r][mj] = xj;
-#pragma unroll
-                for (int m = 0; m < NREG; ++m)
-                    if (m >= mj) x[r][m] -= lv[m] * xj;
-            }
-        }
-    }
+        };
+        fwd_seg(CTagS<0>{});
+        if constexpr (NREG > 1) fwd_seg(CTagS<1>{});
+        if constexpr (NREG > 2) fwd_seg(CTagS<2>{});
+        if constexpr (NREG > 3) fwd_seg(CTagS<3>{});
     }
     // unit-diagonal factor L' = L D^-1:  L x = y  <=>  L' (D x) = y  and  L^T k = x  <=>  L'^T k = D^-1 x,
     // so the two sweeps need no per-step scaling, just D^-2 in between (D^-1 after a forward-only sweep
@@ -541,31 +568,49 @@ __global__ __launch_bounds__(64 * WAVES) void k_solve_lds(SolveArgs s) {
                 x[r][m] *= (MODE == 3) ? di * di : di;
             }
     }
-    // backward sweep  L^T k = x
+    // backward sweep  L^T k = x  (row j of L: contiguous in the packed factor; row j - 2 requested ahead)
     if constexpr ((MODE & 2) != 0) {
+        int nb = n;
+        asm volatile("" : "+s"(nb));                                        // (keeps the forward sweep's 192 predicates from being kept alive)
+        auto rowb = [&](auto tagm, int j, double (&lv)[NREG]) {
+            constexpr int mj = decltype(tagm)::value;
+            const double* rowj = lp + (j >= 0 ? j * (j + 1) / 2 : 0);
 #pragma unroll
-    for (int mj = NREG - 1; mj >= 0; --mj) {
-#pragma unroll 4
-        for (int jj = 63; jj >= 0; --jj) {
-            const int j = mj * 64 + jj;
-            if (j >= n) continue;
-            double lv[NREG];
+            for (int m = 0; m < NREG; ++m) lv[m] = (m <= mj) ? rowj[pcol[m]] : 0.0;   // (lanes at / right of the diagonal: masked below)
+        };
+        auto bwd_seg = [&](auto tagm) {
+            constexpr int mj = decltype(tagm)::value;
+            if (mj * 64 >= nb) return;
+            const int jtop = min(63, nb - 1 - mj * 64);
+            // rows j, j - 1, j - 2 in slots j % 3, ...: the first two are requested here, whatever row the sweep starts at
+            double lb[3][NREG];
 #pragma unroll
-            for (int m = 0; m < NREG; ++m) {
-                const int i = lane + 64 * m;
-                lv[m] = (m <= mj && i < j) ? lp[j * (j + 1) / 2 + i] : 0.0;
+            for (int q = 0; q < 3; ++q)
+                if ((jtop % 3) == q) { rowb(tagm, mj * 64 + jtop, lb[q]); rowb(tagm, mj * 64 + jtop - 1, lb[(q + 2) % 3]); }
+#pragma unroll
+            for (int jj = 63; jj >= 0; --jj) {
+                const int j = mj * 64 + jj;
+                if (j < nb) {
+                    rowb(tagm, j - 2, lb[(jj + 1) % 3]);                     // (jj - 2) mod 3
+                    double lv[NREG];
+#pragma unroll
+                    for (int m = 0; m < NREG; ++m) lv[m] = (m == mj) ? ((lane < jj) ? lb[jj % 3][m] : 0.0) : lb[jj % 3][m];
+                    const double sj = unit ? 1.0 : sinv[j];
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) {
+                        const double kj = unit ? readlane_d(x[r][mj], jj) : readlane_d(x[r][mj], jj) * sj;
+                        if (!unit && lane == jj) x[r][mj] = kj;
+#pragma unroll
+                        for (int m = 0; m < NREG; ++m)
+                            if (m <= mj) x[r][m] -= lv[m] * kj;
+                    }
+                }
             }
-            const double sj = unit ? 1.0 : sinv[j];
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const double kj = unit ? readlane_d(x[r][mj], jj) : readlane_d(x[r][mj], jj) * sj;
-                if (!unit && lane == jj) x[r][mj] = kj;
-#pragma unroll
-                for (int m = 0; m < NREG; ++m)
-                    if (m <= mj) x[r][m] -= lv[m] * kj;
-            }
-        }
-    }
+        };
+        if constexpr (NREG > 3) bwd_seg(CTagS<3>{});
+        if constexpr (NREG > 2) bwd_seg(CTagS<2>{});
+        if constexpr (NREG > 1) bwd_seg(CTagS<1>{});
+        bwd_seg(CTagS<0>{});
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
