@@ -28,26 +28,36 @@ struct GemmArgs {
                                   // 2: A[M][K] is upper triangular (k >= m)
 };
 
-// One wavefront per 16x16 tile of C.  The four 16-lane groups of the MFMA each
-// take a contiguous quarter of the K range (the sum over k is order free), so a
-// lane streams contiguous doubles of its A row (and of its B row when transB).
-__global__ __launch_bounds__(64) void k_gemm_f64(GemmArgs g) {
-    const int lane = threadIdx.x;
+// One workgroup of GEMM_WAVES wavefronts per 16x16 tile of C: the K range is cut into GEMM_WAVES * 4 contiguous
+// pieces -- one per wavefront and 16-lane group of the MFMA (the sum over k is order free) -- so a lane streams
+// contiguous doubles of its A row (and of its B row when transB), and a 180-deep product is 12 dependent MFMAs per
+// wavefront instead of 45.  The partial tiles meet in LDS; wavefront w finishes rows {lane >> 4 + 4 w}.
+#ifndef MSCKF_GEMM_WAVES
+#define MSCKF_GEMM_WAVES 4
+#endif
+constexpr int GEMM_WAVES = MSCKF_GEMM_WAVES;   // 4 or 8
+__global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f64(GemmArgs g) {
+    __shared__ double sAcc[GEMM_WAVES][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
-    const int r = lane & 15, grp = lane >> 4;
+    const int r = lane & 15, grp = wv * 4 + (lane >> 4);
+    // the addend of this wavefront's share of the epilogue: requested first, used last
+    const int ocol = n0 + (lane & 15), orow = m0 + (lane >> 4) + 4 * wv;
+    const bool ook = wv < 4 && orow < g.M && ocol < g.N;              // (the first four wavefronts finish the tile)
+    double c0 = 0.0;
+    if (g.C0 && ook) c0 = g.C0[(size_t)orow * g.ldc0 + ocol];
     int kbeg = 0;
     if (g.tri == 1) kbeg = n0;
     else if (g.tri == 2) kbeg = m0;
     const int klen = g.K - kbeg;
-    const int kq = (klen + 3) / 4;                 // per-group chunk
+    const int kq = (klen + 4 * GEMM_WAVES - 1) / (4 * GEMM_WAVES);   // per-group piece
     const int k_lo = kbeg + grp * kq;
     const int k_hi = min(g.K, k_lo + kq);
     const int arow = m0 + r, bcol = n0 + r;
     const bool aok = arow < g.M, bok = bcol < g.N;
     const double* ap = g.A + (size_t)arow * g.lda;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
-    // GEMM_TRIP k-steps per trip, all loads of a trip issued before its first MFMA: the loop is bound
-    // by the global-load round trip (K = 180 is 45 doubles per lane), so fewer, wider trips win
+    // GEMM_TRIP k-steps per trip, all loads of a trip issued before its first MFMA (K <= 256 is one trip)
     constexpr int GEMM_TRIP = 16;
     if (g.transB) {
         const double* bp = g.B + (size_t)bcol * g.ldb;
@@ -78,16 +88,17 @@ __global__ __launch_bounds__(64) void k_gemm_f64(GemmArgs g) {
         }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-    const int col = n0 + (lane & 15);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + (lane >> 4) + 4 * i;
-        if (row < g.M && col < g.N) {
-            double x = g.alpha * acc[i];
-            if (g.C0) x += g.beta * g.C0[(size_t)row * g.ldc0 + col];
-            if (row == col) x += g.diag_add;
-            g.C[(size_t)row * g.ldc + col] = x;
-        }
+    for (int i = 0; i < 4; ++i) sAcc[wv][i][lane] = acc[i];
+    __syncthreads();
+    if (ook) {
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < GEMM_WAVES; ++w) x += sAcc[w][wv & 3][lane];   // register wv of every partial tile: rows (lane >> 4) + 4 wv
+        x *= g.alpha;
+        if (g.C0) x += g.beta * c0;
+        if (orow == ocol) x += g.diag_add;
+        g.C[(size_t)orow * g.ldc + ocol] = x;
     }
 }
 

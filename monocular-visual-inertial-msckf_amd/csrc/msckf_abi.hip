@@ -797,7 +797,7 @@ int launch_feature(msckf_ctx* c) {
 void gemm(msckf_ctx* c, const double* A, int lda, const double* B, int ldb, const double* C0, int ldc0,
           double* C, int ldc, int M, int N, int K, double alpha, double beta, double diag, int transB, int tri) {
     GemmArgs g{A, lda, B, ldb, C0, ldc0, C, ldc, M, N, K, alpha, beta, diag, transB, tri};
-    hipLaunchKernelGGL(k_gemm_f64, dim3((N + 15) / 16, (M + 15) / 16), dim3(64), 0, c->stream, g);
+    hipLaunchKernelGGL(k_gemm_f64, dim3((N + 15) / 16, (M + 15) / 16), dim3(64 * GEMM_WAVES), 0, c->stream, g);
 }
 
 // One-sided / two-sided triangular sweeps over the rows of X (in place) with the unit-diagonal packed factor Lp.
