@@ -33,7 +33,7 @@ struct GemmArgs {
 // contiguous doubles of its A row (and of its B row when transB), and a 180-deep product is 12 dependent MFMAs per
 // wavefront instead of 45.  The partial tiles meet in LDS; wavefront w finishes rows {lane >> 4 + 4 w}.
 #ifndef MSCKF_GEMM_WAVES
-#define MSCKF_GEMM_WAVES 4
+#define MSCKF_GEMM_WAVES 8
 #endif
 constexpr int GEMM_WAVES = MSCKF_GEMM_WAVES;   // 4 or 8
 __global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f64(GemmArgs g) {

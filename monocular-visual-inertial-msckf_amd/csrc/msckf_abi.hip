@@ -452,7 +452,8 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
         c->leaf_nf = (!wide_leaf && F >= LS_BIG_BATCH) ? 12 : 8;
         const int unit = c->leaf_nf * fpb;
-        int want = (F + 239) / 240;
+        static const int leaf_target = [] { const char* e = std::getenv("MSCKF_LEAF_TARGET"); return e ? std::max(1, atoi(e)) : 240; }();
+        int want = (F + leaf_target - 1) / leaf_target;
         want = ((want + unit - 1) / unit) * unit;
         leaf_feats = std::max(std::min(unit, 128), std::min(want, 128));
         if (c->cfg.leaf_rows > 0) leaf_feats = 128;
