@@ -336,8 +336,18 @@ def bench_sharded(args, world, rank, local_rank):
         prob = synth.make_problem(N, F_total, M, seed=0)
         eng = UpdateEngine(max_clones=N, max_features=F_total, max_track=max(M, 2), device=local_rank)
         uid = exchange_unique_id(eng, rank, world, id_base + tag)
-        drv = RcclShardedUpdate(eng, rank, world, uid)
-        drv.load(prob)                                       # every rank keeps its shard (and the state) resident
+        # librccl prints its version banner with plain printf at communicator creation: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            drv = RcclShardedUpdate(eng, rank, world, uid)
+            drv.load(prob)                                   # every rank keeps its shard (and the state) resident
+            drv.step()
+            eng.sync()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         tbuf = eng.comm_buffer(drv.count * (world + 1) + 8) + 8 * drv.count * (world + 1)   # one double behind the exchange buffers
 
         def barrier():

@@ -237,7 +237,21 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     const int zero_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64;
     const int lco = cq + CL * rq;
     // ---- P2P progress words: [slot] = (fold index << 32) | rows done (first row not yet done by that fold) --------
-    volatile long long* prog = reinterpret_cast<volatile long long*>(smem + (size_t)nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + 2);
+    // (read and written with explicit ds instructions: a volatile pointer into LDS compiles to FLAT accesses with
+    //  vmcnt waits, which is what made the first version of this variant slow)
+    const unsigned prog_addr = (unsigned)(size_t)(smem + (size_t)nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + 2);
+    auto prog_load = [&](int slot) -> long long {          // one lane asks, everybody gets the word
+        double v;
+        const unsigned a = prog_addr + (unsigned)slot * 8u;
+        asm volatile("s_mov_b64 exec, 1\n\tds_read_b64 %0, %1\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+        return ((long long)hi << 32) | (unsigned int)lo;
+    };
+    auto prog_store = [&](int slot, long long w) {         // (called where the whole wavefront is active)
+        const unsigned a = prog_addr + (unsigned)slot * 8u;
+        const double v = __longlong_as_double(w);
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(a), "v"(v) : "memory");
+    };
     const int fbeg = nd.fold_begin + ((nd.fold_end > nd.fold_begin && f0.t0 == 0) ? 1 : 0);   // first fold that runs steps
     int cur_fi = 0;                      // fold this wavefront is running
     int safe_row = 0;                    // rows < safe_row are clear of every earlier fold (as of the last look)
@@ -248,13 +262,13 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             // issue order: the word lands behind this step's R entries.
             asm volatile("" ::: "memory");
             const int bound = (done == 0x7fffffff) ? done : min(done, safe_row);
-            if (lane == 0) prog[fs] = ((long long)cur_fi << 32) | (unsigned int)bound;
+            prog_store(fs, ((long long)cur_fi << 32) | (unsigned int)bound);
         }
     };
     auto peek_prev = [&]() -> long long {        // the word of the fold right in front (issued early, used after the dots)
         if constexpr (P2P) {
             const int pf = cur_fi - 1;
-            return (pf >= fbeg) ? prog[(pf - fbeg) % NF] : (((long long)0x7fffffff) << 32);
+            return (pf >= fbeg) ? prog_load((pf - fbeg) % NF) : (((long long)0x7fffffff) << 32);
         }
         return 0;
     };
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
                     for (int j = 1; j < NF; ++j) {
                         const int qf = cur_fi - j;
                         if (qf >= fbeg) {
-                            const long long wj = prog[(qf - fbeg) % NF];
+                            const long long wj = prog_load((qf - fbeg) % NF);
                             const int idx = (int)(wj >> 32), done = (int)(wj & 0xffffffffLL);
                             const int lim = (idx > qf) ? 0x7fffffff : (idx == qf ? done : 0);   // finished / running / not started
                             safe = min(safe, lim);
