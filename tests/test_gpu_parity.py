@@ -57,6 +57,8 @@ def test_golden(eng, case):
     (32, 200, 8, 27, {}),                      # dc = 192: just past one register-tiled Cholesky -> two-block K6 (160 + 32)
     (45, 300, 10, 28, {"outlier_fraction": 0.05, "outlier_px": 500.0}),   # two-block K6, 160 + 110
     (53, 200, 6, 29, {}),                      # dc = 318: the widest two-block window (160 + 158)
+    (2, 6, 2, 30, {}),                         # dc = 12: one partly filled 16 x 16 block in the Cholesky
+    (3, 12, 3, 33, {}),                        # dc = 18: two blocks, the second with two columns
 ])
 def test_against_oracle(eng, N, F, M, seed, kw):
     from msckf_amd import synth
