@@ -108,6 +108,8 @@ struct msckf_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8]{};
     std::string last_error;
+    double hp[12] = {0};                  // MSCKF_HOSTPROF=1: accumulated host-side phase times of msckf_update (us)
+    long hp_calls = 0;
     // capacities
     int maxN = 0, maxF = 0, maxM = 0;
     // current problem
@@ -1139,6 +1141,13 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
 
 void msckf_destroy(msckf_ctx* c) {
     if (!c) return;
+    if (c->hp_calls > 0 && std::getenv("MSCKF_HOSTPROF")) {
+        const double n = (double)c->hp_calls;
+        std::fprintf(stderr, "msckf_update host phases, us per call over %ld calls: set_state %.1f | validate %.1f, sort %.1f, gather %.1f, "
+                     "upload + K1-K4 launch %.1f, plan %.1f, plan upload %.1f | K5-K7 launches %.1f | wait for device + copies %.1f, "
+                     "unpack %.1f | whole call %.1f\n", c->hp_calls, c->hp[0] / n, c->hp[1] / n, c->hp[2] / n, c->hp[3] / n, c->hp[4] / n,
+                     c->hp[5] / n, c->hp[6] / n, c->hp[7] / n, c->hp[8] / n, c->hp[9] / n, c->hp[10] / n);
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
@@ -1238,6 +1247,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         }
         fmin_in[f] = lo; fmax_in[f] = hi;
     }
+    const double tv = now_us();
     if (c->n_chi2 <= 2 * Mmax) return MSCKF_ERR_ARG;
     const int sumM = view_ptr[F];
     c->F = F; c->sumM = sumM; c->Mmax = Mmax;            // validated: commit the batch size
@@ -1249,6 +1259,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
         for (int f = 0; f < F; ++f) c->perm[cnt[(size_t)fmin_in[f] * N + fmax_in[f]]++] = f;
     }
+    const double ts = now_us();
     // arena layout (8-byte aligned pieces): doubles first, then the 64-bit offsets, then the ints
     const size_t o_uv = 0, o_base = o_uv + (size_t)sumM * 16, o_m = o_base + (size_t)F * 24, o_rho = o_m + (size_t)F * 24;
     const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
@@ -1370,6 +1381,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     }
     if (!c->oneshot) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->us_h2d += (float)((t2 - t1) + (now_us() - t3));
+    c->hp[1] += tv - t0; c->hp[2] += ts - tv; c->hp[3] += t1 - ts; c->hp[4] += t2 - t1; c->hp[5] += t3 - t2; c->hp[6] += now_us() - t3;
     c->have_features = true;
     return MSCKF_OK;
 }
@@ -1437,6 +1449,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
         HIPCHK(c, hipMemcpyAsync(c->hRes, c->dResArena.p, bytes, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double tsync = now_us();
     int counters[4] = {0, 0, 0, 0};
     int status[4] = {0};
     std::vector<unsigned char> acc_sorted;
@@ -1460,6 +1473,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
         else HIPCHK(c, hipMemcpy(P_out, c->dP.p, d * d * 8, hipMemcpyDeviceToHost));
     }
     c->us_d2h = (float)(now_us() - t0);
+    c->hp[8] += tsync - t0; c->hp[9] += now_us() - tsync;
     if (st) {
         std::memset(st, 0, sizeof(*st));
         st->n_features = c->F - counters[3]; st->n_accepted = n_acc;
@@ -1499,10 +1513,12 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
                  const double* idp_base, const double* idp_m, const double* idp_rho, const double* chi2_crit,
                  int32_t n_crit, double* dx, double* P_out, uint8_t* accepted, msckf_stats* stats) {
     if (!c) return MSCKF_ERR_ARG;
+    const double tu0 = now_us();
     c->defer_state_sync = F > 0;
     int rc = msckf_set_state(c, N, P, cam_R, cam_t, cam_R0, cam_t0, gravity, Kinv, sigma, chi2_crit, n_crit);
     c->defer_state_sync = false;
     if (rc != MSCKF_OK) return rc;
+    c->hp[0] += now_us() - tu0;
     c->oneshot = F > 0;
     rc = msckf_set_features(c, F, view_ptr, obs_uv, obs_slot, idp_base, idp_m, idp_rho);
     c->oneshot = false;
@@ -1515,15 +1531,19 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
         if (stats) { std::memset(stats, 0, sizeof(*stats)); }
         return MSCKF_NOOP;
     }
+    const double tu1 = now_us();
     rc = run_pipeline(c, true, nullptr);               // K1-K4 is already in the stream (ev[6] sits in front of it)
     if (rc != MSCKF_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    c->hp[7] += now_us() - tu1;
     // the result copies go into the stream right behind the kernels: ONE host wait for kernels + copies
     rc = msckf_get_result(c, dx, P_out, accepted, stats);
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
     c->us_total = ms * 1000.0f;
     if (stats) stats->us_total = c->us_total;
+    c->hp[10] += now_us() - tu0;
+    ++c->hp_calls;
     return rc;
 }
 
