@@ -452,7 +452,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         const bool wide_leaf = 6 * max_span + 1 > 64;
         const int rb = wide_leaf ? LSweepGeom<6, LS_RS6>::RB : LSweepGeom<4, LS_RS4>::RB;
         const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
-        c->leaf_nf = (!wide_leaf && F >= LS_BIG_BATCH) ? 12 : 8;
+        c->leaf_nf = (F >= LS_BIG_BATCH) ? 12 : 8;
         const int unit = c->leaf_nf * fpb;
         static const int leaf_target = [] { const char* e = std::getenv("MSCKF_LEAF_TARGET"); return e ? std::max(1, atoi(e)) : 240; }();
         int want = (F + leaf_target - 1) / leaf_target;
@@ -677,8 +677,13 @@ int launch_leaves_band(msckf_ctx* c) {
     }
     if (c->leaf_wide) {
         a.wide = 1;
-        const size_t lds = lsweep_lds_bytes<6, LS_RS6>(SWEEP_NW);
-        hipLaunchKernelGGL((k_lsweep<SWEEP_NW, 6, LS_RS6>), grid, block, lds, c->stream, a);
+        if (c->leaf_nf == 12) {          // large batches: twelve row blocks in flight (three wavefronts per SIMD)
+            const size_t lds = lsweep_lds_bytes<6, LS_RS6>(12);
+            hipLaunchKernelGGL((k_lsweep<12, 6, LS_RS6, false>), grid, dim3(64 * 12), lds, c->stream, a);
+        } else {
+            const size_t lds = lsweep_lds_bytes<6, LS_RS6>(SWEEP_NW);
+            hipLaunchKernelGGL((k_lsweep<SWEEP_NW, 6, LS_RS6>), grid, block, lds, c->stream, a);
+        }
     }
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
@@ -1092,6 +1097,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 4, LS_RS4, false>), FOLD_LDS_BYTES, "k_lsweep<12,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 6, LS_RS6>), FOLD_LDS_BYTES, "k_lsweep<6> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 6, LS_RS6, false>), FOLD_LDS_BYTES, "k_lsweep<12,6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 4>), FOLD_LDS_BYTES, "k_wsweep<4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 6>), FOLD_LDS_BYTES, "k_wsweep<6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_chol<512>), LDS_MAX_BYTES - 1024, "k_chol LDS attribute");
