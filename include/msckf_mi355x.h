@@ -51,7 +51,8 @@ extern "C" {
 #define MSCKF_ERR_DUP_SLOT (-6)     /* a track observes the same clone slot twice           */
 
 #define MSCKF_FLAG_TREE_PLAN 1      /* K5: always the merge tree (default: the band pipeline
-                                       whenever every track spans <= 10 clone slots)        */
+                                       whenever every track spans <= 16 clone slots,
+                                       see msckf_band_rule)                                */
 
 #define MSCKF_DTYPE_F64 0
 #define MSCKF_DTYPE_F32 1
@@ -254,7 +255,7 @@ int msckf_export_block(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_acc
 int msckf_run_merge_gain(msckf_ctx* ctx, const void* blocks, int32_t n_blocks, int device_ptr,
                          int32_t total_accepted /* sum of the shards' n_accepted */);
 
-/* Group exchange (band pipeline, every track spans <= 10 slots and N <= 37): instead of its root block a
+/* Group exchange (the 60-column band pipeline: every track spans <= 10 slots and N <= 37, msckf_band_rule): instead of its root block a
  * rank exports the triangles of its first-slot groups, one record of N flags, its accepted count and N slots
  * of 60 x 61 doubles (the triangle of group s covers the fixed window of min(10, N - s) slots).  The rank then stops in front
  * of its root sweep (msckf_run_compress) and the root folds, per group, the triangles of all shards and

@@ -823,9 +823,9 @@ void launch_tri_sweep(msckf_ctx* c, double* X, int ldx, int rows, const double* 
     else hipLaunchKernelGGL((k_solve_lds<3, WV, 1, true, MODE>), grid, block, lds_need, c->stream, a);
 }
 
-// K6 for windows wider than one register-tiled Cholesky (4 CHOL_TILE_MAX_NT < dc <= 2 GAIN_BLK): S is factored
+// K6 for windows wider than one single-workgroup Cholesky (4 CHOL_TILE_MAX_NT < dc <= 2 GAIN_BLK): S is factored
 // as a 2 x 2 block matrix, S = [A B^T; B C], L = [L11 0; W L22] with W = B L11^-T, L22 L22^T = C - W W^T; both
-// diagonal factors come from k_chol_tile, everything else is triangular sweeps with the factor in LDS and MFMA
+// diagonal factors come from launch_chol_small (k_chol16), everything else is triangular sweeps with the factor in LDS and MFMA
 // GEMMs.  K = Y S^-1 row by row:  X1 = Y1 L11^-T,  K2 = (Y2 - X1 W^T) L22^-T L22^-1,  K1 = (X1 - K2 W) L11^-1.
 constexpr int GAIN_BLK = 160;
 // Cholesky of a matrix of at most 4 * CHOL_TILE_MAX_NT rows, one workgroup.
