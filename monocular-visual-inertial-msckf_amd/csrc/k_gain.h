@@ -124,13 +124,20 @@ __device__ __forceinline__ float ld32(const void* p, size_t i, int f32) {
 }
 
 template <bool AF, bool C0F>      // A / C0 stored as float (else double); B is always one of the fp64 operands
-__global__ __launch_bounds__(64) void k_gemm_f32(Gemm32Args g) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f32(Gemm32Args g) {
+    // as k_gemm_f64: GEMM_WAVES wavefronts per tile, the K range in GEMM_WAVES * 4 contiguous pieces, partial tiles summed in LDS
+    __shared__ float sAcc[GEMM_WAVES][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
-    const int r = lane & 15, grp = lane >> 4;
+    const int r = lane & 15, grp = wv * 4 + (lane >> 4);
+    // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg; wavefront w < 4 finishes register w
+    const int ocol = n0 + (lane & 15), orow = m0 + 4 * (lane >> 4) + (wv & 3);
+    const bool ook = wv < 4 && orow < g.M && ocol < g.N;
+    float c0 = 0.f;
+    if (g.C0 && ook) c0 = ld32(g.C0, (size_t)orow * g.ldc0 + ocol, C0F);
     const int kbeg = (g.tri == 1) ? n0 : 0;
     const int klen = g.K - kbeg;
-    const int kq = (klen + 3) / 4;
+    const int kq = (klen + 4 * GEMM_WAVES - 1) / (4 * GEMM_WAVES);
     const int k_lo = kbeg + grp * kq;
     const int k_hi = min(g.K, k_lo + kq);
     const int arow = m0 + r, bcol = n0 + r;
@@ -149,16 +156,16 @@ __global__ __launch_bounds__(64) void k_gemm_f32(Gemm32Args g) {
 #pragma unroll
         for (int u = 0; u < TRIP; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
     }
-    // C/D layout of v_mfma_f32_16x16x4_f32: col = lane & 15, row = 4 * (lane >> 4) + reg
-    const int col = n0 + (lane & 15);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = m0 + 4 * (lane >> 4) + i;
-        if (row < g.M && col < g.N) {
-            float x = g.alpha * acc[i];
-            if (g.C0) x += g.beta * ld32(g.C0, (size_t)row * g.ldc0 + col, C0F);
-            static_cast<float*>(g.C)[(size_t)row * g.ldc + col] = x;
-        }
+    for (int i = 0; i < 4; ++i) sAcc[wv][i][lane] = acc[i];
+    __syncthreads();
+    if (ook) {
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < GEMM_WAVES; ++w) x += sAcc[w][wv & 3][lane];
+        x *= g.alpha;
+        if (g.C0) x += g.beta * c0;
+        static_cast<float*>(g.C)[(size_t)orow * g.ldc + ocol] = x;
     }
 }
 

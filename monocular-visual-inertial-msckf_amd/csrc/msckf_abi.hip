@@ -940,9 +940,9 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
                           void* C, int ldc, int M_, int N_, int K_, float alpha, float beta, int tri) {
             Gemm32Args g{A, lda, af, B, ldb, bf, C0, ldc0, c0f, C, ldc, 1, M_, N_, K_, alpha, beta, 1, tri};
             const dim3 grid((N_ + 15) / 16, (M_ + 15) / 16);
-            if (!af && !c0f) hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, dim3(64), 0, c->stream, g);
-            else if (af && !c0f) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, dim3(64), 0, c->stream, g);
-            else hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, dim3(64), 0, c->stream, g);
+            if (!af && !c0f) hipLaunchKernelGGL((k_gemm_f32<false, false>), grid, dim3(64 * GEMM_WAVES), 0, c->stream, g);
+            else if (af && !c0f) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, dim3(64 * GEMM_WAVES), 0, c->stream, g);
+            else hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, dim3(64 * GEMM_WAVES), 0, c->stream, g);
         };
         float* B2f = reinterpret_cast<float*>(B2);
         float* Df = reinterpret_cast<float*>(D);
