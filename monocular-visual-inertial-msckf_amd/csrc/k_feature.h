@@ -67,6 +67,7 @@ __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
     return head + R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2) + 8;
 }
 
+template <int V> struct FTag { static constexpr int value = V; };
 // RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
 template <int RMAX>
 __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs p) {      // (tracks of 12-15 views: 3 wavefronts per SIMD, the LDS footprint allows 9 per CU)
@@ -471,6 +472,60 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     // entries travel by v_readlane, no LDS round trip per step); the extra row R2 ends with
     // -gamma in the corner
     int bad = 0;
+    double gam = 0.0;
+    if constexpr (RMAX <= 32) {
+        // Two matrix rows per lane: lane l < 16 keeps row l in srow and takes row l + 16 into sb, so every row sits in
+        // the first 16-lane DPP row and the pivot row reaches all of them folded into the update itself
+        // (v_fmac_f64_dpp ... row_newbcast:k): two instructions per (pivot, column) instead of two v_readlane and an FMA.
+        double sb[RMAX];
+        {
+            const int src4 = ((lane & 15) + 16) * 4;
+#pragma unroll
+            for (int j = 0; j < RMAX; ++j) {
+                const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(srow[j]));
+                const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(srow[j]));
+                sb[j] = __hiloint2double(hi, lo);
+            }
+        }
+        const int l15 = lane & 15;
+        auto pivot_step = [&](auto tagk) {
+            constexpr int k = decltype(tagk)::value;
+            if (k >= rank && k < R2 && !bad) {
+                const double piv = (k < 16) ? readlane_d(srow[k], k & 15) : readlane_d(sb[k], k & 15);
+                if (!(piv > 0.0)) {
+                    bad = 1;
+                } else {
+                    const double rp = fast_rcp(piv);
+                    const double wB = (l15 + 16 > k) ? -(sb[k] * rp) : 0.0;           // rows 16 .. 31
+                    if constexpr (k < 16) {
+                        const double wA = (l15 > k) ? -(srow[k] * rp) : 0.0;          // rows 0 .. 15; the pivot row is lane k's srow
+#pragma unroll
+                        for (int j = k + 1; j < RMAX; ++j)
+                            if (j <= R2) {
+                                fmac_row_bcast16<k>(sb[j], srow[j], wB);
+                                fmac_row_bcast16<k>(srow[j], srow[j], wA);
+                            }
+                    } else {                                                             // rows 0 .. 15 are done; the pivot row is lane k - 16's sb
+#pragma unroll
+                        for (int j = k + 1; j < RMAX; ++j)
+                            if (j <= R2) fmac_row_bcast16<(k & 15)>(sb[j], sb[j], wB);
+                    }
+                }
+            }
+        };
+        pivot_step(FTag<0>{}); pivot_step(FTag<1>{}); pivot_step(FTag<2>{}); pivot_step(FTag<3>{}); pivot_step(FTag<4>{});
+        pivot_step(FTag<5>{}); pivot_step(FTag<6>{}); pivot_step(FTag<7>{}); pivot_step(FTag<8>{}); pivot_step(FTag<9>{});
+        pivot_step(FTag<10>{}); pivot_step(FTag<11>{}); pivot_step(FTag<12>{}); pivot_step(FTag<13>{}); pivot_step(FTag<14>{});
+        pivot_step(FTag<15>{}); pivot_step(FTag<16>{}); pivot_step(FTag<17>{}); pivot_step(FTag<18>{}); pivot_step(FTag<19>{});
+        pivot_step(FTag<20>{}); pivot_step(FTag<21>{}); pivot_step(FTag<22>{});
+        if constexpr (RMAX > 24) {
+            pivot_step(FTag<23>{}); pivot_step(FTag<24>{}); pivot_step(FTag<25>{}); pivot_step(FTag<26>{}); pivot_step(FTag<27>{});
+            pivot_step(FTag<28>{}); pivot_step(FTag<29>{}); pivot_step(FTag<30>{});
+        }
+#pragma unroll
+        for (int j = 0; j < RMAX; ++j)
+            if (j == R2) gam = -((j < 16) ? readlane_d(srow[j], j & 15) : readlane_d(sb[j], j & 15));
+    } else {
 #pragma unroll
     for (int k = 0; k < RMAX - 1; ++k) {
         if (k >= rank && k < R2 && !bad) {
@@ -485,10 +540,10 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
             }
         }
     }
-    double gam = 0.0;
 #pragma unroll
     for (int j = 0; j < RMAX; ++j)
         if (j == R2) gam = -readlane_d(srow[j], R2);
+    }
     if (p.stamps) tq[6] = wall_clock64();
     bool ok = (q >= 1) && (bad == 0) && (q < p.n_chi2);
     if (ok) ok = (gam <= p.chi2[q]);

@@ -713,13 +713,6 @@ __device__ __forceinline__ double row_bcast16(double x) {      // lane P of ever
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + P, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-// d += (lane P of the 16-lane row of src) * w: one DP instruction with the row broadcast folded in (64-bit DPP knows
-// row_newbcast only, which is exactly this).  The s_nop covers the VALU-write -> DPP-read hazard, which the compiler's
-// hazard recogniser does not see inside inline assembly.
-template <int P>
-__device__ __forceinline__ void fmac_row_bcast16(double& d, double src, double w) {
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(w), "i"(P));
-}
 __device__ __forceinline__ unsigned lds_addr(const volatile void* p) { return (unsigned)(size_t)p; }
 
 __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {

@@ -70,6 +70,13 @@ __device__ __forceinline__ double fast_norm(double s, double y) {
     return fma(fma(-n, n, s), 0.5 * y, n);
 }
 
+// d += (lane P of the 16-lane row of src) * w: one DP instruction with the row broadcast folded in (64-bit DPP knows
+// row_newbcast only, which is exactly this).  The s_nop covers the VALU-write -> DPP-read hazard, which the compiler's
+// hazard recogniser does not see inside inline assembly.
+template <int P>
+__device__ __forceinline__ void fmac_row_bcast16(double& d, double src, double w) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(w), "i"(P));
+}
 __device__ __forceinline__ double lane_bcast(double x, int lane) { return readlane_d(x, lane); }
 
 }  // namespace msckf
