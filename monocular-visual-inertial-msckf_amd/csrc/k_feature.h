@@ -474,41 +474,57 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     int bad = 0;
     double gam = 0.0;
     if constexpr (RMAX <= 32) {
-        // Two matrix rows per lane: lane l < 16 keeps row l in srow and takes row l + 16 into sb, so every row sits in
-        // the first 16-lane DPP row and the pivot row reaches all of them folded into the update itself
-        // (v_fmac_f64_dpp ... row_newbcast:k): two instructions per (pivot, column) instead of two v_readlane and an FMA.
-        double sb[RMAX];
-        {
-            const int src4 = ((lane & 15) + 16) * 4;
+        // All 64 lanes: lane (g, l) = (lane >> 4, lane & 15) holds rows l (ea) and l + 16 (eb) of the columns j = 4 jj + g.
+        // A pivot step is then: pivot by v_readlane, the multipliers (column k, which group k & 3 holds) by one
+        // ds_bpermute pair per row slot, and the update with the pivot row folded in (v_fmac_f64_dpp row_newbcast:k & 15,
+        // the pivot row of MY columns sits in MY 16-lane row) -- two DP instructions per (pivot, column quad) instead of
+        // two v_readlane and an FMA per (pivot, column).  Columns left of the pivot are never read again, so they are
+        // not masked out; rows at or above it are (their multiplier is zero).
+        double* sT = sZ + 3 * C6;                       // the staging area of K4 / the gate is free now
+        const int ldT = R2 + 3;
+        __syncthreads();
+        if (lane <= R2) {
 #pragma unroll
-            for (int j = 0; j < RMAX; ++j) {
-                const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(srow[j]));
-                const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(srow[j]));
-                sb[j] = __hiloint2double(hi, lo);
-            }
+            for (int j = 0; j < RMAX; ++j)
+                if (j <= R2) sT[lane * ldT + j] = srow[j];
         }
-        const int l15 = lane & 15;
+        __syncthreads();
+        const int g = lane >> 4, l15 = lane & 15;
+        double ea[8], eb[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = 4 * jj + g;
+            ea[jj] = (j <= R2 && l15 <= R2) ? sT[l15 * ldT + j] : 0.0;
+            eb[jj] = (j <= R2 && l15 + 16 <= R2) ? sT[(l15 + 16) * ldT + j] : 0.0;
+        }
+        auto bperm_d = [&](double x, int src4) {
+            const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(x));
+            const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(x));
+            return __hiloint2double(hi, lo);
+        };
         auto pivot_step = [&](auto tagk) {
             constexpr int k = decltype(tagk)::value;
+            constexpr int gk = k & 3, jk = k >> 2, lk = k & 15;
             if (k >= rank && k < R2 && !bad) {
-                const double piv = (k < 16) ? readlane_d(srow[k], k & 15) : readlane_d(sb[k], k & 15);
+                const double piv = (k < 16) ? readlane_d(ea[jk], 16 * gk + lk) : readlane_d(eb[jk], 16 * gk + lk);
                 if (!(piv > 0.0)) {
                     bad = 1;
                 } else {
                     const double rp = fast_rcp(piv);
-                    const double wB = (l15 + 16 > k) ? -(sb[k] * rp) : 0.0;           // rows 16 .. 31
+                    const int src4 = (16 * gk + l15) * 4;                              // the lane of group gk with my rows
+                    const double mb = bperm_d(eb[jk], src4);
+                    const double wB = (l15 + 16 > k) ? -(mb * rp) : 0.0;               // rows 16 .. 31
                     if constexpr (k < 16) {
-                        const double wA = (l15 > k) ? -(srow[k] * rp) : 0.0;          // rows 0 .. 15; the pivot row is lane k's srow
+                        const double ma = bperm_d(ea[jk], src4);
+                        const double wA = (l15 > k) ? -(ma * rp) : 0.0;                // rows 0 .. 15; the pivot row is lane lk's ea
 #pragma unroll
-                        for (int j = k + 1; j < RMAX; ++j)
-                            if (j <= R2) {
-                                fmac_row_bcast16<k>(sb[j], srow[j], wB);
-                                fmac_row_bcast16<k>(srow[j], srow[j], wA);
-                            }
-                    } else {                                                             // rows 0 .. 15 are done; the pivot row is lane k - 16's sb
+                        for (int jj = jk; jj < 8; ++jj) {
+                            fmac_row_bcast16<lk>(eb[jj], ea[jj], wB);
+                            fmac_row_bcast16<lk>(ea[jj], ea[jj], wA);
+                        }
+                    } else {                                                             // rows 0 .. 15 are done; the pivot row is lane lk's eb
 #pragma unroll
-                        for (int j = k + 1; j < RMAX; ++j)
-                            if (j <= R2) fmac_row_bcast16<(k & 15)>(sb[j], sb[j], wB);
+                        for (int jj = jk; jj < 8; ++jj) fmac_row_bcast16<lk>(eb[jj], eb[jj], wB);
                     }
                 }
             }
@@ -524,7 +540,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
         }
 #pragma unroll
         for (int j = 0; j < RMAX; ++j)
-            if (j == R2) gam = -((j < 16) ? readlane_d(srow[j], j & 15) : readlane_d(sb[j], j & 15));
+            if (j == R2) gam = -((j < 16) ? readlane_d(ea[j >> 2], 16 * (j & 3) + (j & 15)) : readlane_d(eb[j >> 2], 16 * (j & 3) + (j & 15)));
     } else {
 #pragma unroll
     for (int k = 0; k < RMAX - 1; ++k) {

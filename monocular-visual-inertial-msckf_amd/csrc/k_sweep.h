@@ -195,17 +195,14 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     // element (row slot rr, column slot k) of a source triangle; unconditional load from a clamped address
     // (structural zeros are read from p.zero, a zero double of the workspace: no select after the load, so the
     //  wait for the data sits at its first use, chunks later)
-    // Addresses are 32-bit BYTE offsets from the (uniform) workspace base, so the load takes the base from SGPRs and the
-    // offset from one VGPR (no 64-bit address arithmetic per element); the host keeps the workspace under 4 GB.
-    const unsigned zero_boff = (unsigned)((p.zero - p.rbuf) * 8);
     auto load_elem = [&](const double* src, int w, int rr, int k) -> double {
         const int r = rq + 4 * rr, lc = cq + CL * k;
         const bool isr = (k == CS - 1) && (cq == CL - 1);
         const bool ok = (r < w) && (isr || (lc >= r && lc < w));
         const int col = isr ? w : lc;
-        const unsigned sbase = (unsigned)((src - p.rbuf) * 8);               // uniform
-        const unsigned boff = ok ? sbase + (unsigned)(r * (w + 1) + col) * 8u : zero_boff;
-        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(p.rbuf) + boff);
+        // (64-bit addresses: a fold's source need not live in the workspace -- rank 0 folds gathered records where they lie)
+        const double* q = ok ? src + (r * (w + 1) + col) : p.zero;
+        return *q;
     };
     auto fetch_next_head = [&]() {      // row slots 0, 1 of the next fold
 #pragma unroll

@@ -708,11 +708,6 @@ void launch_wsweep(msckf_ctx* c, int node_base, int count, int rc_log2) {
 }
 
 int launch_sweeps(msckf_ctx* c, bool with_root = true) {
-    // the sweep kernels address the workspace with 32-bit byte offsets
-    if ((c->rbuf_doubles + 16) * 8 >= (size_t)0xffffffffu) {
-        c->last_error = "band plan workspace over 4 GB";
-        return MSCKF_ERR_ARG;
-    }
     if (c->snodes.empty()) return MSCKF_OK;
     if (c->sweep_mode > 0) {
         auto go = [&](int base, int count) {
