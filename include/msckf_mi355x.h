@@ -268,7 +268,7 @@ int msckf_set_group_exchange(msckf_ctx* ctx, int on);
  * this context (so msckf_export_groups will work), 0 when it gets the merge tree (MSCKF_FLAG_TREE_PLAN,
  * tracks wider than the sweep tiles, band R over the LDS budget): then use msckf_export_block. */
 int msckf_band_rule(const msckf_ctx* ctx, int32_t N, int32_t max_span);
-size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + N * 3660 */
+size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + gate-byte doubles (msckf_set_exchange_mask) + N * 3660 */
 int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted /* nullable */);
 int msckf_run_merge_groups(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,
                            int32_t total_accepted /* < 0: the sum of the counts in the records */);
@@ -281,6 +281,24 @@ int msckf_run_merge_groups(msckf_ctx* ctx, const void* records, int32_t n_record
 int msckf_run_merge_groups_flags(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,
                                  const uint8_t* flags);
 
+/* The gate results of a sharded update (the boundary's accepted[F] and the reference counter
+ * number_of_residuals_discarded_for_gasting_test, MSCKF.py:578) ride with the exchange instead of a collective of
+ * their own.  `bounds` (n_shards + 1 ints, host, bounds[0] = 0): shard r holds the features [bounds[r], bounds[r+1])
+ * of the whole batch in input order; the same on every rank.  From then on (call it before msckf_set_features)
+ *   - a shard's group record carries its gate bytes behind the accepted count (ceil(max shard size / 8) doubles),
+ *   - the merging rank (msckf_run_merge_groups[_flags] with n_records = n_shards) lays the gate bytes of the whole
+ *     batch behind P_out, so that status (64 B: Cholesky status words, total accepted, F_total) | dx | P_out | gate
+ *     bytes is ONE contiguous HBM range of msckf_result_range_doubles() doubles at msckf_device_pointer(ctx, 5):
+ *     one broadcast hands every rank the complete result,
+ *   - msckf_get_shared_result reads that range on ANY rank (after the broadcast) and derives the same return code
+ *     on all of them (0 / 1 no-op / MSCKF_ERR_NOT_SPD): accepted[F_total] in input order of the whole batch,
+ *     stats->n_accepted / n_rejected / not_spd filled.
+ * n_shards = 0 switches it off.  With the root-block fallback exchange (msckf_run_merge_gain) the caller places
+ * the gate bytes at msckf_device_pointer(ctx, 6) itself (shard.py does). */
+int msckf_set_exchange_mask(msckf_ctx* ctx, int32_t n_shards, const int32_t* bounds);
+size_t msckf_result_range_doubles(const msckf_ctx* ctx);
+int msckf_get_shared_result(msckf_ctx* ctx, double* dx, double* P_out, uint8_t* accepted, msckf_stats* stats);
+
 /* ---- RCCL exchange behind the C-ABI (one context = one rank = one GPU; no PyTorch on the data path) ---- *
  * The one exchange of the sharded update (gather of the compressed blocks to rank 0,
  * broadcast of dx | P+ back) on librccl, loaded with dlopen at the first call (a single-GPU process never
@@ -290,7 +308,7 @@ int msckf_run_merge_groups_flags(msckf_ctx* ctx, const void* records, int32_t n_
 #define MSCKF_COMM_ID_BYTES 128
 #define MSCKF_ERR_COMM (-7)         /* RCCL failure (msckf_last_error has the text)                      */
 int msckf_comm_unique_id(void* id_out /* MSCKF_COMM_ID_BYTES */);
-int msckf_comm_init(msckf_ctx* ctx, int32_t rank, int32_t world, const void* id);
+int msckf_comm_init(msckf_ctx* ctx, int32_t rank, int32_t world, const void* id);   /* (ctx, rank, world, id) */
 int msckf_comm_destroy(msckf_ctx* ctx);
 /* rank `root` receives world x count doubles (rank r's at recv + r * count); recv is ignored elsewhere. */
 int msckf_comm_gather(msckf_ctx* ctx, const void* send, void* recv, size_t count, int32_t root);
@@ -322,8 +340,10 @@ int msckf_debug_fold_stamps(msckf_ctx* ctx, long long* out, int32_t max_nodes);
 /* Average device time of the selection kernel (HIP events, `iters` re-launches of the last
  * msckf_run_select; the kernel is idempotent). */
 int msckf_debug_time_select(msckf_ctx* ctx, int32_t iters, float* us_per_launch);
-/* Raw device pointers (as integers) for zero-copy interop: which = 0 dx (dx | P_out are contiguous), 1 P_out,
- * 2 root block [T | r_n], 3 the shard's group record (msckf_set_group_exchange), 4 the prior covariance P. */
+/* Raw device pointers (as integers) for zero-copy interop: which = 0 dx (dx[d] | P_out[d*d] are contiguous for the
+ * CURRENT d = 15 + 6 N: the range is re-seated whenever N changes), 1 P_out, 2 root block [T | r_n], 3 the shard's
+ * group record (msckf_set_group_exchange), 4 the prior covariance P, 5 the result range (status 64 B | dx | P_out |
+ * gate bytes, msckf_set_exchange_mask), 6 its gate bytes. */
 uint64_t msckf_device_pointer(msckf_ctx* ctx, int which);
 void* msckf_stream(msckf_ctx* ctx);                     /* hipStream_t of the context */
 

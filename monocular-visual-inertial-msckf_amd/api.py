@@ -480,15 +480,52 @@ class UpdateEngine:
         return out
 
     def result_host(self):
-        """dx, P+ of the result range as host arrays without the gate bookkeeping (ranks that received them
-        through the broadcast)."""
+        """dx, P+ of the result range as host arrays without the gate bookkeeping (two copies: dx and P_out each
+        from its own address)."""
         d = 15 + 6 * self._N
-        o = self.comm_get(self.device_pointer(0), d + d * d)
-        return o[:d].copy(), o[d:].reshape(d, d).copy()
+        dx = self.comm_get(self.device_pointer(0), d)
+        P = self.comm_get(self.device_pointer(1), d * d)
+        return dx, P.reshape(d, d)
 
     def device_pointer(self, which: int) -> int:
-        """0 dx | P_out (contiguous), 1 P_out, 2 root block, 3 group record of the shard, 4 prior covariance."""
+        """0 dx (dx | P_out contiguous for the current N), 1 P_out, 2 root block, 3 group record of the shard,
+        4 prior covariance, 5 result range (status | dx | P_out | gate bytes), 6 its gate bytes."""
         return int(self._lib.msckf_device_pointer(self._h, int(which)))
+
+    # -- sharded update: gate results riding with the exchange ---------------------------------
+    def set_exchange_mask(self, bounds=None):
+        """`bounds` (n_shards + 1,): shard r holds features [bounds[r], bounds[r+1]) of the whole batch; None
+        switches the ride-along off.  Call before `load` / `set_features` (the record layout changes)."""
+        if bounds is None:
+            self._check(self._lib.msckf_set_exchange_mask(self._h, 0, None), allow_noop=False)
+            self._F_total = 0
+            return
+        b = _ffi.i32(np.asarray(bounds).reshape(-1))
+        self._check(self._lib.msckf_set_exchange_mask(self._h, int(b.size) - 1, _ffi.iptr(b)), allow_noop=False)
+        self._F_total = int(b[-1])
+
+    def gate_bytes(self) -> np.ndarray:
+        """Gate byte per feature of the loaded batch, input order: 1 accepted, 0 otherwise (the group records
+        carry the finer codes 2 = gate matrix not SPD, 3 = not selected; this host read-back, used by the
+        root-block fallback exchange only, folds them into 0)."""
+        st = _ffi.Stats()
+        acc = np.zeros(max(self._F, 1), dtype=np.uint8)
+        self._check(self._lib.msckf_get_result(self._h, None, None, _ffi.uptr(acc), C.byref(st)))
+        return acc[:self._F]
+
+    def result_range_doubles(self) -> int:
+        return int(self._lib.msckf_result_range_doubles(self._h))
+
+    def shared_result(self) -> UpdateResult:
+        """The complete result of a sharded update as read from the result range (any rank, after the
+        broadcast): status, dx, P+, accepted[F_total] of the whole batch in input order, gate counters."""
+        d = 15 + 6 * self._N
+        F = getattr(self, "_F_total", 0)
+        dx, P_out = np.empty(d), np.empty((d, d))
+        acc = np.zeros(max(F, 1), dtype=np.uint8)
+        st = _ffi.Stats()
+        rc = self._check(self._lib.msckf_get_shared_result(self._h, _ffi.dptr(dx), _ffi.dptr(P_out), _ffi.uptr(acc), C.byref(st)))
+        return UpdateResult(rc, dx, P_out, acc[:F].copy(), st.as_dict())
 
     def result_device_view(self):
         """`dx | P+` of the last run as ONE contiguous HBM range (d + d*d doubles) exposed through
@@ -588,19 +625,32 @@ class UpdateEngine:
     def prune_poorest_camera_states(self, filt) -> int:
         """Drop-in for `MSCKF.prune_poorest_camera_states()` (reference `MSCKF.py:710-737`): the two clones seen by
         the fewest features, the features seen by them -> `get_valid_features` -> `update` -> `remove_cameras`,
-        composed on the resident engine: selection, update, commit and the removal of the clones' rows / columns
-        (`:751-757`) run back to back in HBM; the covariance crosses PCIe once in each direction.  The dictionary
-        bookkeeping of `remove_cameras` (`:759-777`) stays on the host.  Returns 0 updated / 1 no update."""
-        from .pack import problem_from_reference, select_params_from_reference, tracks_from_reference
-        from .inject import inject_state
-        cams = filt.state.cameras
+        composed on the resident engine (`_prune`).  Returns 0 updated / 1 no update."""
         count = {}
         for ft in filt.features.values():                                             # :712-716
             for ci in ft.camera_indices:
                 count[ci] = count.get(ci, 0) + 1
         poorest = [k for k, _ in sorted(count.items(), key=lambda kv: kv[1])][:2]     # :718-724 (stable sort, dict order)
-        drop = {k: cams[k] for k in poorest}
-        todo = {i: ft for i, ft in filt.features.items() if any(ci in drop for ci in ft.camera_indices)}   # :726-731
+        return self._prune(filt, {k: filt.state.cameras[k] for k in poorest})
+
+    def prune_camera_states(self, filt) -> int:
+        """Drop-in for `MSCKF.prune_camera_states()` (reference `MSCKF.py:663-680`): every
+        `int(max_number_of_camera_states / camera_states_to_delete)`-th clone of the window (position i > 0 with
+        i % step == 0, `:665-667`), the features seen by them -> `get_valid_features` -> `update` ->
+        `remove_cameras`, composed on the resident engine (`_prune`).  Returns 0 updated / 1 no update."""
+        step = int(filt.max_number_of_camera_states / filt.camera_states_to_delete)   # :666
+        drop = {k: cam for i, (k, cam) in enumerate(filt.state.cameras.items()) if i > 0 and i % step == 0}
+        return self._prune(filt, drop)
+
+    def _prune(self, filt, drop) -> int:
+        """Shared tail of the reference's two pruning methods (`MSCKF.py:669-680`, `:726-737`): selection, update,
+        commit and the removal of the clones' rows / columns (`:751-757`) run back to back in HBM; the covariance
+        crosses PCIe once in each direction.  The dictionary bookkeeping of `remove_cameras` (`:758-777`, including
+        the `last_camera_measurement` entries of features that lost all their views) stays on the host."""
+        from .pack import problem_from_reference, select_params_from_reference, tracks_from_reference
+        from .inject import inject_state
+        cams = filt.state.cameras
+        todo = {i: ft for i, ft in filt.features.items() if any(ci in drop for ci in ft.camera_indices)}   # :669-674
         keys = list(cams.keys())
         slots = [keys.index(k) for k in drop]
         status = 1
@@ -617,7 +667,7 @@ class UpdateEngine:
                     ft.inverse_depth_point.rho = float(sel.idp_rho[j])
                     if hasattr(filt, "estimated_world_points"):
                         filt.estimated_world_points.append(sel.world[j].copy())
-            if sel.valid.any():                                                       # :733-735
+            if sel.valid.any():                                                       # :676-678
                 self.run()
                 d = 15 + 6 * self._N
                 dx = np.zeros(d)
@@ -631,12 +681,13 @@ class UpdateEngine:
         else:
             self.set_prior(filt.state.covariance, filt.state.imu.W_gravity, filt.K, filt.sigma_image,
                            [c.T_W_Ci.R for c in cams.values()], [c.T_W_Ci.t for c in cams.values()])
-        self.remove_clones(slots)                                                     # :751-757 on the resident P
+        if slots:
+            self.remove_clones(slots)                                                 # :751-757 on the resident P
         filt.state.covariance = self.covariance()
-        for k in drop:                                                                # :758-777
+        for k in drop:                                                                # :758
             del cams[k]
         gone = []
-        for i, ft in filt.features.items():
+        for i, ft in filt.features.items():                                           # :760-769
             for k in drop:
                 if k in ft.camera_indices:
                     v = ft.camera_indices.index(k)
@@ -646,6 +697,12 @@ class UpdateEngine:
                             del lst[v]
             if len(ft.camera_indices) == 0:
                 gone.append(i)
-        for i in gone:
+        lcm = getattr(filt, "last_camera_measurement", None)
+        for i in gone:                                                                # :771-777
             del filt.features[i]
+            if lcm is not None:
+                idx = np.where(lcm.features_indices == i)[0]
+                if len(idx) > 0:
+                    lcm.descriptors = np.delete(lcm.descriptors, idx[0], axis=0)
+                    lcm.features_indices = np.delete(lcm.features_indices, idx[0], axis=0)
         return status

@@ -27,7 +27,11 @@
 //     follows the FP64 instruction count, not the FMA chain); the quad's partials are reduce-scattered so
 //     that row lane rq holds the dot of slot rq, i.e. every lane looks after ONE column of the pivot row:
 //     it reads that R entry, forms tau, writes the entry back, and tau is broadcast over the quad for the
-//     rank-1 update.  The pivot column's own dot is v^T v: its squared norm costs no extra reduction.
+//     rank-1 update.
+//   * the squared norm of the NEXT pivot column is taken by its owners right behind its update (one quad
+//     reduction, handed on in scalar registers), so that the reflector scalars of a step -- a dependent chain of
+//     ~370 cycles: rsq, rcp, two Newton steps -- no longer wait for the step's dots but run beside them
+//     (round 3: the step was the sum of the two chains, now it is the longer of the two).
 //   * the rows of the source triangle are fetched two row slots per chunk, one
 //     chunk ahead of their first use; the first two row slots of the NEXT fold are
 //     fetched during the last chunks of the current one.
@@ -92,11 +96,18 @@ __device__ __forceinline__ double quad_sum(double x) {
     return x;
 }
 
-// Group exchange: the shard's accepted count (features with accepted == 1) as a double into its record.
-__global__ __launch_bounds__(256) void k_count_accepted(const unsigned char* accepted, int F, double* dst) {
+// Group exchange: the shard's accepted count (features with accepted == 1) as a double into its record and,
+// with `mask`, the gate byte of every feature in INPUT order (perm: sorted position -> input index) behind it, so
+// that the merging rank can hand the whole batch's gate results back with dx | P+ (reference counter MSCKF.py:578).
+__global__ __launch_bounds__(256) void k_count_accepted(const unsigned char* accepted, int F, double* dst, const int* perm,
+                                                        unsigned char* mask) {
     __shared__ int part[4];
     int n = 0;
-    for (int f = threadIdx.x; f < F; f += 256) n += accepted[f] == 1;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        const unsigned char a = accepted[f];
+        n += a == 1;
+        if (mask) mask[perm[f]] = a;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
@@ -111,6 +122,19 @@ __global__ __launch_bounds__(64) void k_sum_record_counts(const double* recs, lo
     s = wave_sum(s);
     if (threadIdx.x == 0) *dst = (int)(s + 0.5);
 }
+
+// Merging rank: the gate bytes of every record (shard r: features [b[r], b[r+1]) of the whole batch, bytes at double
+// `head` of its record) into the result range behind P_out; F_total into status word 3.
+struct MaskBounds { int n; int b[65]; };
+__global__ __launch_bounds__(256) void k_collect_masks(const double* recs, long long rec_stride, int head, MaskBounds mb,
+                                                       unsigned char* dst, int* status) {
+    const int r = blockIdx.x;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(recs + (size_t)r * rec_stride + head);
+    const int lo = mb.b[r], n = mb.b[r + 1] - lo;
+    for (int i = threadIdx.x; i < n; i += 256) dst[lo + i] = src[i];
+    if (r == 0 && threadIdx.x == 0) status[3] = mb.b[mb.n];
+}
+__global__ void k_set_int(int* p, int v) { *p = v; }
 
 template <int KK> struct STag { static constexpr int value = KK; };
 
@@ -312,6 +336,29 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         rstep = valid ? (isr ? SWEEP_RS : SWEEP_RS - 1) : 0;
     };
 
+    // |next pivot column|^2 (column slot KN, rows rr <= RP) as a wave-uniform value: four partial sums in every lane over
+    // ITS column of the slot (only the owners' sum is used), one quad reduction, v_readlane from the owners' quad
+    double sg_cur = 0.0;                                  // |pivot column|^2 of the step about to run
+    auto next_norm = [&](auto tagk, auto tagr, int col) {
+        constexpr int KN = decltype(tagk)::value;
+        constexpr int RP = decltype(tagr)::value < 15 ? decltype(tagr)::value : 15;
+        if constexpr (KN < CS) {
+            double p0 = a[0][KN] * a[0][KN], p1 = 0.0, p2 = 0.0, p3 = 0.0;
+            if constexpr (RP >= 1) p1 = a[1][KN] * a[1][KN];
+            if constexpr (RP >= 2) p2 = a[2][KN] * a[2][KN];
+            if constexpr (RP >= 3) p3 = a[3][KN] * a[3][KN];
+#pragma unroll
+            for (int rr = 4; rr <= RP; ++rr) {
+                if ((rr & 3) == 0) p0 = fma(a[rr][KN], a[rr][KN], p0);
+                else if ((rr & 3) == 1) p1 = fma(a[rr][KN], a[rr][KN], p1);
+                else if ((rr & 3) == 2) p2 = fma(a[rr][KN], a[rr][KN], p2);
+                else p3 = fma(a[rr][KN], a[rr][KN], p3);
+            }
+            const double pn = quad_sum((p0 + p1) + (p2 + p3));
+            sg_cur = readlane_d(pn, 4 * (col & (CL - 1)));
+        }
+    };
+
     auto step = [&](auto tagk, int i) {
         constexpr int KK = decltype(tagk)::value;
         constexpr int RMAX = 2 * KK + 1;                  // live row slots (rows <= 8 KK + 7)
@@ -333,6 +380,24 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             rck = smem[ra];                                // R(c, off + lco)
         }
         const bool on = (lco > i) || (rq == CS - 1 && cq == CL - 1);   // left of / at the pivot: retired (the rhs never is)
+        // |column i|^2 was taken when the column was last updated (next_norm)
+        const double sg = sg_cur;
+        const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
+        double ss = 1.0, y = 1.0, nrm = 1.0, beta = 0.0, alpha = 0.0, v0 = 0.0;
+        auto scalars = [&]() {
+            // ---- reflector scalars (every lane, uniform values) ---------------------------
+            // Branch-free: sg > 1e-290 keeps ss = x0^2 + sg a normal number whose rsqrt / rcp seeds + one Newton step
+            // are good to a few 1e-16 (the reflector stays orthogonal to that level); a column with nothing to
+            // eliminate gets beta = 0, alpha = x0 (identity).  |x0| > 1e150 does not occur (R entries are bounded by
+            // the column norms of a normalised-coordinate Jacobian stack).
+            ss = live ? fma(x0, x0, sg) : 1.0;
+            y = fast_rsqrt(ss);
+            nrm = ss * y;
+            beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;      // 1 / (nrm (nrm + |x0|))
+            alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
+            v0 = x0 - alpha;
+        };
+        if constexpr (!P2P) scalars();                    // (independent of the dots: the two chains overlap)
         // ---- dots (one partial sum per live slot), reduce-scattered over the quad ---------------------
         double sp[CS];
 #pragma unroll
@@ -361,21 +426,8 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             wait_row(f_off + i, wprev);                    // the earlier folds are past this row of R
             x0 = smem[rrow];
             rck = smem[ra];
+            scalars();
         }
-        // |column i|^2 = the pivot column's dot with itself: the lanes that published v hold a[.][K0] == v
-        const double sg = readlane_d(tot, 4 * (i - CL * K0) + K0);
-        const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
-        // ---- reflector scalars (every lane, uniform values) ---------------------------
-        // Branch-free: sg > 1e-290 keeps ss = x0^2 + sg a normal number whose rsqrt / rcp seeds + one Newton step
-        // are good to a few 1e-16 (the reflector stays orthogonal to that level); a column with nothing to
-        // eliminate gets beta = 0, alpha = x0 (identity).  |x0| > 1e150 does not occur (R entries are bounded by
-        // the column norms of a normalised-coordinate Jacobian stack).
-        const double ss = live ? fma(x0, x0, sg) : 1.0;
-        const double y = fast_rsqrt(ss);
-        const double nrm = ss * y;
-        const double beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;      // 1 / (nrm (nrm + |x0|))
-        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
-        const double v0 = x0 - alpha;
         // ---- tau of this lane's column, its R entry, then the rank-1 update of every slot ----------
         const double tau_own = (on ? beta : 0.0) * fma(v0, rck, tot);
         smem[on ? wa : dump_i] = fma(-tau_own, v0, rck);
@@ -390,11 +442,12 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
                 for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
             }
         };
-        // the slot of the next pivot column first, then its owners publish it while the other slots update
+        // the slot of the next pivot column first, then its owners publish it and take its norm while the other slots update
         const int in = i + 1;
         slot(STag<K0>{});
         if (in < f_ew && (in & 7) != 0) {
             if (cq == (in & (CL - 1))) publish(STag<K0>{}, STag<RMAX>{});         // same chunk: in / CL == K0
+            next_norm(STag<K0>{}, STag<RMAX>{}, in);
         }
         slot(STag<K0 + 1>{});
         slot(STag<K0 + 2>{});
@@ -403,6 +456,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             // first column of the next chunk: slot 8 (KK + 1) / CL, column lane 8 (KK + 1) % CL, two more row slots
             constexpr int KN = (8 * (KK + 1)) / CL;
             if (cq == (8 * (KK + 1)) % CL) publish(STag<KN>{}, STag<RMAX + 2>{});
+            next_norm(STag<KN>{}, STag<RMAX + 2>{}, in);
         }
     };
 
@@ -459,6 +513,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
 #pragma unroll
             for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
         if (cq == 0) publish(STag<0>{}, STag<1>{});
+        next_norm(STag<0>{}, STag<1>{}, 0);
         if constexpr (!P2P) {
             __syncthreads();                               // column 0 is visible to the fold's other wavefront
             ++tcur;                                        // (the host schedules t0 >= 1 and one spare step per slot reuse)

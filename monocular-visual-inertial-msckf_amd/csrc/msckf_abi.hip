@@ -187,6 +187,11 @@ struct msckf_ctx {
     Buf dPoseArena, dFeatArena, dResArena, dGateArena;
     void *hPose = nullptr, *hFeat = nullptr, *hRes = nullptr, *hGate = nullptr, *hP = nullptr;   // pinned staging
     size_t hFeatCap = 0, res_dx_off = 0, res_p_off = 0;
+    size_t res_mask_off = 0, res_mask_cap = 0, res_cap = 0;   // gate bytes of the whole (sharded) batch behind P_out; arena bytes
+    // sharded update: the gate results ride with the exchange (msckf_set_exchange_mask)
+    std::vector<int> x_bounds;            // [n_shards + 1] shard r holds features [b[r], b[r+1]) of the whole batch; empty = off
+    int xmask_doubles = 0;                // doubles of the record head that carry the shard's gate bytes (input order)
+    Buf dPerm;                            // sorted position -> input index, on the device (view into the feature arena)
     std::vector<double> chi2_cache;
     bool defer_state_sync = false;        // msckf_update: the feature upload's sync covers the state upload
     bool oneshot = false;                 // msckf_update: set_features uploads, launches K1-K4 and plans K5 meanwhile, no sync
@@ -272,6 +277,19 @@ int upload_poses(msckf_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->dPoseArena.p, h, 24 * mN * 8, hipMemcpyHostToDevice, c->stream));
     return MSCKF_OK;
 }
+
+// status (64 B) | dx (d) | P_out (d x d) | gate bytes of the whole batch: ONE contiguous range for the CURRENT d, so
+// that one collective / one copy moves a complete result (re-seated whenever d changes)
+void seat_result_views(msckf_ctx* c) {
+    const size_t d = c->d;
+    c->res_dx_off = 64; c->res_p_off = 64 + d * 8; c->res_mask_off = c->res_p_off + d * d * 8;
+    set_view(c->dStatus, c->dResArena.p, 0, 64);
+    set_view(c->dDx, c->dResArena.p, c->res_dx_off, d * 8);
+    set_view(c->dPout, c->dResArena.p, c->res_p_off, d * d * 8);
+}
+
+// doubles in front of the group triangles of an export record: N flags | accepted count | gate bytes
+inline size_t rec_head(const msckf_ctx* c) { return (size_t)c->N + 1 + (size_t)c->xmask_doubles; }
 
 // the clone set changed: feature batch, plan and results of the old layout are void
 void invalidate_batch(msckf_ctx* c) {
@@ -463,10 +481,11 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     c->leaf_narrow = c->leaf_wide = false;
     c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear();
     c->sweep_levels.clear(); c->n_group_merges = 0;
-    // group exchange: the record [N flags | accepted count | N slots of XCHG_SLOT doubles] heads the workspace; the triangle of
+    // group exchange: the record [N flags | accepted count | gate bytes (msckf_set_exchange_mask) | N slots of XCHG_SLOT doubles]
+    // heads the workspace; the triangle of
     // group s (fixed window of min(10, N - s) slots, so its shape depends on (N, s) only) is produced in slot s
     const bool xchg = c->xchg;
-    size_t off = xchg ? (size_t)N + 1 + (size_t)N * XCHG_SLOT : 0;
+    size_t off = xchg ? rec_head(c) + (size_t)N * XCHG_SLOT : 0;
     if (xchg) c->h_xflags.assign(N, 0.0);
     struct Tri { long long src; int lo, w; };
     std::vector<Tri> group_tri;                                           // one triangle per group, by first slot
@@ -504,7 +523,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         // merge levels of this group: one k_sweep node folds up to 2 * SWEEP_NW triangles (two rounds of the
         // fold slots); larger groups first reduce chunks of SWEEP_NW triangles in parallel workgroups
         std::vector<Tri> cur = leaves;
-        const long long xdest = xchg ? (long long)((size_t)N + 1 + (size_t)s * XCHG_SLOT) : -1;
+        const long long xdest = xchg ? (long long)(rec_head(c) + (size_t)s * XCHG_SLOT) : -1;
         auto merge_node = [&](size_t b, size_t e, int level, long long dest = -1) -> Tri {
             SweepNode m{};
             m.fold_begin = (int)c->sfolds.size();
@@ -999,8 +1018,10 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, with_gain || !c->xchg_planned)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
+        // (with msckf_set_exchange_mask the shard's gate bytes ride behind it, in input order)
         hipLaunchKernelGGL(k_count_accepted, dim3(1), dim3(256), 0, c->stream, ptr<unsigned char>(c->dAcc), c->F,
-                           ptr<double>(c->dRbuf) + c->N);
+                           ptr<double>(c->dRbuf) + c->N, ptr<int>(c->dPerm),
+                           c->xmask_doubles > 0 ? reinterpret_cast<unsigned char*>(ptr<double>(c->dRbuf) + c->N + 1) : nullptr);
         HIPCHK(c, hipGetLastError());
     }
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
@@ -1112,19 +1133,19 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
     E(c->dP, (size_t)d * d * 8);
     E(c->dPoseArena, (size_t)24 * N * 8);
-    c->res_dx_off = 64; c->res_p_off = 64 + (size_t)d * 8;
-    E(c->dResArena, c->res_p_off + (size_t)d * d * 8, true);
+    c->res_mask_cap = ((size_t)std::max(c->maxF, 1) + 7) & ~(size_t)7;
+    c->res_cap = 64 + (size_t)d * 8 + (size_t)d * d * 8 + c->res_mask_cap;
+    E(c->dResArena, c->res_cap, true);
     E(c->dGateArena, (size_t)5 * std::max(c->maxF, 1));
     if (rc == MSCKF_OK) {
         set_view(c->dCamR, c->dPoseArena.p, 0, (size_t)N * 72);
         set_view(c->dCamT, c->dPoseArena.p, (size_t)9 * N * 8, (size_t)N * 24);
         set_view(c->dCamR0, c->dPoseArena.p, (size_t)12 * N * 8, (size_t)N * 72);
         set_view(c->dCamT0, c->dPoseArena.p, (size_t)21 * N * 8, (size_t)N * 24);
-        set_view(c->dStatus, c->dResArena.p, 0, 64);
-        set_view(c->dDx, c->dResArena.p, c->res_dx_off, (size_t)d * 8);
-        set_view(c->dPout, c->dResArena.p, c->res_p_off, (size_t)d * d * 8);
+        c->d = 15;                                                         // no clone yet
+        seat_result_views(c);
         bool ok = hipHostMalloc(&c->hPose, (size_t)24 * N * 8) == hipSuccess &&
-                  hipHostMalloc(&c->hRes, c->res_p_off + (size_t)d * d * 8) == hipSuccess &&
+                  hipHostMalloc(&c->hRes, c->res_cap) == hipSuccess &&
                   hipHostMalloc(&c->hGate, (size_t)5 * std::max(c->maxF, 1)) == hipSuccess &&
                   hipHostMalloc(&c->hP, (size_t)d * d * 8) == hipSuccess;
         if (!ok) rc = MSCKF_ERR_HIP;
@@ -1176,6 +1197,7 @@ int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_
     const double t0 = now_us();
     if (N != c->N) c->have_features = false;
     c->N = N; c->d = 15 + 6 * N; c->dc = 6 * N;
+    seat_result_views(c);
     c->sigma = sigma; c->n_chi2 = n_crit;
     std::memcpy(c->g, gravity, 24);
     std::memcpy(c->Kinv, Kinv, 72);
@@ -1221,6 +1243,23 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->band_plan = false; c->root = -1; c->perm.clear();
         c->plan_valid = false;
+        c->xchg_planned = false;
+        if (c->xchg) {
+            // a shard without tracks still takes part in the gather: an empty record (no flag, count 0, no gate byte)
+            // heads the workspace; the triangles behind it are never read (the merging rank goes by the flags)
+            const size_t need = (rec_head(c) + (size_t)N * XCHG_SLOT + 16) * 8;
+            if (c->dRbuf.bytes < need) {
+                if (c->dRbuf.p) HIPCHK(c, hipFree(c->dRbuf.p));
+                c->dRbuf.p = nullptr; c->dRbuf.bytes = 0;
+                HIPCHK(c, hipMalloc(&c->dRbuf.p, need));
+                c->dRbuf.bytes = need;
+            }
+            HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, rec_head(c) * 8, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            c->xchg_planned = true;
+            c->rbuf_doubles = rec_head(c) + (size_t)N * XCHG_SLOT;
+            c->gather_off = c->rbuf_doubles;
+        }
         c->have_features = true;
         c->us_host_prep = (float)(now_us() - t0);
         return MSCKF_OK;
@@ -1266,7 +1305,8 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
     const size_t o_slot = o_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7), o_fmin = o_slot + (((size_t)sumM * 4 + 7) & ~(size_t)7);
     const size_t o_info = (o_fmin + (size_t)F * 4 + 15) & ~(size_t)15;                    // FeatInfo records (16-byte aligned)
-    const size_t feat_bytes = o_info + (size_t)F * sizeof(FeatInfo);
+    const size_t o_perm = o_info + (size_t)F * sizeof(FeatInfo);                          // sorted position -> input index
+    const size_t feat_bytes = o_perm + (size_t)F * 4;
     if (c->hFeatCap < feat_bytes) {
         if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
         c->hFeat = nullptr; c->hFeatCap = 0;
@@ -1320,6 +1360,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     }
     h_view[F] = pos;
     std::memcpy(h_viewp, h_view.data(), (size_t)(F + 1) * 4);
+    std::memcpy(hb + o_perm, c->perm.data(), (size_t)F * 4);
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
     c->h_fmin = h_fmin; c->h_fmax = h_fmax;
@@ -1334,6 +1375,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     set_view(c->dObsSlot, c->dFeatArena.p, o_slot, (size_t)sumM * 4);
     set_view(c->dFmin, c->dFeatArena.p, o_fmin, (size_t)F * 4);
     set_view(c->dFeatInfo, c->dFeatArena.p, o_info, (size_t)F * sizeof(FeatInfo));
+    set_view(c->dPerm, c->dFeatArena.p, o_perm, (size_t)F * 4);
     // gate results: rank[F] (int) then accepted[F] (byte), contiguous so they come back in one copy
     set_view(c->dRank, c->dGateArena.p, 0, (size_t)F * 4);
     set_view(c->dAcc, c->dGateArena.p, (size_t)F * 4, (size_t)F);
@@ -1775,6 +1817,7 @@ int msckf_augment(msckf_ctx* c, const double* J15, const double* R, const double
     c->h_cam[0].insert(c->h_cam[0].end(), R, R + 9); c->h_cam[1].insert(c->h_cam[1].end(), t, t + 3);
     c->h_cam[2].insert(c->h_cam[2].end(), R, R + 9); c->h_cam[3].insert(c->h_cam[3].end(), t, t + 3);
     c->N += 1; c->d = 15 + 6 * c->N; c->dc = 6 * c->N;
+    seat_result_views(c);
     if (int rc = upload_poses(c)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate_batch(c);
@@ -1810,6 +1853,7 @@ int msckf_remove_clones(msckf_ctx* c, int32_t n, const int32_t* slots) {
     std::swap(c->dP, c->dB2);
     for (int q = 0; q < 4; ++q) c->h_cam[q].swap(nc[q]);
     c->N -= n; c->d = 15 + 6 * c->N; c->dc = 6 * c->N;
+    seat_result_views(c);
     if (int rc = upload_poses(c)) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     invalidate_batch(c);
@@ -1922,6 +1966,8 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     (void)N;
     int rc = launch_gain(c, root);
     if (rc != MSCKF_OK) return rc;
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, ptr<int>(c->dStatus) + 2, (int)total_accepted);   // (shared result)
+    HIPCHK(c, hipGetLastError());
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
     return MSCKF_OK;
@@ -1942,7 +1988,7 @@ int msckf_band_rule(const msckf_ctx* c, int32_t N, int32_t max_span) {
 }
 
 size_t msckf_group_record_doubles(const msckf_ctx* c) {
-    return c ? (size_t)c->N + 1 + (size_t)c->N * XCHG_SLOT : 0;
+    return c ? rec_head(c) + (size_t)c->N * XCHG_SLOT : 0;
 }
 
 int msckf_export_groups(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accepted) {
@@ -1984,6 +2030,19 @@ int msckf_run_merge_groups_flags(msckf_ctx* c, const void* records, int32_t n_re
 }
 
 namespace {
+// sharded update with msckf_set_exchange_mask: the gate bytes of all shards -> the result range (behind P_out)
+int collect_masks(msckf_ctx* c, const double* recs, long long rec_stride, int n_rec) {
+    if (c->x_bounds.empty() || c->xmask_doubles == 0) return MSCKF_OK;
+    if ((int)c->x_bounds.size() != n_rec + 1) return MSCKF_ERR_ARG;
+    MaskBounds mb{};
+    mb.n = n_rec;
+    for (int i = 0; i <= n_rec; ++i) mb.b[i] = c->x_bounds[i];
+    hipLaunchKernelGGL(k_collect_masks, dim3(n_rec), dim3(256), 0, c->stream, recs, rec_stride, c->N + 1, mb,
+                       static_cast<unsigned char*>(c->dResArena.p) + c->res_mask_off, ptr<int>(c->dStatus));
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+
 int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int device_ptr, int32_t total_accepted, const uint8_t* flags) {
     if (!c || !records || n_rec < 1) return MSCKF_ERR_ARG;
     if (!c->have_state) return MSCKF_ERR_STATE;
@@ -2035,6 +2094,8 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
             acc_sum += head[(size_t)r * (N + 1) + N];
         }
         if (total_accepted < 0) total_accepted = (int32_t)(acc_sum + 0.5);    // the counts the shards wrote into their records
+        hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, ptr<int>(c->dStatus) + 2, (int)total_accepted);
+        HIPCHK(c, hipGetLastError());
     }
     const bool reuse = c->x_plan_valid && c->x_nrec == n_rec && c->x_root_off == o_root && c->x_rec_base == rec_base &&
                        c->x_key == key;
@@ -2048,7 +2109,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
             const int w = 6 * (std::min(s0 + SWEEP_MAX_W / 6, N) - s0);
             std::vector<long long> src;
             for (int r = 0; r < n_rec; ++r)
-                if (key[(size_t)r * N + s0] != 0.0) src.push_back(rec_base + (long long)((size_t)r * rec + N + 1 + (size_t)s0 * XCHG_SLOT));
+                if (key[(size_t)r * N + s0] != 0.0) src.push_back(rec_base + (long long)((size_t)r * rec + rec_head(c) + (size_t)s0 * XCHG_SLOT));
             if (src.empty()) continue;
             if (src.size() == 1) { groups.push_back({src[0], s0, w}); continue; }
             SweepNode m{};
@@ -2094,6 +2155,11 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         c->x_plan_valid = true;
     }
     if (c->x_snodes.empty()) {            // no shard has a track: nothing to update
+        if (!count_on_device) {
+            hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, ptr<int>(c->dStatus) + 2, 0);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
         c->ran = true; c->ran_gain = false; c->acc_override = 0; c->acc_from_dev = false;
         return MSCKF_OK;
     }
@@ -2115,6 +2181,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     HIPCHK(c, hipGetLastError());
     int rc = launch_gain(c, rb + c->x_root_off);
     if (rc != MSCKF_OK) return rc;
+    if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
     c->acc_from_dev = count_on_device;
@@ -2229,6 +2296,87 @@ int msckf_import_covariance(msckf_ctx* c, const void* P, int device_ptr) {
     return MSCKF_OK;
 }
 
+int msckf_set_exchange_mask(msckf_ctx* c, int32_t n_shards, const int32_t* bounds) {
+    if (!c || n_shards < 0 || n_shards > 64 || (n_shards > 0 && !bounds)) return MSCKF_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int cap = 0;
+    for (int r = 0; r < n_shards; ++r) {
+        if (bounds[r + 1] < bounds[r] || bounds[0] != 0) return MSCKF_ERR_ARG;
+        cap = std::max(cap, bounds[r + 1] - bounds[r]);
+    }
+    c->x_bounds.clear();
+    if (n_shards > 0) c->x_bounds.assign(bounds, bounds + n_shards + 1);
+    c->xmask_doubles = (cap + 7) / 8;
+    c->have_features = false;             // the record layout changed: the next msckf_set_features plans afresh
+    c->plan_valid = false;
+    c->x_plan_valid = false;
+    c->ran = false;
+    const size_t total = n_shards > 0 ? (size_t)bounds[n_shards] : 0;
+    if (total > c->res_mask_cap) {        // the result range grows: nothing may be in flight on it
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const size_t dmax = 15 + 6 * (size_t)c->maxN;
+        const size_t mcap = (total + 7) & ~(size_t)7;
+        const size_t cap_bytes = 64 + dmax * 8 + dmax * dmax * 8 + mcap;
+        void* np = nullptr;
+        void* nh = nullptr;
+        HIPCHK(c, hipMalloc(&np, cap_bytes));
+        HIPCHK(c, hipMemset(np, 0, cap_bytes));
+        if (hipHostMalloc(&nh, cap_bytes) != hipSuccess) { (void)hipFree(np); return MSCKF_ERR_HIP; }
+        (void)hipFree(c->dResArena.p);
+        (void)hipHostFree(c->hRes);
+        c->dResArena.p = np; c->dResArena.bytes = cap_bytes;
+        c->hRes = nh;
+        c->res_mask_cap = mcap; c->res_cap = cap_bytes;
+        seat_result_views(c);
+    }
+    return MSCKF_OK;
+}
+
+size_t msckf_result_range_doubles(const msckf_ctx* c) {
+    if (!c) return 0;
+    const size_t total = c->x_bounds.empty() ? 0 : (size_t)c->x_bounds.back();
+    return 8 + (size_t)c->d + (size_t)c->d * c->d + (total + 7) / 8;
+}
+
+int msckf_get_shared_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted, msckf_stats* st) {
+    if (!c) return MSCKF_ERR_ARG;
+    if (!c->have_state) return MSCKF_ERR_STATE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t d = c->d;
+    const size_t total = c->x_bounds.empty() ? 0 : (size_t)c->x_bounds.back();
+    HIPCHK(c, hipMemcpyAsync(c->hRes, c->dResArena.p, c->res_mask_off + total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int status[4];
+    std::memcpy(status, c->hRes, 16);
+    const int dc = c->dc;
+    const bool blocked = dc > 4 * CHOL_TILE_MAX_NT && dc <= 2 * GAIN_BLK && dc - GAIN_BLK >= 4;    // as launch_gain decides
+    const int n_acc = status[2];
+    int rc = (n_acc <= 0) ? MSCKF_NOOP : MSCKF_OK;
+    if (rc == MSCKF_OK && (status[0] != 0 || (blocked && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
+    const char* hres = static_cast<const char*>(c->hRes);
+    if (dx) {
+        if (rc == MSCKF_OK) std::memcpy(dx, hres + c->res_dx_off, d * 8);
+        else std::memset(dx, 0, d * 8);
+    }
+    if (P_out) {
+        if (rc == MSCKF_OK) std::memcpy(P_out, hres + c->res_p_off, d * d * 8);
+        else HIPCHK(c, hipMemcpy(P_out, c->dP.p, d * d * 8, hipMemcpyDeviceToHost));       // untouched prior (MSCKF.py:584-585)
+    }
+    int n_rej = 0, n_nspd = 0, n_unsel = 0;
+    const unsigned char* mk = reinterpret_cast<const unsigned char*>(hres + c->res_mask_off);
+    for (size_t i = 0; i < total; ++i) {
+        const unsigned char a = mk[i];
+        if (accepted) accepted[i] = a == 1 ? 1 : 0;
+        n_rej += a == 0; n_nspd += a == 2; n_unsel += a == 3;
+    }
+    if (st) {
+        std::memset(st, 0, sizeof(*st));
+        st->n_features = (int)total - n_unsel; st->n_accepted = std::max(n_acc, 0);
+        st->n_rejected = n_rej; st->not_spd = n_nspd;
+    }
+    return rc;
+}
+
 int msckf_debug_gate(msckf_ctx* c, double* gamma, int32_t* qdim) {
     if (!c || !c->ran) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2289,6 +2437,8 @@ uint64_t msckf_device_pointer(msckf_ctx* c, int which) {
         case 2: return (c->root >= 0) ? (uint64_t)root_block(c) : 0;
         case 3: return c->xchg_planned ? (uint64_t)c->dRbuf.p : 0;
         case 4: return (uint64_t)c->dP.p;
+        case 5: return (uint64_t)c->dResArena.p;                                   // status | dx | P_out | gate bytes
+        case 6: return (uint64_t)(static_cast<char*>(c->dResArena.p) + c->res_mask_off);
         default: return 0;
     }
 }

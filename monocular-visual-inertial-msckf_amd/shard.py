@@ -135,37 +135,59 @@ def shard_group_flags(prob: UpdateProblem, shards: List[Tuple[int, int]]) -> np.
     return flags
 
 
-def exchange_unique_id(engine, rank: int, world: int, path: str, timeout_s: float = 120.0) -> bytes:
-    """Bootstrap of the RCCL communicator without any other communication layer: rank 0 writes the id to
-    `path` (atomically), the others poll for it."""
+def _run_tag() -> bytes:
+    """16 bytes that every rank of ONE launch shares and an earlier launch almost surely does not: the launcher's
+    rendezvous (run id, master address / port) and its process id (the ranks' common parent under
+    `torch.distributed.run` / `mpirun`).  Callers with their own side channel pass a tag explicitly."""
+    import hashlib
+    e = os.environ
+    key = "|".join([e.get("TORCHELASTIC_RUN_ID", ""), e.get("MASTER_ADDR", ""), e.get("MASTER_PORT", ""),
+                    e.get("MSCKF_RUN_TAG", ""), str(os.getppid())])
+    return hashlib.sha256(key.encode()).digest()[:16]
+
+
+def exchange_unique_id(engine, rank: int, world: int, path: str, timeout_s: float = 120.0, tag: bytes = None) -> bytes:
+    """Bootstrap of the RCCL communicator without any other communication layer: rank 0 writes `tag | id` to `path`
+    (atomically), the others poll for a file that carries THEIR launch's tag -- a file left over from an earlier or
+    crashed run has another tag and is ignored (joining with a stale id would hang in ncclCommInitRank).  Rank 0
+    removes the file in `RcclShardedUpdate.__init__` once the communicator is up (every rank has read it by then)."""
+    tag = _run_tag() if tag is None else bytes(tag)[:16].ljust(16, b"\0")
     if rank == 0:
         uid = engine.comm_unique_id()
         tmp = path + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
-            f.write(uid)
+            f.write(tag + uid)
         os.replace(tmp, path)
         return uid
     t0 = time.time()
     while time.time() - t0 < timeout_s:
         try:
             with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
+                blob = f.read()
+            if len(blob) == 16 + 128 and blob[:16] == tag:
+                return blob[16:]
         except FileNotFoundError:
             pass
         time.sleep(0.01)
-    raise TimeoutError("no RCCL id at " + path)
+    raise TimeoutError("no RCCL id of this launch at " + path)
 
 
 class RcclShardedUpdate:
     """One sharded update per `step()`: K1-K5 on the local shard, ONE RCCL gather of the group records (or root
-    blocks) to rank 0, merge + K6-K7 there, ONE RCCL broadcast of dx | P+.  Everything is enqueued on the
-    engine's stream; a step returns without waiting for the device."""
+    blocks) to rank 0, merge + K6-K7 there, ONE RCCL broadcast of the result range
+    `status | dx | P+ | gate bytes of the whole batch` (`msckf_set_exchange_mask`: the shards' gate results ride in
+    their records).  Everything is enqueued on the engine's stream; a step returns without waiting for the device.
+    `result()` is the same call on every rank and yields the same status everywhere (0 updated / 1 no-op; a
+    non-SPD innovation covariance raises on every rank, none keeps the garbage)."""
 
-    def __init__(self, engine, rank: int, world: int, uid: bytes):
+    def __init__(self, engine, rank: int, world: int, uid: bytes, id_path: str = None):
         self.e, self.rank, self.world = engine, rank, world
         engine.comm_init(rank, world, uid)
+        if rank == 0 and id_path:
+            try:
+                os.unlink(id_path)                # every rank has joined: the id file has served
+            except OSError:
+                pass
         self.groups = False
         self.count = 0
         self.flags = None
@@ -175,22 +197,28 @@ class RcclShardedUpdate:
         """Every rank passes the same full problem; it keeps its shard resident."""
         e = self.e
         shards = partition_features(prob.view_ptr, self.world)
+        self.bounds = np.array([s[0] for s in shards] + [shards[-1][1]], dtype=np.int32)
         self.groups = bool(e.band_ok(prob))
         e.set_group_exchange(self.groups)
+        e.set_exchange_mask(self.bounds)
         lo, hi = shards[self.rank]
         e.load(prob.subset(lo, hi))
         self.d = prob.d
         self.shard = (lo, hi)
+        self.F_total = int(prob.F)
+        self.mask_doubles = (int(np.diff(self.bounds).max()) + 7) // 8
         if self.groups:
             self.count = e.group_record_doubles()
             self.flags = shard_group_flags(prob, shards)
-            self.recv = e.comm_buffer(self.count * self.world) if self.rank == 0 else 0
         else:
-            # fallback exchange (tracks wider than the sweep tiles, merge tree forced): root blocks [R | Q^T r] plus the
-            # shard's accepted count, staged through host memory on both sides
-            self.count = e.block_doubles() + 1
-            buf = e.comm_buffer(self.count * (self.world + 1))
-            self.recv, self.send = buf, buf + 8 * self.count * self.world
+            # fallback exchange (tracks wider than the sweep tiles, merge tree forced): root blocks [R | Q^T r], the
+            # shard's accepted count and its gate bytes, staged through host memory on both sides
+            self.count = e.block_doubles() + 1 + self.mask_doubles
+        # ONE allocation (a second, larger request would move the buffer under the pointers handed out here):
+        # receive side of the gather | staging record of the fallback exchange | 8 doubles of scratch for the caller
+        buf = e.comm_buffer(self.count * (self.world + 1) + 8)
+        self.recv, self.send = buf, buf + 8 * self.count * self.world
+        self.scratch = buf + 8 * self.count * (self.world + 1)
 
     def step(self):
         e = self.e
@@ -201,23 +229,29 @@ class RcclShardedUpdate:
                 e.merge_groups_flags(self.recv, self.world, self.flags)          # no read-back: flags from the partition
         else:
             blk, n = e.export_block()
-            e.comm_put(self.send, np.concatenate([blk.reshape(-1), [float(n)]]))
+            gate = np.zeros(8 * self.mask_doubles, dtype=np.uint8)
+            lo, hi = self.shard
+            if hi > lo:
+                gate[:hi - lo] = e.gate_bytes()
+            e.comm_put(self.send, np.concatenate([blk.reshape(-1), [float(n)], gate.view(np.float64)]))
             e.comm_gather(self.send, self.recv, self.count, 0)
             if self.rank == 0:
                 g = e.comm_get(self.recv, self.count * self.world).reshape(self.world, self.count)
                 dc = 6 * e.n_clones
-                e.merge_gain(g[:, :-1].reshape(self.world, dc, dc + 1), int(round(g[:, -1].sum())))
-        e.comm_broadcast(e.device_pointer(0), self.d + self.d * self.d, 0)       # dx | P+ into every rank's result range
+                nb = dc * (dc + 1)
+                e.merge_gain(g[:, :nb].reshape(self.world, dc, dc + 1), int(round(g[:, nb].sum())))
+                allg = np.zeros((self.F_total + 7) // 8 * 8, dtype=np.uint8)
+                for r in range(self.world):
+                    a, b = int(self.bounds[r]), int(self.bounds[r + 1])
+                    allg[a:b] = np.ascontiguousarray(g[r, nb + 1:]).view(np.uint8)[:b - a]
+                e.comm_put(e.device_pointer(6), allg.view(np.float64))
+        # status | dx | P+ | gate bytes into every rank's result range
+        e.comm_broadcast(e.device_pointer(5), e.result_range_doubles(), 0)
 
     def result(self):
-        """(status, dx, P_new) on every rank (the broadcast filled the result range); syncs."""
-        e = self.e
-        e.sync()
-        if self.rank == 0:
-            r = e.result()
-            return r.status, r.dx, r.P_new
-        dx, P = e.result_host()
-        return 0, dx, P
+        """(status, dx, P_new, accepted[F], n_rejected) -- identical on every rank; syncs."""
+        r = self.e.shared_result()
+        return r.status, r.dx, r.P_new, r.accepted, int(r.stats["n_rejected"])
 
     def close(self):
         self.e.comm_destroy()

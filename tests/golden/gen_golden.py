@@ -436,10 +436,14 @@ def build_filter(prob, keys=None):
     return f, feats, keys
 
 
-def run_reference_prune(prob, tracks, sp):
+def run_reference_prune(prob, tracks, sp, method="poorest", max_states=None):
     """`MSCKF.prune_poorest_camera_states` (`MSCKF.py:710-737`): the two clones seen by the fewest features, the
-    features seen by them -> get_valid_features -> update -> remove_cameras.  Returns what it left behind."""
+    features seen by them -> get_valid_features -> update -> remove_cameras.  Returns what it left behind.
+    method="states": `MSCKF.prune_camera_states` (`:663-680`, every int(max / to_delete)-th clone) instead, with a
+    `last_camera_measurement` in place so that the bookkeeping of `remove_cameras` (`:771-777`) is on record too."""
     params = MSCKFParameters()
+    if max_states is not None:
+        params.max_number_of_camera_states = int(max_states)
     params.K = prob.K
     params.sigma_image = prob.sigma
     params.W_gravity = prob.gravity.copy()
@@ -480,11 +484,23 @@ def run_reference_prune(prob, tracks, sp):
 
     f.correct = wrapped
     rej0 = f.number_of_residuals_discarded_for_gasting_test
-    f.prune_poorest_camera_states()
+    extra = {}
+    if method == "states":
+        from src.msckf.FeatureExtractor import CameraMeasurement
+        ids = np.array(sorted(feats.keys()), dtype=np.int64)
+        f.last_camera_measurement = CameraMeasurement(keypoints=[], descriptors=np.arange(len(ids) * 4, dtype=np.float64).reshape(len(ids), 4),
+                                                      scores=[], features_indices=ids.copy())
+        f.prune_camera_states()
+        extra = dict(prune_lcm_indices_left=np.asarray(f.last_camera_measurement.features_indices, dtype=np.int64),
+                     prune_lcm_descriptors_left=np.asarray(f.last_camera_measurement.descriptors, dtype=np.float64),
+                     prune_max_states=np.int32(f.max_number_of_camera_states),
+                     prune_states_to_delete=np.int32(f.camera_states_to_delete))
+    else:
+        f.prune_poorest_camera_states()
     left = list(f.state.cameras.keys())
     removed = [i for i, k in enumerate(keys) if k not in left]
     views_left = np.array([len(feats[100 + j].camera_indices) if (100 + j) in f.features else 0 for j in range(prob.F)], dtype=np.int32)
-    return dict(prune_removed_slots=np.array(removed, dtype=np.int32), prune_P_after=f.state.covariance.copy(),
+    return dict(extra, prune_removed_slots=np.array(removed, dtype=np.int32), prune_P_after=f.state.covariance.copy(),
                 prune_dx=cap.get("dx", np.zeros(prob.d)), prune_status=np.int32(0 if "dx" in cap else 1),
                 prune_n_rejected=np.int32(f.number_of_residuals_discarded_for_gasting_test - rej0),
                 prune_post_cam_R=np.stack([f.state.cameras[k].T_W_Ci.R for k in left]),
@@ -667,6 +683,20 @@ def main():
         save_select("sel_prune_poorest", prob, tracks, sp, sel)
         print("    prune removed slots", out["prune_removed_slots"], "status", int(out["prune_status"]),
               "features left", int(out["prune_features_left"]))
+
+    # prune_camera_states (MSCKF.py:663-680): every int(max / to_delete)-th clone of the window; tracks short enough
+    # that some features lose ALL their views with the removed clones (remove_cameras :770-777 then touches
+    # last_camera_measurement)
+    if not args.only or args.only == "sel_prune_states":
+        prob = synth.make_problem(12, 110, 5, seed=31, variable_tracks=True, min_track=1)
+        sp = SP(min_parallax_deg=3.0, min_frames_tracked=2)
+        tracks = synth.make_tracks(prob, seed=31, lost_fraction=0.7)
+        out = run_reference_prune(prob, tracks, sp, method="states", max_states=12)
+        sel = run_reference_select(prob, tracks, sp, None)
+        sel.update(out)
+        save_select("sel_prune_states", prob, tracks, sp, sel)
+        print("    prune_camera_states removed slots", out["prune_removed_slots"], "status", int(out["prune_status"]),
+              "features left", int(out["prune_features_left"]), "lcm entries left", len(out["prune_lcm_indices_left"]))
 
     # f4: the per-view consistency tests of add_camera_measurements (MSCKF.py:332-412)
     if not args.only or args.only == "assoc_tests":

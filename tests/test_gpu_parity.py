@@ -466,6 +466,102 @@ def test_group_exchange_shards_on_one_gpu(N, F, M, shards, kw):
         assert rel_err(one.dx, ref["dx"]) < TOL and rel_err(one.P_new, ref["P_new"]) < TOL
 
 
+def _shipped_merge(e, prob, shards, ref):
+    """The exact call sequence of `RcclShardedUpdate.load / step / result` with S logical shards on ONE engine: every
+    shard's record is copied (in HBM) into slot r of the exchange buffer -- what the RCCL gather does --, rank 0's
+    `merge_groups_flags` with the flags of the partition, then the shared result range is read the way every rank
+    reads it after the broadcast."""
+    from msckf_amd.shard import shard_group_flags
+    bounds = np.array([sh[0] for sh in shards] + [shards[-1][1]], dtype=np.int32)
+    e.set_group_exchange(True)
+    e.set_exchange_mask(bounds)
+    count = None
+    recv = 0
+    for r, (lo, hi) in enumerate(shards):
+        e.load(prob.subset(lo, hi))
+        if count is None:
+            count = e.group_record_doubles()
+            recv = e.comm_buffer(count * (len(shards) + 1) + 8)
+        assert e.group_record_doubles() == count
+        e.run_compress()
+        assert e.device_pointer(3) != 0                       # the record heads the workspace, also for a shard without tracks
+        e.export_groups(dst_ptr=recv + 8 * count * r, count=False)
+    e.set_state(prob)
+    flags = shard_group_flags(prob, shards)
+    for it in range(2):                                       # the second call reuses the cached merge plan
+        e.merge_groups_flags(recv, len(shards), flags)
+        assert e.result_range_doubles() == 8 + prob.d + prob.d ** 2 + (prob.F + 7) // 8
+        res = e.shared_result()
+        assert res.status == ref["status"]
+        assert np.array_equal(res.accepted, ref["accepted"])
+        assert res.stats["n_accepted"] == int(ref["accepted"].sum())
+        assert res.n_rejected == prob.F - int(ref["accepted"].sum())
+        if ref["status"] == 0:
+            assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        else:
+            assert not res.dx.any() and np.array_equal(res.P_new, prob.P)
+    e.set_exchange_mask(None)
+    e.set_group_exchange(False)
+    return res
+
+
+@pytest.mark.parametrize("N,F,M,S,kw", [
+    (30, 2000, 10, 2, {"outlier_fraction": 0.1, "outlier_px": 400.0}),
+    (30, 2000, 10, 8, {"outlier_fraction": 0.1, "outlier_px": 400.0}),
+    (12, 60, 10, 4, {"variable_tracks": True}),              # shards without tracks at some first slots
+    (10, 3, 5, 4, {}),                                       # fewer features than ranks: an empty shard takes part
+    (8, 20, 5, 3, {"sigma": 0.01, "pixel_noise": 80.0}),     # nothing passes the gate anywhere: no-op on every rank
+])
+def test_shipped_merge_path_logical_shards(N, F, M, S, kw):
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from msckf_amd.shard import partition_features
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=61, **kw)
+    ref = oracle.update(prob, dense_noise=False)
+    shards = partition_features(prob.view_ptr, S)
+    with UpdateEngine(max_clones=N + 3, max_features=max(F, 8), max_track=max(M, 2)) as e:    # (capacity above N on purpose)
+        assert e.band_ok(prob)
+        _shipped_merge(e, prob, shards, ref)
+
+
+@pytest.mark.parametrize("S", [2, 4, 8])
+def test_shipped_merge_path_config4_full_size(S):
+    """BASELINE.json configs[3] (30, 8000, 10) through the calls `RcclShardedUpdate.step()` makes on rank 0."""
+    from msckf_amd.api import UpdateEngine
+    from msckf_amd.shard import partition_features
+    prob, ref = _big_case(30, 8000, 10)
+    with UpdateEngine(max_clones=30, max_features=8000, max_track=10) as e:
+        _shipped_merge(e, prob, partition_features(prob.view_ptr, S), ref)
+
+
+def test_result_range_follows_the_current_window():
+    """`dx | P_out` is ONE contiguous range for the CURRENT N, also when the engine was created for more clones
+    (round-2 advisor finding: the range was seated for max_clones, a broadcast of d + d*d doubles then carried a gap
+    and a truncated P+)."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    prob = synth.make_problem(12, 200, 6, seed=62)
+    with UpdateEngine(max_clones=30, max_features=256, max_track=8) as e:
+        e.load(prob)
+        e.run()
+        res = e.result()
+        d = prob.d
+        assert e.device_pointer(1) - e.device_pointer(0) == 8 * d
+        flat = e.comm_get(e.device_pointer(0), d + d * d)
+        assert np.array_equal(flat[:d], res.dx) and np.array_equal(flat[d:].reshape(d, d), res.P_new)
+        dx2, P2 = e.result_host()
+        assert np.array_equal(dx2, res.dx) and np.array_equal(P2, res.P_new)
+        # the window grows: the range is re-seated
+        big = synth.make_problem(20, 200, 6, seed=63)
+        e.load(big)
+        e.run()
+        r2 = e.result()
+        assert e.device_pointer(1) - e.device_pointer(0) == 8 * big.d
+        dx3, P3 = e.result_host()
+        assert np.array_equal(dx3, r2.dx) and np.array_equal(P3, r2.P_new)
+
+
 def test_group_exchange_refuses_tree_planned_batches(eng):
     from msckf_amd import synth
     from msckf_amd._ffi import EngineError

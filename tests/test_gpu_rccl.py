@@ -52,21 +52,31 @@ print("RCCL_ABI_OK", flush=True)
 # RcclShardedUpdate (the driver bench.py --gpus N runs): compress -> RCCL gather -> merge + gain -> RCCL broadcast, all on
 # the engine's stream; group records where the batch runs the 60-column band pipeline, root blocks otherwise
 for (N, F, M, groups) in [(30, 2000, 10, True), (16, 120, 14, False)]:
-    prob = synth.make_problem(N, F, M, seed=81)
+    prob = synth.make_problem(N, F, M, seed=81, outlier_fraction=0.05, outlier_px=400.0)
     ref = oracle.update(prob, dense_noise=False)
     with tempfile.TemporaryDirectory() as td, UpdateEngine(max_clones=N, max_features=F, max_track=M) as e:
-        uid = exchange_unique_id(e, 0, 1, os.path.join(td, "id"))
-        assert exchange_unique_id(e, 1, 1, os.path.join(td, "id")) == uid     # what another rank would read
-        drv = RcclShardedUpdate(e, 0, 1, uid)
+        idp = os.path.join(td, "id")
+        with open(idp, "wb") as fh:                               # a file left over by an earlier launch (another tag): ignored
+            fh.write(b"\x01" * 16 + b"\x02" * 128)
+        try:
+            exchange_unique_id(e, 1, 1, idp, timeout_s=0.2)
+            raise AssertionError("a stale id file was accepted")
+        except TimeoutError:
+            pass
+        uid = exchange_unique_id(e, 0, 1, idp)
+        assert exchange_unique_id(e, 1, 1, idp) == uid            # what another rank of THIS launch would read
+        drv = RcclShardedUpdate(e, 0, 1, uid, id_path=idp)
+        assert not os.path.exists(idp)                            # rank 0 removed it once the communicator was up
         drv.load(prob)
         assert drv.groups == groups
         for _ in range(3):                                        # steps chain on the stream, no sync in between
             drv.step()
-        status, dx, P = drv.result()
+        status, dx, P, acc, n_rej = drv.result()
         e_dx = np.linalg.norm(dx - ref["dx"]) / np.linalg.norm(ref["dx"])
         e_P = np.linalg.norm(P - ref["P_new"]) / np.linalg.norm(ref["P_new"])
         assert status == 0 and e_dx < 1e-8 and e_P < 1e-8, (status, e_dx, e_P)
-        dx2, P2 = e.result_host()                                 # what a non-root rank reads after the broadcast
+        assert np.array_equal(acc, ref["accepted"]) and n_rej == prob.F - int(ref["accepted"].sum())
+        dx2, P2 = e.result_host()                                 # dx and P_out read from their own addresses
         assert np.array_equal(dx2, dx) and np.array_equal(P2, P)
         drv.close()
     print("RCCL_STEP_OK", N, F, M, flush=True)

@@ -195,11 +195,8 @@ def test_process_features_on_reference_shaped_objects(eng):
     np.testing.assert_allclose(rho, ref["sel_idp_rho"], rtol=1e-8)
 
 
-def test_prune_poorest_camera_states_composed_on_the_device(eng):
-    """`UpdateEngine.prune_poorest_camera_states(filt)` against the reference's own run of
-    `MSCKF.prune_poorest_camera_states` (MSCKF.py:710-737; fixture sel_prune_poorest): same clones removed, same
-    covariance after update + removal, same poses of the remaining clones, same feature bookkeeping."""
-    prob, tracks, params, ref = load_golden_select("sel_prune_poorest")
+def _filter_from_fixture(prob, tracks, params, with_lcm=False):
+    """A reference-shaped filter object (the attributes the pruning methods read) built from a sel_* fixture."""
     keys = [10 * (i + 1) for i in range(prob.N)]
     cams = OrderedDict()
     for i, k in enumerate(keys):
@@ -223,8 +220,15 @@ def test_prune_poorest_camera_states_composed_on_the_device(eng):
         state=SimpleNamespace(cameras=cams, covariance=prob.P.copy(), imu=imu), K=prob.K, sigma_image=prob.sigma,
         features=feats, number_of_residuals_discarded_for_gasting_test=0, estimated_world_points=[],
         min_number_of_frames_to_be_lost=params.min_frames_lost, min_number_of_frames_to_be_tracked=max(params.min_frames_tracked, 2),
-        use_parallax=params.use_parallax, min_parallax=params.min_parallax_deg)
-    status = eng.prune_poorest_camera_states(filt)
+        use_parallax=params.use_parallax, min_parallax=params.min_parallax_deg, last_camera_measurement=None)
+    if with_lcm:
+        ids = np.array(sorted(feats.keys()), dtype=np.int64)
+        filt.last_camera_measurement = SimpleNamespace(
+            descriptors=np.arange(len(ids) * 4, dtype=np.float64).reshape(len(ids), 4), features_indices=ids.copy())
+    return filt, keys, feats
+
+
+def _check_pruned(eng, filt, keys, feats, prob, ref, status):
     assert status == int(ref["prune_status"])
     left = list(filt.state.cameras.keys())
     assert [i for i, k in enumerate(keys) if k not in left] == list(ref["prune_removed_slots"])
@@ -237,4 +241,29 @@ def test_prune_poorest_camera_states_composed_on_the_device(eng):
     assert len(filt.features) == int(ref["prune_features_left"])
     views = np.array([len(feats[100 + j].camera_indices) if (100 + j) in filt.features else 0 for j in range(prob.F)])
     assert np.array_equal(views, ref["prune_views_left"])
-    assert eng.n_clones == prob.N - 2                        # the engine's resident state lost the two clones as well
+    assert eng.n_clones == prob.N - len(ref["prune_removed_slots"])     # the engine's resident state lost the clones as well
+
+
+def test_prune_poorest_camera_states_composed_on_the_device(eng):
+    """`UpdateEngine.prune_poorest_camera_states(filt)` against the reference's own run of
+    `MSCKF.prune_poorest_camera_states` (MSCKF.py:710-737; fixture sel_prune_poorest): same clones removed, same
+    covariance after update + removal, same poses of the remaining clones, same feature bookkeeping."""
+    prob, tracks, params, ref = load_golden_select("sel_prune_poorest")
+    filt, keys, feats = _filter_from_fixture(prob, tracks, params)
+    status = eng.prune_poorest_camera_states(filt)
+    _check_pruned(eng, filt, keys, feats, prob, ref, status)
+
+
+def test_prune_camera_states_composed_on_the_device(eng):
+    """`UpdateEngine.prune_camera_states(filt)` against the reference's own run of `MSCKF.prune_camera_states`
+    (MSCKF.py:663-680; fixture sel_prune_states: every third clone of a 12-clone window): clones, covariance, poses,
+    counters, and the `last_camera_measurement` entries of the features that lost all their views (:771-777)."""
+    prob, tracks, params, ref = load_golden_select("sel_prune_states")
+    filt, keys, feats = _filter_from_fixture(prob, tracks, params, with_lcm=True)
+    filt.max_number_of_camera_states = int(ref["prune_max_states"])
+    filt.camera_states_to_delete = int(ref["prune_states_to_delete"])
+    status = eng.prune_camera_states(filt)
+    _check_pruned(eng, filt, keys, feats, prob, ref, status)
+    assert int(ref["prune_features_left"]) < prob.F                        # the fixture does exercise :771-777
+    assert np.array_equal(filt.last_camera_measurement.features_indices, ref["prune_lcm_indices_left"])
+    assert np.array_equal(filt.last_camera_measurement.descriptors, ref["prune_lcm_descriptors_left"])

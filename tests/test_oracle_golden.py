@@ -157,6 +157,32 @@ def test_oracle_prune_poorest_composition():
     assert rel_err(P_after, ref["prune_P_after"]) < 1e-11
 
 
+def test_oracle_prune_camera_states_composition():
+    """`MSCKF.prune_camera_states` (MSCKF.py:663-680) restated with the oracle's pieces -- every
+    int(max_states / to_delete)-th clone, their features -> select -> update -> remove_cameras -- against the
+    reference's own run (fixture sel_prune_states)."""
+    from msckf_amd import synth
+    prob, tracks, params, ref = load_golden_select("sel_prune_states")
+    step = int(int(ref["prune_max_states"]) / int(ref["prune_states_to_delete"]))
+    drop = [i for i in range(prob.N) if i > 0 and i % step == 0]
+    assert drop == list(ref["prune_removed_slots"])
+    vp = prob.view_ptr
+    todo = [j for j in range(prob.F) if any(int(s) in drop for s in prob.obs_slot[vp[j]:vp[j + 1]])]
+    sub = prob.take(todo)
+    rows = np.concatenate([np.arange(vp[j], vp[j + 1]) for j in todo])
+    tsub = synth.TrackTable(line_base=tracks.line_base[rows], line_dir=tracks.line_dir[rows], line_conf=tracks.line_conf[rows],
+                            lost_for=tracks.lost_for[todo], tracked_for=tracks.tracked_for[todo])
+    sel = oracle.select_features(sub, tsub, params)
+    valid = np.nonzero(sel["flags"] & 1)[0]
+    upd = sub.take(valid)
+    upd.idp_m, upd.idp_rho = sel["idp_m"][valid], sel["idp_rho"][valid]
+    out = oracle.update(upd, dense_noise=True)
+    assert out["status"] == int(ref["prune_status"])
+    assert rel_err(out["dx"], ref["prune_dx"]) < 1e-9
+    P_after = oracle.remove_clones_covariance(out["P_new"], drop)
+    assert rel_err(P_after, ref["prune_P_after"]) < 1e-11
+
+
 def test_oracle_association_tests_match_reference():
     """f4: `oracle.associate` against the reference's own `add_camera_measurements` loop (MSCKF.py:332-412; fixture
     assoc_tests): which matches were appended, how many failed each test."""
