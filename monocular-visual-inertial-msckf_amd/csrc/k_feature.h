@@ -58,12 +58,17 @@ __host__ __device__ inline int feature_chunk_views(int M) {
     return (M + nch - 1) / nch;
 }
 // LDS doubles needed for a track of M views.  Two layouts (k_feature<RMAX>):
-//   all columns at once (launches whose tracks have at most 11 views): slots, D rows, V, Z, Z P_sub, E (R2 x (6M+1)), S;
+//   all columns at once (launches whose tracks have at most 11 views): slots, D rows, V, Z, E (R2 x (6M+1)); S goes from
+//   E straight into registers, the elimination's staging tile reuses E (round 3: 17.9 -> 12.8 KB at 10 views, 12 instead
+//   of 8 wavefronts per CU);
 //   column chunks (longer tracks): slots, D rows, V, Z, one chunk of E / H_o (+ the rhs column), r_o -- S lives in registers.
 __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
     const int R2 = 2 * M, C6 = 6 * M;
     const int head = (M + 2) / 2 + R2 * 6 + R2 * 3 + 3 * C6;
-    if (!chunked) return head + 3 * C6 + R2 * (C6 + 1) + (R2 + 1) * (R2 + 2) + 8;
+    if (!chunked) {
+        const int stage = R2 * (C6 + 1), elim = (R2 + 1) * (R2 + 3);        // E | the elimination's tile (reuses E)
+        return head + (stage > elim ? stage : elim) + 8;
+    }
     return head + R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2) + 8;
 }
 
@@ -241,28 +246,24 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     double srow[RMAX];
     if constexpr (!CHUNKED) {
     // (tracks of up to 11 views: all 6M columns at once, S staged in LDS -- the faster form while it fits)
-    const int ldE = C6 + 1, ldS = R2 + 2;
-    double* sZP = sZ + 3 * C6;             // [3][C6]   Z * P_sub
-    double* sE = sZP + 3 * C6;             // [R2][ldE] H_o * P_sub
-    double* sS = sE + R2 * ldE;            // [R2+1][ldS]
+    const int ldE = C6 + 1;
+    double* sE = sZ + 3 * C6;              // [R2][ldE] H_o | r_o (K4 staging), then H_o * P_sub (the r_o column stays)
     // ---------------- K4: write the compact block [H_o | r_o] ----------------
     // The rows are staged in sE (free until the gate's first pass) and leave as ONE contiguous range: the q
     // projected rows, row-major with 6M + 1 columns, every lane storing consecutive scalars.
+    // Lanes over COLUMNS (60 of 64 busy at 10 views; round 2 had one lane per row, 20 busy): lane c holds Z[:, c] and
+    // walks the rows, H_o[L][c] = D[L][c] - V[L,:] Z[:, c] with D[L][c] != 0 only for the two rows of c's own view.
     {
-        if (lane < R2) {
-            const double av[6] = {a0, a1, a2, a3, a4, a5};
-            double* erow = sE + lane * ldE;
-            for (int vw = 0; vw < M; ++vw) {
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    const int c = 6 * vw + a;
-                    double x = -(vv0 * sZ[c] + vv1 * sZ[C6 + c] + vv2 * sZ[2 * C6 + c]);
-                    if (vw == view) x += av[a];
-                    erow[c] = x;
-                }
+        for (int c = lane; c < C6; c += 64) {
+            const double z0 = sZ[c], z1 = sZ[C6 + c], z2 = sZ[2 * C6 + c];
+            const int vwc = c / 6, ac = c - 6 * vwc;
+            for (int L = 0; L < R2; ++L) {
+                double x = -(sV[L * 3 + 0] * z0 + sV[L * 3 + 1] * z1 + sV[L * 3 + 2] * z2);
+                if ((L >> 1) == vwc) x += sA[L * 6 + ac];
+                sE[L * ldE + c] = x;
             }
-            erow[C6] = ro;
         }
+        if (lane < R2) sE[lane * ldE + C6] = ro;
         __syncthreads();
         const int nel = q * ldE;
         const double* srcrows = sE + rank * ldE;
@@ -310,7 +311,6 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
 #pragma unroll
             for (int a = 0; a < 6; ++a) pv[a] = pn[a];
         }
-        sZP[c] = zp0; sZP[C6 + c] = zp1; sZP[2 * C6 + c] = zp2;
         // E -= V ZP  (same column, all rows)
         for (int L = 0; L < R2; ++L) {
             sE[L * ldE + c] -= sV[L * 3 + 0] * zp0 + sV[L * 3 + 1] * zp1 + sV[L * 3 + 2] * zp2;
@@ -318,30 +318,38 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     }
     __syncthreads();
     if (p.stamps) tq[4] = wall_clock64();
-    // pass 2, lanes over rows: S[L][L'] = E[L,:] . H_o[L',:]
-    if (lane < R2) {
+    // pass 2, lanes over rows: S[L][L'] = E[L,:] . H_o[L',:] straight into the lane's REGISTER row (no copy of S in LDS);
+    // column R2 is the rhs r_o, lane R2 holds the extra row r_o^T (read from the r_o column of the staging tile)
+    {
         double ez0 = 0, ez1 = 0, ez2 = 0;
-        for (int c = 0; c < C6; ++c) {
-            const double e = sE[lane * ldE + c];
-            ez0 += e * sZ[c]; ez1 += e * sZ[C6 + c]; ez2 += e * sZ[2 * C6 + c];
+        if (lane < R2) {
+            for (int c = 0; c < C6; ++c) {
+                const double e = sE[lane * ldE + c];
+                ez0 += e * sZ[c]; ez1 += e * sZ[C6 + c]; ez2 += e * sZ[2 * C6 + c];
+            }
         }
-        for (int L2 = 0; L2 < R2; ++L2) {
-            const int vw = L2 >> 1;
-            double s = 0.0;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) s += sE[lane * ldE + 6 * vw + a] * sA[L2 * 6 + a];
-            s -= ez0 * sV[L2 * 3 + 0] + ez1 * sV[L2 * 3 + 1] + ez2 * sV[L2 * 3 + 2];
-            if (L2 == lane) s += p.sigma2;
-            sS[lane * ldS + L2] = s;
+        for (int j = 0; j < RMAX; ++j) {
+            double x = 0.0;
+            if (j < R2) {                                           // (uniform)
+                if (lane < R2) {
+                    const int vw = j >> 1;
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) sacc += sE[lane * ldE + 6 * vw + a] * sA[j * 6 + a];
+                    sacc -= ez0 * sV[j * 3 + 0] + ez1 * sV[j * 3 + 1] + ez2 * sV[j * 3 + 2];
+                    if (j == lane) sacc += p.sigma2;
+                    x = sacc;
+                } else if (lane == R2) {
+                    x = sE[j * ldE + C6];                           // r_o of row j
+                }
+            } else if (j == R2) {
+                if (lane < R2) x = ro;
+            }
+            srow[j] = x;
         }
-        sS[lane * ldS + R2] = ro;          // rhs column
-        sS[R2 * ldS + lane] = ro;          // extra row r_o^T
     }
-    if (lane == 0) sS[R2 * ldS + R2] = 0.0;
-    __syncthreads();
     if (p.stamps) tq[5] = wall_clock64();
-#pragma unroll
-    for (int j = 0; j < RMAX; ++j) srow[j] = (j <= R2 && lane <= R2) ? sS[lane * ldS + j] : 0.0;
     } else {
     const int CV = feature_chunk_views(M);   // views per column chunk
     const int ldE = 6 * CV + 1;
