@@ -51,7 +51,7 @@ extern "C" {
 #define MSCKF_ERR_DUP_SLOT (-6)     /* a track observes the same clone slot twice           */
 
 #define MSCKF_FLAG_TREE_PLAN 1      /* K5: always the merge tree (default: the band pipeline
-                                       whenever every track spans <= 16 clone slots,
+                                       whenever every track spans <= 15 clone slots,
                                        see msckf_band_rule)                                */
 
 #define MSCKF_DTYPE_F64 0
@@ -263,12 +263,20 @@ int msckf_run_merge_gain(msckf_ctx* ctx, const void* blocks, int32_t n_blocks, i
  * msckf_set_group_exchange must precede msckf_set_features; msckf_export_groups returns MSCKF_ERR_STATE
  * when the batch was planned as a merge tree (then use msckf_export_block / msckf_run_merge_gain). */
 int msckf_set_group_exchange(msckf_ctx* ctx, int on);
-/* The planner's rule, for callers that must agree on the exchange format BEFORE sharding a batch: 1 when a
+/* The longest track of the WHOLE batch in clone slots (last slot - first slot + 1 over every shard; 0 = not told).
+ * With it every shard lays its record out for the sweep mode of the whole batch (msckf_band_rule), whatever its own
+ * tracks look like, and the group exchange also covers the ring-buffered modes: N > 37 clones (60-column slots) and
+ * tracks of 11 - 15 slots (90-column slots, BASELINE.json configs[4]: N = 50, track 15).  Without it only the
+ * 60-column k_sweep form (every track <= 10 slots, N <= 37) is exchanged as group records.  Same value on every
+ * rank; call before msckf_set_features. */
+int msckf_set_exchange_span(msckf_ctx* ctx, int32_t max_span);
+/* The planner's rule, for callers that must agree on the exchange format BEFORE sharding a batch: > 0 when a
  * batch of tracks spanning at most `max_span` clone slots over N clones is planned as the band pipeline on
- * this context (so msckf_export_groups will work), 0 when it gets the merge tree (MSCKF_FLAG_TREE_PLAN,
- * tracks wider than the sweep tiles, band R over the LDS budget): then use msckf_export_block. */
+ * this context (1 k_sweep, 2 k_wsweep<4> with the band in a ring, 3 k_wsweep<6> with 90-column tiles; group
+ * records work for all three once msckf_set_exchange_span told the span), 0 when it gets the merge tree
+ * (MSCKF_FLAG_TREE_PLAN, tracks wider than 15 slots): then use msckf_export_block. */
 int msckf_band_rule(const msckf_ctx* ctx, int32_t N, int32_t max_span);
-size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + gate-byte doubles (msckf_set_exchange_mask) + N * 3660 */
+size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + gate-byte doubles (msckf_set_exchange_mask) + N * 3660 (8190 with 90-column slots) */
 int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted /* nullable */);
 int msckf_run_merge_groups(msckf_ctx* ctx, const void* records, int32_t n_records, int device_ptr,
                            int32_t total_accepted /* < 0: the sum of the counts in the records */);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "msckf_propagate", "msckf_augment", "msckf_remove_clones", "msckf_set_poses", "msckf_get_covariance",
     "msckf_comm_unique_id", "msckf_comm_init", "msckf_comm_destroy", "msckf_comm_gather", "msckf_comm_broadcast",
     "msckf_comm_allreduce", "msckf_comm_buffer", "msckf_comm_put", "msckf_comm_get",
-    "msckf_set_exchange_mask", "msckf_result_range_doubles", "msckf_get_shared_result",
+    "msckf_set_exchange_mask", "msckf_result_range_doubles", "msckf_get_shared_result", "msckf_set_exchange_span",
 ]
 
 
@@ -143,6 +143,8 @@ def load():
     lib.msckf_comm_put.restype = C.c_int
     lib.msckf_comm_get.argtypes = [vp, vp, vp, C.c_size_t]
     lib.msckf_comm_get.restype = C.c_int
+    lib.msckf_set_exchange_span.argtypes = [vp, C.c_int32]
+    lib.msckf_set_exchange_span.restype = C.c_int
     lib.msckf_set_exchange_mask.argtypes = [vp, C.c_int32, _ip]
     lib.msckf_set_exchange_mask.restype = C.c_int
     lib.msckf_result_range_doubles.argtypes = [vp]

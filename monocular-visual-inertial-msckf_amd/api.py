@@ -396,11 +396,17 @@ class UpdateEngine:
         rc = self._lib.msckf_band_rule(self._h, int(prob.N), self.max_span(prob))
         if rc < 0:
             self._check(rc, allow_noop=False)
-        return rc == 1
+        return rc >= 1
 
     def set_group_exchange(self, on: bool = True):
         """Plan the following batches with the group-record layout (call before `load`)."""
         self._check(self._lib.msckf_set_group_exchange(self._h, 1 if on else 0), allow_noop=False)
+
+    def set_exchange_span(self, max_span: int):
+        """Tell the engine the longest track of the WHOLE batch (clone slots) before its shard is loaded: every rank
+        then lays its group record out for the sweep mode of the whole batch (also the ring-buffered modes, N > 37
+        or tracks of 11 - 15 slots).  0 = not told (60-column k_sweep form only)."""
+        self._check(self._lib.msckf_set_exchange_span(self._h, int(max_span)), allow_noop=False)
 
     def group_record_doubles(self) -> int:
         return int(self._lib.msckf_group_record_doubles(self._h))

@@ -75,7 +75,10 @@ constexpr int LS_BIG_BATCH = 4000;               // from this many features on t
 constexpr bool SWEEP_P2P = MSCKF_SWEEP_P2P != 0;  // root sweep: point-to-point progress words instead of a barrier per step
 constexpr int SWEEP_NW = MSCKF_SWEEP_NW;         // concurrent folds of k_sweep
 constexpr int SWEEP_WPF = MSCKF_SWEEP_WPF;       // wavefronts per fold (1 or 2)
-constexpr size_t XCHG_SLOT = (size_t)SWEEP_MAX_W * (SWEEP_MAX_W + 1);   // doubles per group triangle in an export record
+// Group exchange: a shard's record holds one triangle slot per first clone slot; the slot is as wide as the sweep tile of
+// the batch's mode (60 columns for k_sweep / k_wsweep<4>, 90 for k_wsweep<6>), whatever the shard's own tracks look like.
+inline int xchg_w(int mode) { return mode == 2 ? WSweepGeom<6>::MAX_W : SWEEP_MAX_W; }
+inline size_t xchg_slot(int mode) { return (size_t)xchg_w(mode) * (xchg_w(mode) + 1); }
 constexpr int FOLD_LDS_BYTES = 160 * 1024 - 512;
 
 inline int fold_class(int w) { return (w + 1 <= 64) ? 1 : (w + 1 <= 128) ? 2 : 3; }
@@ -158,6 +161,7 @@ struct msckf_ctx {
     size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
     // group exchange (sharded band pipeline): the group triangles live in one export record at the head of rbuf
     bool xchg = false;                    // requested by msckf_set_group_exchange
+    int xchg_span = 0;                    // longest track of the WHOLE batch in clone slots (msckf_set_exchange_span); 0: not told
     bool xchg_planned = false;            // the current plan has the record layout
     std::vector<double> h_xflags;         // [N] 1.0 where this shard has tracks starting at the slot
     std::vector<double> x_key;            // flags of the last merged records (plan cache of msckf_run_merge_groups)
@@ -290,6 +294,14 @@ void seat_result_views(msckf_ctx* c) {
 
 // doubles in front of the group triangles of an export record: N flags | accepted count | gate bytes
 inline size_t rec_head(const msckf_ctx* c) { return (size_t)c->N + 1 + (size_t)c->xmask_doubles; }
+int sweep_mode_for(const msckf_ctx* c, int N, int max_span);
+// sweep mode of the group exchange at N clones: that of the whole batch's longest track when the caller told it
+// (every rank then lays its record out alike), else the 60-column k_sweep form only (-1: no group exchange)
+inline int xchg_mode(const msckf_ctx* c, int N) {
+    if (c->xchg_span > 0) return sweep_mode_for(c, N, c->xchg_span);
+    return sweep_mode_for(c, N, 1) == 0 ? 0 : -1;
+}
+inline size_t rec_slot(const msckf_ctx* c) { const int m = xchg_mode(c, c->N); return xchg_slot(m < 0 ? 0 : m); }
 
 // the clone set changed: feature batch, plan and results of the old layout are void
 void invalidate_batch(msckf_ctx* c) {
@@ -420,7 +432,7 @@ int sweep_mode_for(const msckf_ctx* c, int N, int max_span) {
 }
 // THE rule for the group exchange of the sharded band pipeline (msckf_band_rule exports it): the record
 // layout and the merging rank's sweeps are those of k_sweep.
-bool band_rule(const msckf_ctx* c, int N, int max_span) { return sweep_mode_for(c, N, max_span) == 0; }
+bool band_rule(const msckf_ctx* c, int N, int max_span) { return sweep_mode_for(c, N, max_span) >= 0; }
 
 // k_wsweep: rows of R no present or future fold step touches at the head of macro step t (the schedule is
 // static).  Entry t = lo | n << 16: rows [lo, lo + n) leave the ring at the head of step t; entry nsteps covers
@@ -457,10 +469,16 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     int max_span = 0;
     for (int f = 0; f < F; ++f)
         if (live(f)) max_span = std::max(max_span, fmax[f] - fmin[f] + 1);
+    if (c->xchg && c->xchg_span > 0) {
+        if (max_span > c->xchg_span) return false;                        // the caller's figure does not cover this shard: root blocks
+        max_span = c->xchg_span;                                          // every shard plans with the mode of the whole batch
+    }
     const int mode = sweep_mode_for(c, N, max_span);
     if (mode < 0) return false;
-    if (c->xchg && mode != 0) return false;                               // the exchange records are k_sweep's: root blocks then
+    if (c->xchg && c->xchg_span == 0 && mode != 0) return false;          // (not told the batch's span: the 60-column k_sweep form only)
     c->sweep_mode = mode;
+    const size_t XCHG_SLOT = xchg_slot(mode);
+    const int XW = xchg_w(mode);
     // Leaf nodes (k_lsweep): one workgroup folds NF row blocks at a time, a block holds `fpb` features, so a node
     // gets a multiple of NF * fpb features: enough nodes to fill the chip once, at most 128 features each.
     // cfg.leaf_rows > 0 (tests) cuts the leaves by stacked rows instead.
@@ -511,7 +529,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
                 ++e;
             }
             FoldNode n{};
-            if (xchg) hi = std::min(s + SWEEP_MAX_W / 6, N) - 1;
+            if (xchg) hi = std::min(s + XW / 6, N) - 1;
             n.kind = 0; n.src_begin = f; n.src_end = last + 1; n.win_lo = s; n.w = 6 * (hi - s + 1); n.pad = 0;
             n.out_off = (long long)off;
             off += (size_t)n.w * (n.w + 1);
@@ -710,18 +728,18 @@ int launch_leaves_band(msckf_ctx* c) {
 
 // band plan, levels 1-2: group merges (one workgroup each), then the root sweep
 template <int CS>
-void launch_wsweep(msckf_ctx* c, int node_base, int count, int rc_log2) {
+void launch_wsweep(msckf_ctx* c, int node_base, int count, int rc_log2, int nsteps_max = -1, const double* zero = nullptr) {
     WSweepArgs a{};
     a.nodes = ptr<SweepNode>(c->dSweepNodes);
     a.folds = ptr<SweepFold>(c->dSweepFolds);
     a.node_base = node_base;
     a.rbuf = ptr<double>(c->dRbuf);
-    a.zero = ptr<double>(c->dRbuf) + c->zero_off;
+    a.zero = zero ? zero : ptr<double>(c->dRbuf) + c->zero_off;
     a.flush = ptr<int>(c->dFlush);
     a.flush_off = ptr<int>(c->dFlushOff);
     a.rc_log2 = rc_log2;
-    int nsteps = 0;
-    for (int i = node_base; i < node_base + count; ++i) nsteps = std::max(nsteps, c->snodes[i].nsteps);
+    int nsteps = nsteps_max;
+    if (nsteps < 0) { nsteps = 0; for (int i = node_base; i < node_base + count; ++i) nsteps = std::max(nsteps, c->snodes[i].nsteps); }
     hipLaunchKernelGGL((k_wsweep<SWEEP_NW, CS>), dim3(count), dim3(64 * SWEEP_NW), wsweep_lds_bytes<CS>(1 << rc_log2, SWEEP_NW, nsteps),
                        c->stream, a);
 }
@@ -1247,7 +1265,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         if (c->xchg) {
             // a shard without tracks still takes part in the gather: an empty record (no flag, count 0, no gate byte)
             // heads the workspace; the triangles behind it are never read (the merging rank goes by the flags)
-            const size_t need = (rec_head(c) + (size_t)N * XCHG_SLOT + 16) * 8;
+            const size_t need = (rec_head(c) + (size_t)N * rec_slot(c) + 16) * 8;
             if (c->dRbuf.bytes < need) {
                 if (c->dRbuf.p) HIPCHK(c, hipFree(c->dRbuf.p));
                 c->dRbuf.p = nullptr; c->dRbuf.bytes = 0;
@@ -1257,7 +1275,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, rec_head(c) * 8, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             c->xchg_planned = true;
-            c->rbuf_doubles = rec_head(c) + (size_t)N * XCHG_SLOT;
+            c->rbuf_doubles = rec_head(c) + (size_t)N * rec_slot(c);
             c->gather_off = c->rbuf_doubles;
         }
         c->have_features = true;
@@ -1978,17 +1996,28 @@ int msckf_set_group_exchange(msckf_ctx* c, int on) {
     if (!c) return MSCKF_ERR_ARG;
     c->xchg = on != 0;
     c->have_features = false;             // the next msckf_set_features plans with the new layout
+    c->plan_valid = false;
+    c->ran = false;
+    return MSCKF_OK;
+}
+
+int msckf_set_exchange_span(msckf_ctx* c, int32_t max_span) {
+    if (!c || max_span < 0) return MSCKF_ERR_ARG;
+    c->xchg_span = max_span;
+    c->have_features = false;
+    c->plan_valid = false;
+    c->x_plan_valid = false;
     c->ran = false;
     return MSCKF_OK;
 }
 
 int msckf_band_rule(const msckf_ctx* c, int32_t N, int32_t max_span) {
     if (!c || N < 0 || max_span < 0) return MSCKF_ERR_ARG;
-    return band_rule(c, N, max_span) ? 1 : 0;
+    return sweep_mode_for(c, N, max_span) + 1;         // 0 merge tree, 1 k_sweep, 2 k_wsweep<4> (ring), 3 k_wsweep<6> (90-column tiles)
 }
 
 size_t msckf_group_record_doubles(const msckf_ctx* c) {
-    return c ? rec_head(c) + (size_t)c->N * XCHG_SLOT : 0;
+    return c ? rec_head(c) + (size_t)c->N * rec_slot(c) : 0;
 }
 
 int msckf_export_groups(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accepted) {
@@ -2048,7 +2077,10 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     if (!c->have_state) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->N, dc = c->dc;
-    if (!band_rule(c, N, 1)) return MSCKF_ERR_ARG;
+    const int xmode = xchg_mode(c, N);
+    if (xmode < 0) return MSCKF_ERR_ARG;
+    const size_t XCHG_SLOT = xchg_slot(xmode);
+    const int XW = xchg_w(xmode);
     const size_t rec = msckf_group_record_doubles(c);
     // workspace behind the local plan: records | merged group triangles | root block | zero words
     const size_t o_rec = c->gather_off, o_mrg = o_rec + (size_t)n_rec * rec, o_root = o_mrg + (size_t)N * XCHG_SLOT;
@@ -2106,7 +2138,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         std::vector<Tri> groups;
         std::vector<SweepFold>& fl = c->x_sfolds;
         for (int s0 = 0; s0 < N; ++s0) {
-            const int w = 6 * (std::min(s0 + SWEEP_MAX_W / 6, N) - s0);
+            const int w = 6 * (std::min(s0 + XW / 6, N) - s0);
             std::vector<long long> src;
             for (int r = 0; r < n_rec; ++r)
                 if (key[(size_t)r * N + s0] != 0.0) src.push_back(rec_base + (long long)((size_t)r * rec + rec_head(c) + (size_t)s0 * XCHG_SLOT));
@@ -2145,6 +2177,24 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         all_n.insert(all_n.end(), c->x_snodes.begin(), c->x_snodes.end());
         std::vector<SweepFold> all_f(c->sfolds);
         all_f.insert(all_f.end(), fl.begin(), fl.end());
+        if (xmode > 0) {
+            // k_wsweep: which rows of R leave the ring at the head of every macro step (tables behind the local plan's)
+            const int rc = 1 << (xmode == 1 ? WS_RC_LOG2_4 : WS_RC_LOG2_6);
+            std::vector<int> fl_tab(c->h_flush), fl_off(c->h_flush_off);
+            fl_off.resize(c->snodes.size(), 0);
+            for (const SweepNode& nd : c->x_snodes) {
+                fl_off.push_back((int)fl_tab.size());
+                if (!sweep_flush_table(fl, nd.fold_begin - fold_base, nd.fold_end - fold_base, nd.nsteps, nd.wtot, rc, fl_tab)) {
+                    c->last_error = "merge plan: the band does not fit the ring of k_wsweep";
+                    return MSCKF_ERR_ARG;
+                }
+            }
+            if (int rc2 = ensure(c, c->dFlush, fl_tab.size() * 4)) return rc2;
+            if (int rc2 = ensure(c, c->dFlushOff, fl_off.size() * 4)) return rc2;
+            HIPCHK(c, hipMemcpyAsync(c->dFlush.p, fl_tab.data(), fl_tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->dFlushOff.p, fl_off.data(), fl_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));                              // fl_tab / fl_off are locals
+        }
         if (int rc = ensure(c, c->dSweepNodes, std::max<size_t>(all_n.size(), 1) * sizeof(SweepNode))) return rc;
         if (int rc = ensure(c, c->dSweepFolds, std::max<size_t>(all_f.size(), 1) * sizeof(SweepFold))) return rc;
         if (!all_n.empty()) HIPCHK(c, hipMemcpyAsync(c->dSweepNodes.p, all_n.data(), all_n.size() * sizeof(SweepNode), hipMemcpyHostToDevice, c->stream));
@@ -2163,6 +2213,28 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         c->ran = true; c->ran_gain = false; c->acc_override = 0; c->acc_from_dev = false;
         return MSCKF_OK;
     }
+    const int nb = (int)c->snodes.size();
+    if (xmode > 0) {
+        // ring-buffered sweeps (N > 37 or tracks of 11-15 slots): cross-rank group merges in one launch, then the root
+        int ms = 0;
+        for (int i = 0; i < c->x_n_merges; ++i) ms = std::max(ms, c->x_snodes[i].nsteps);
+        const int rs = c->x_snodes.back().nsteps;
+        if (xmode == 1) {
+            if (c->x_n_merges > 0) launch_wsweep<4>(c, nb, c->x_n_merges, WS_RC_LOG2_4, ms, rb + c->x_zero_off);
+            launch_wsweep<4>(c, nb + c->x_n_merges, 1, WS_RC_LOG2_4, rs, rb + c->x_zero_off);
+        } else {
+            if (c->x_n_merges > 0) launch_wsweep<6>(c, nb, c->x_n_merges, WS_RC_LOG2_6, ms, rb + c->x_zero_off);
+            launch_wsweep<6>(c, nb + c->x_n_merges, 1, WS_RC_LOG2_6, rs, rb + c->x_zero_off);
+        }
+        HIPCHK(c, hipGetLastError());
+        int rcg = launch_gain(c, rb + c->x_root_off);
+        if (rcg != MSCKF_OK) return rcg;
+        if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
+        c->ran = true; c->ran_gain = true;
+        c->acc_override = total_accepted;
+        c->acc_from_dev = count_on_device;
+        return MSCKF_OK;
+    }
     SweepArgs a{};
     a.nodes = ptr<SweepNode>(c->dSweepNodes);
     a.folds = ptr<SweepFold>(c->dSweepFolds);
@@ -2170,7 +2242,6 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     a.stamps = nullptr;
     a.zero = rb + c->x_zero_off;
     const dim3 block(64 * SWEEP_NW * SWEEP_WPF);
-    const int nb = (int)c->snodes.size();
     if (c->x_n_merges > 0) {
         a.node_base = nb;
         hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(c->x_n_merges), block,

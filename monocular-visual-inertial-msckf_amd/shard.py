@@ -59,6 +59,7 @@ class HipShardBackend:
     def prepare(self, prob: UpdateProblem):
         self.groups = bool(self.engine.band_ok(prob))
         self.engine.set_group_exchange(self.groups)
+        self.engine.set_exchange_span(self.engine.max_span(prob) if self.groups else 0)   # every rank: the mode of the whole batch
 
     def compress(self, local: UpdateProblem):
         self.engine.load(local)
@@ -200,6 +201,7 @@ class RcclShardedUpdate:
         self.bounds = np.array([s[0] for s in shards] + [shards[-1][1]], dtype=np.int32)
         self.groups = bool(e.band_ok(prob))
         e.set_group_exchange(self.groups)
+        e.set_exchange_span(e.max_span(prob) if self.groups else 0)    # every rank: the sweep mode of the whole batch
         e.set_exchange_mask(self.bounds)
         lo, hi = shards[self.rank]
         e.load(prob.subset(lo, hi))

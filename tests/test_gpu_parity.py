@@ -466,7 +466,7 @@ def test_group_exchange_shards_on_one_gpu(N, F, M, shards, kw):
         assert rel_err(one.dx, ref["dx"]) < TOL and rel_err(one.P_new, ref["P_new"]) < TOL
 
 
-def _shipped_merge(e, prob, shards, ref):
+def _shipped_merge(e, prob, shards, ref, tol_dx=TOL, tol_P=TOL):
     """The exact call sequence of `RcclShardedUpdate.load / step / result` with S logical shards on ONE engine: every
     shard's record is copied (in HBM) into slot r of the exchange buffer -- what the RCCL gather does --, rank 0's
     `merge_groups_flags` with the flags of the partition, then the shared result range is read the way every rank
@@ -474,6 +474,7 @@ def _shipped_merge(e, prob, shards, ref):
     from msckf_amd.shard import shard_group_flags
     bounds = np.array([sh[0] for sh in shards] + [shards[-1][1]], dtype=np.int32)
     e.set_group_exchange(True)
+    e.set_exchange_span(e.max_span(prob))                     # every shard: the record layout of the whole batch's sweep mode
     e.set_exchange_mask(bounds)
     count = None
     recv = 0
@@ -497,10 +498,11 @@ def _shipped_merge(e, prob, shards, ref):
         assert res.stats["n_accepted"] == int(ref["accepted"].sum())
         assert res.n_rejected == prob.F - int(ref["accepted"].sum())
         if ref["status"] == 0:
-            assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+            assert rel_err(res.dx, ref["dx"]) < tol_dx and rel_err(res.P_new, ref["P_new"]) < tol_P
         else:
             assert not res.dx.any() and np.array_equal(res.P_new, prob.P)
     e.set_exchange_mask(None)
+    e.set_exchange_span(0)
     e.set_group_exchange(False)
     return res
 
@@ -511,6 +513,10 @@ def _shipped_merge(e, prob, shards, ref):
     (12, 60, 10, 4, {"variable_tracks": True}),              # shards without tracks at some first slots
     (10, 3, 5, 4, {}),                                       # fewer features than ranks: an empty shard takes part
     (8, 20, 5, 3, {"sigma": 0.01, "pixel_noise": 80.0}),     # nothing passes the gate anywhere: no-op on every rank
+    (40, 1200, 10, 4, {}),                                   # N > 37: band R in a ring (k_wsweep<4>), 60-column slots
+    (24, 600, 15, 3, {"variable_tracks": True}),             # tracks of up to 15 slots: 90-column slots (k_wsweep<6>), ragged:
+                                                             # shards whose own tracks are short lay their records out alike
+    (50, 900, 15, 8, {"outlier_fraction": 0.05, "outlier_px": 500.0}),   # N = 50, track 15: ring + 90 columns + two-block K6
 ])
 def test_shipped_merge_path_logical_shards(N, F, M, S, kw):
     from msckf_amd import synth
@@ -523,6 +529,20 @@ def test_shipped_merge_path_logical_shards(N, F, M, S, kw):
     with UpdateEngine(max_clones=N + 3, max_features=max(F, 8), max_track=max(M, 2)) as e:    # (capacity above N on purpose)
         assert e.band_ok(prob)
         _shipped_merge(e, prob, shards, ref)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_shipped_merge_path_config5_full_size(dtype):
+    """BASELINE.json configs[4] (N = 50, 20000 features, track 15) split over 8 logical shards, in fp64 and as specified
+    (fp32 storage + f32 MFMA P-update): group records with 90-column slots, rank 0 folds them with k_wsweep<6> and runs
+    ONE ring-buffered root sweep and the two-block K6 -- no root blocks through host memory, no k_fold_g levels."""
+    from msckf_amd.api import UpdateEngine
+    from msckf_amd.shard import partition_features
+    prob, ref = _big_case(50, 20000, 15)
+    tol = (TOL, TOL) if dtype == "f64" else (1e-4, 1e-5)      # tolerance of the fp32 mode: tests/test_gpu_f32.py
+    with UpdateEngine(max_clones=50, max_features=20000, max_track=15, dtype=dtype) as e:
+        assert e.band_ok(prob)
+        _shipped_merge(e, prob, partition_features(prob.view_ptr, 8), ref, *tol)
 
 
 @pytest.mark.parametrize("S", [2, 4, 8])
@@ -565,7 +585,7 @@ def test_result_range_follows_the_current_window():
 def test_group_exchange_refuses_tree_planned_batches(eng):
     from msckf_amd import synth
     from msckf_amd._ffi import EngineError
-    prob = synth.make_problem(16, 120, 14, seed=36)          # tracks of 14 slots: merge tree
+    prob = synth.make_problem(16, 120, 16, seed=36)          # tracks of 16 slots: wider than the sweep tiles, merge tree
     assert not eng.band_ok(prob)
     eng.set_group_exchange(True)
     try:
@@ -651,6 +671,9 @@ def test_band_rule_comes_from_the_library():
     with UpdateEngine(max_clones=64, max_features=500, max_track=31) as e:
         assert e.band_ok(narrow)
         assert e.band_ok(synth.make_problem(12, 40, 10, seed=2, variable_tracks=True))
+        assert e.band_ok(synth.make_problem(45, 300, 10, seed=4))              # N > 37: band R in a ring
+        assert e.band_ok(synth.make_problem(20, 100, 15, seed=5))              # tracks of 15 slots: 90-column tiles
+        assert not e.band_ok(synth.make_problem(20, 60, 16, seed=6))           # 16 slots: wider than the tiles
         assert not e.band_ok(synth.make_problem(40, 40, 31, seed=3))           # tracks of 31 slots: merge tree
         assert not e.band_ok(synth.make_problem(5, 0, 3, seed=0))              # empty batch
     with UpdateEngine(max_clones=30, max_features=500, max_track=10, plan="tree") as e:

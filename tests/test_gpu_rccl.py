@@ -51,7 +51,7 @@ print("RCCL_ABI_OK", flush=True)
 
 # RcclShardedUpdate (the driver bench.py --gpus N runs): compress -> RCCL gather -> merge + gain -> RCCL broadcast, all on
 # the engine's stream; group records where the batch runs the 60-column band pipeline, root blocks otherwise
-for (N, F, M, groups) in [(30, 2000, 10, True), (16, 120, 14, False)]:
+for (N, F, M, groups) in [(30, 2000, 10, True), (16, 120, 14, True), (20, 120, 18, False)]:
     prob = synth.make_problem(N, F, M, seed=81, outlier_fraction=0.05, outlier_px=400.0)
     ref = oracle.update(prob, dense_noise=False)
     with tempfile.TemporaryDirectory() as td, UpdateEngine(max_clones=N, max_features=F, max_track=M) as e:
@@ -88,7 +88,7 @@ def test_rccl_exchange_through_the_abi():
     not mix with the system ones inside one process; the product path never imports it)."""
     r = subprocess.run([sys.executable, "-c", _RCCL_CODE % {"root": ROOT}], capture_output=True, text=True, timeout=600)
     out = r.stdout + r.stderr
-    assert "RCCL_ABI_OK" in out and out.count("RCCL_STEP_OK") == 2, out[-3000:]
+    assert "RCCL_ABI_OK" in out and out.count("RCCL_STEP_OK") == 3, out[-3000:]
 
 
 _WORKER = r"""
@@ -105,7 +105,7 @@ from msckf_amd.api import UpdateEngine
 from msckf_amd.shard import ShardedUpdate, HipShardBackend
 from oracle import msckf_oracle as oracle
 ok = True
-for (N, F, M, kw) in [(30, 600, 10, {}), (12, 80, 12, {"variable_tracks": True})]:
+for (N, F, M, kw) in [(30, 600, 10, {}), (12, 80, 12, {"variable_tracks": True}), (20, 100, 18, {})]:
     prob = synth.make_problem(N, F, M, seed=91, **kw)
     with UpdateEngine(max_clones=N, max_features=F, max_track=M, device=0) as e:
         drv = ShardedUpdate(HipShardBackend(e), rank, world, dist)
@@ -123,8 +123,8 @@ print("SHARD_WORLD2_OK" if ok else "SHARD_WORLD2_FAIL", flush=True)
 
 def test_sharded_driver_world2_on_the_hip_path():
     """ShardedUpdate(HipShardBackend) with a real process group of two ranks: both compress their shard on the
-    GPU, rank 0 merges (group records for the first batch, root blocks for the wide ragged one), everyone gets
-    dx / P+ / the mask."""
+    GPU, rank 0 merges (group records for the first two batches -- 60- and 90-column slots --, root blocks for the
+    tracks of 18 slots), everyone gets dx / P+ / the mask."""
     with tempfile.TemporaryDirectory() as td:
         code = _WORKER % {"root": ROOT}
         store = os.path.join(td, "store")
