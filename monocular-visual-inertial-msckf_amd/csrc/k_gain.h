@@ -50,25 +50,27 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f64(GemmArgs g) {
     if (g.tri == 1) kbeg = n0;
     else if (g.tri == 2) kbeg = m0;
     const int klen = g.K - kbeg;
-    const int kq = (klen + 4 * GEMM_WAVES - 1) / (4 * GEMM_WAVES);   // per-group piece
-    const int k_lo = kbeg + grp * kq;
-    const int k_hi = min(g.K, k_lo + kq);
+    const int kq = (klen + 4 * GEMM_WAVES - 1) / (4 * GEMM_WAVES);   // MFMA steps per wavefront
+    // wavefront w covers k in [kbeg + 4 kq w, + 4 kq); at step u its four 16-lane groups take k = .. + 4 u + group, so one
+    // load instruction touches 16 rows x 32 contiguous bytes (round 2: every group streamed its own piece, 64 different
+    // cache lines per instruction -- the products were bound by the texture addresser, not by the matrix cores)
+    const int k_lo = kbeg + wv * 4 * kq + (lane >> 4);
+    const int k_hi = g.K;
+    (void)grp;
     const int arow = m0 + r, bcol = n0 + r;
     const bool aok = arow < g.M, bok = bcol < g.N;
-    const double* ap = g.A + (size_t)arow * g.lda;
     v4d acc = {0.0, 0.0, 0.0, 0.0};
     // GEMM_TRIP k-steps per trip, all loads of a trip issued before its first MFMA (K <= 256 is one trip)
     constexpr int GEMM_TRIP = 16;
     if (g.transB) {
-        const double* bp = g.B + (size_t)bcol * g.ldb;
         for (int s0 = 0; s0 < kq; s0 += GEMM_TRIP) {
             double av[GEMM_TRIP], bv[GEMM_TRIP];
 #pragma unroll
             for (int u = 0; u < GEMM_TRIP; ++u) {
-                const int k = k_lo + s0 + u;
+                const int k = k_lo + 4 * (s0 + u);
                 const bool kok = (s0 + u < kq) && (k < k_hi);
-                av[u] = (aok && kok) ? ap[k] : 0.0;
-                bv[u] = (bok && kok) ? bp[k] : 0.0;
+                av[u] = (aok && kok) ? g.A[(size_t)arow * g.lda + k] : 0.0;
+                bv[u] = (bok && kok) ? g.B[(size_t)bcol * g.ldb + k] : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < GEMM_TRIP; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
@@ -78,9 +80,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f64(GemmArgs g) {
             double av[GEMM_TRIP], bv[GEMM_TRIP];
 #pragma unroll
             for (int u = 0; u < GEMM_TRIP; ++u) {
-                const int k = k_lo + s0 + u;
+                const int k = k_lo + 4 * (s0 + u);
                 const bool kok = (s0 + u < kq) && (k < k_hi);
-                av[u] = (aok && kok) ? ap[k] : 0.0;
+                av[u] = (aok && kok) ? g.A[(size_t)arow * g.lda + k] : 0.0;
                 bv[u] = (bok && kok) ? g.B[(size_t)k * g.ldb + bcol] : 0.0;
             }
 #pragma unroll
@@ -99,6 +101,84 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f64(GemmArgs g) {
         if (g.C0) x += g.beta * c0;
         if (orow == ocol) x += g.diag_add;
         g.C[(size_t)orow * g.ldc + ocol] = x;
+    }
+}
+
+// Joseph covariance update (MSCKF.py:612-614) in ONE launch.  With Y = P T_H^T and S = T_H P T_H^T + sigma^2 I the form
+//     P+ = (I - K T_H) P (I - K T_H)^T + sigma^2 K K^T
+// expands to  Pn = P - K Y^T - Y K^T + K S K^T  =  P - K Y^T + W K^T,  W = K S - Y  (the residual of K = Y S^-1: the Joseph
+// correction), and P_out = (Pn + Pn^T) / 2.  One workgroup per PAIR of 16 x 16 tiles (I, J), I <= J: both tiles of Pn
+// over the virtual product depth 2 dc ([-K | W] [Y | K]^T, cut into 32 contiguous pieces as in k_gemm_f64), the halves
+// of the symmetrisation meet in LDS and both mirror tiles of P_out leave bit-equal.  Round 2 ran B2, D, Pn and the
+// symmetrisation as four launches of ~5 us each.
+struct JosephArgs {
+    const double* P; int ldp;     // prior covariance (d x d)
+    const double* K;              // gain (d x dc)
+    const double* Y;              // P T_H^T (d x dc)
+    const double* W;              // K S - Y (d x dc)
+    double* Pout; int ldo;
+    int d, dc;
+};
+__global__ __launch_bounds__(64 * GEMM_WAVES) void k_joseph_f64(JosephArgs g) {
+    __shared__ double sAcc[2][GEMM_WAVES][4][64];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (ti > tj) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m0 = ti * 16, n0 = tj * 16;
+    const int r = lane & 15, grp = wv * 4 + (lane >> 4);
+    const int K2 = 2 * g.dc;
+    const int kq = (K2 + 4 * GEMM_WAVES - 1) / (4 * GEMM_WAVES);
+    const int k_lo = wv * 4 * kq + (lane >> 4);      // (k = k_lo + 4 u: 16 rows x 32 contiguous bytes per load instruction)
+    (void)grp;
+    constexpr int TRIP = 16;                        // 2 dc <= 512: one trip
+    const bool ra = m0 + r < g.d, rb = n0 + r < g.d;
+    const size_t oa = (size_t)(m0 + r) * g.dc, ob = (size_t)(n0 + r) * g.dc;
+    v4d acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < kq; s0 += TRIP) {
+        double a1[TRIP], b1[TRIP], a2[TRIP], b2[TRIP];
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) {
+            const int k = k_lo + 4 * (s0 + u);
+            const bool kok = (s0 + u < kq) && (k < K2);
+            const bool first = k < g.dc;               // [-K | W] [Y | K]^T
+            const int kk = first ? k : k - g.dc;
+            // tile (I, J): rows m0.., columns n0..; tile (J, I): rows n0.., columns m0..  (unconditional loads from
+            // selected / clamped addresses: guarded loads compile to an exec-mask branch each)
+            const double* Ap = first ? g.K : g.W;
+            const double* Bp = first ? g.Y : g.K;
+            const double sgn = first ? -1.0 : 1.0;
+            const bool va = kok && ra, vb = kok && rb;
+            const size_t ia = va ? oa + kk : 0, ib = vb ? ob + kk : 0;
+            const double xa1 = Ap[ia], xb1 = Bp[ib], xa2 = Ap[ib], xb2 = Bp[ia];
+            a1[u] = va ? sgn * xa1 : 0.0;
+            b1[u] = vb ? xb1 : 0.0;
+            a2[u] = vb ? sgn * xa2 : 0.0;
+            b2[u] = va ? xb2 : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) {
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[u], b2[u], acc2, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sAcc[0][wv][i][lane] = acc1[i]; sAcc[1][wv][i][lane] = acc2[i]; }
+    __syncthreads();
+    // element (i, j) of tile (I, J): i = (lane >> 4) + 4 reg, j = lane & 15 -- the first four wavefronts finish it (reg = wv)
+    if (wv < 4) {
+        const int i = (lane >> 4) + 4 * wv, j = lane & 15;
+        const int gi = m0 + i, gj = n0 + j;
+        if (gi < g.d && gj < g.d) {
+            double x1 = 0.0, x2 = 0.0;
+            const int l2 = (j & 3) * 16 + i, r2 = j >> 2;            // element (j, i) of tile (J, I)
+#pragma unroll
+            for (int w = 0; w < GEMM_WAVES; ++w) { x1 += sAcc[0][w][wv][lane]; x2 += sAcc[1][w][r2][l2]; }
+            const double pn1 = g.P[(size_t)gi * g.ldp + gj] + x1;     // Pn[gi][gj]
+            const double pn2 = g.P[(size_t)gj * g.ldp + gi] + x2;     // Pn[gj][gi]
+            const double o = 0.5 * (pn1 + pn2);
+            g.Pout[(size_t)gi * g.ldo + gj] = o;
+            g.Pout[(size_t)gj * g.ldo + gi] = o;
+        }
     }
 }
 
@@ -138,8 +218,9 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f32(Gemm32Args g) {
     const int kbeg = (g.tri == 1) ? n0 : 0;
     const int klen = g.K - kbeg;
     const int kq = (klen + 4 * GEMM_WAVES - 1) / (4 * GEMM_WAVES);
-    const int k_lo = kbeg + grp * kq;
-    const int k_hi = min(g.K, k_lo + kq);
+    const int k_lo = kbeg + wv * 4 * kq + (lane >> 4);     // k = k_lo + 4 u (as k_gemm_f64: 16 rows x 4 consecutive k per load)
+    const int k_hi = g.K;
+    (void)grp;
     const int arow = m0 + r, bcol = n0 + r;
     const bool aok = arow < g.M, bok = bcol < g.N;
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -148,7 +229,7 @@ __global__ __launch_bounds__(64 * GEMM_WAVES) void k_gemm_f32(Gemm32Args g) {
         float av[TRIP], bv[TRIP];
 #pragma unroll
         for (int u = 0; u < TRIP; ++u) {
-            const int k = k_lo + s0 + u;
+            const int k = k_lo + 4 * (s0 + u);
             const bool kok = (s0 + u < kq) && (k < k_hi);
             av[u] = (aok && kok) ? ld32(g.A, (size_t)arow * g.lda + k, AF) : 0.f;
             bv[u] = (bok && kok) ? ld32(g.B, (size_t)bcol * g.ldb + k, 0) : 0.f;      // B[N][K] (transB form), double

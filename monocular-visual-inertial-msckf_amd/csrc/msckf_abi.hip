@@ -143,6 +143,7 @@ struct msckf_ctx {
     std::vector<SweepFold> sfolds;
     int n_group_merges = 0;
     std::vector<std::pair<int, int>> sweep_levels;   // (node_base, count) per group-merge launch
+    std::vector<int> sweep_level_nf;                 // fold slots (wavefronts) of that launch: SWEEP_NW or SWEEP_NW_BIG
     int sweep_mode = 0;                   // 0 k_sweep (60-column tiles, whole band R in LDS), 1 k_wsweep<4> (ring), 2 k_wsweep<6> (90-column tiles, ring)
     std::vector<int> h_flush, h_flush_off;            // k_wsweep: per sweep node the rows final at the head of every macro step
     Buf dFlush, dFlushOff;
@@ -399,7 +400,8 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
 //   level 2 : ONE k_sweep workgroup folds the group triangles (first columns 6 slots apart -> lag 7)
 //             into the band R = the root block [T | r_n].
 // Returns false when the batch does not qualify (wide tracks, R band over the LDS budget): tree plan then.
-void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps) {
+constexpr int SWEEP_NW_BIG = 12;                 // k_sweep group merges of more than SWEEP_NW + 1 triangles: twelve fold slots, one round
+void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps, int nf = SWEEP_NW) {
     int last = 0;
     if (end > begin) folds[begin].t0 = 0;                  // adopted: copied into the empty R, no elimination steps
     const int first = begin + 1;
@@ -408,7 +410,7 @@ void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nste
         if (g > first) t0 = folds[g - 1].t0 + (folds[g].off - folds[g - 1].off) + 1;
         // (a fold runs one step per column of its ENVELOPE ew >= w: where R already reaches further right than the
         //  source triangle, the tile's rows fill in there and the fill has to be eliminated as well)
-        if (g - first >= SWEEP_NW) t0 = std::max(t0, folds[g - SWEEP_NW].t0 + folds[g - SWEEP_NW].ew + 1);
+        if (g - first >= nf) t0 = std::max(t0, folds[g - nf].t0 + folds[g - nf].ew + 1);
         folds[g].t0 = t0;
         last = std::max(last, t0 + folds[g].ew);
     }
@@ -554,7 +556,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             }
             m.fold_end = (int)c->sfolds.size();
             m.wtot = wtot;
-            sweep_schedule(c->sfolds, m.fold_begin, m.fold_end, &m.nsteps);
+            m.nsteps = 0;                                                  // (scheduled per level below: one kernel, one slot count)
             if (dest >= 0) m.out_off = dest;
             else { m.out_off = (long long)off; off += (size_t)wtot * (wtot + 1); }
             if ((int)merge_levels.size() <= level) merge_levels.resize(level + 1);
@@ -583,8 +585,16 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     c->n_leaves = (int)c->nodes.size();
     if (c->n_leaves > 0) c->levels.push_back({0, c->n_leaves});
     c->sweep_levels.clear();
-    for (const auto& lv : merge_levels) {
+    c->sweep_level_nf.clear();
+    for (auto& lv : merge_levels) {
+        // a level is one launch: twelve fold slots when a node has more triangles than eight slots take in one round
+        // (groups of 9 - 16 leaf triangles at >= 10000 features: 60 + 9 macro steps instead of two rounds of 61)
+        int most = 0;
+        for (const SweepNode& m : lv) most = std::max(most, m.fold_end - m.fold_begin - 1);
+        const int nf = (mode == 0 && most > SWEEP_NW) ? SWEEP_NW_BIG : SWEEP_NW;
+        for (SweepNode& m : lv) sweep_schedule(c->sfolds, m.fold_begin, m.fold_end, &m.nsteps, nf);
         c->sweep_levels.push_back({(int)c->snodes.size(), (int)lv.size()});
+        c->sweep_level_nf.push_back(nf);
         c->snodes.insert(c->snodes.end(), lv.begin(), lv.end());
     }
     c->n_group_merges = (int)c->snodes.size();
@@ -763,12 +773,16 @@ int launch_sweeps(msckf_ctx* c, bool with_root = true) {
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) : nullptr;
     a.zero = ptr<double>(c->dRbuf) + c->zero_off;          // inside the plan's (zero-initialised, never written) region
     const dim3 block(64 * SWEEP_NW * SWEEP_WPF);
-    for (const auto& lv : c->sweep_levels) {
+    for (size_t li = 0; li < c->sweep_levels.size(); ++li) {
+        const auto& lv = c->sweep_levels[li];
         int wmax = 0;
         for (int i = lv.first; i < lv.first + lv.second; ++i) wmax = std::max(wmax, c->snodes[i].wtot);
         a.node_base = lv.first;
         a.stamp_base = (int)c->nodes.size() + lv.first;
-        hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(lv.second), block, sweep_lds_bytes(wmax, SWEEP_NW, SWEEP_WPF), c->stream, a);
+        if (li < c->sweep_level_nf.size() && c->sweep_level_nf[li] == SWEEP_NW_BIG)
+            hipLaunchKernelGGL((k_sweep<SWEEP_NW_BIG, 1>), dim3(lv.second), dim3(64 * SWEEP_NW_BIG), sweep_lds_bytes(wmax, SWEEP_NW_BIG, 1), c->stream, a);
+        else
+            hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(lv.second), block, sweep_lds_bytes(wmax, SWEEP_NW, SWEEP_WPF), c->stream, a);
     }
     if (with_root) {
         a.node_base = c->n_group_merges;
@@ -987,17 +1001,17 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
         HIPCHK(c, hipGetLastError());
         return MSCKF_OK;
     }
-    // Joseph form (MSCKF.py:613) with A = I - K T_H, T_H = [0 | T]:
-    //   B2 = A P = P - K (T_H P) = P - K Y^T           (P symmetric)
-    gemm(c, Kg, dc, Y, dc, P, d, B2, d, d, d, dc, -1.0, 1.0, 0.0, 1, 0);
-    //   D = sigma^2 K - B2[:, 15:] T^T
-    gemm(c, B2 + 15, d, Tblk, ldt, Kg, dc, D, dc, d, dc, dc, -1.0, s2, 0.0, 1, 1);
-    //   Pn = B2 A^T + sigma^2 K K^T = B2 + D K^T
-    gemm(c, D, dc, Kg, dc, B2, d, Pn, d, d, d, dc, 1.0, 1.0, 0.0, 1, 0);
-    //   P_out = (Pn + Pn^T) / 2                         (MSCKF.py:614)
-    hipLaunchKernelGGL(k_symmetrize, dim3((d + 15) / 16, (d + 15) / 16), dim3(16, 16), 0, c->stream, Pn,
-                       ptr<double>(c->dPout), d, d);
+    // Joseph form (MSCKF.py:613) with T_H = [0 | T], expanded:  (I - K T_H) P (I - K T_H)^T + sigma^2 K K^T
+    //   = P - K Y^T - Y K^T + K S K^T = P - K Y^T + W K^T,   W = K S - Y   (S = T_H P T_H^T + sigma^2 I as factored above)
+    gemm(c, Kg, dc, S, dc, Y, dc, D, dc, d, dc, dc, 1.0, -1.0, 0.0, 0, 0);
+    //   P_out = (Pn + Pn^T) / 2                         (MSCKF.py:614), both tiles of a mirror pair in one workgroup
+    {
+        JosephArgs j{P, d, Kg, Y, D, ptr<double>(c->dPout), d, d, dc};
+        const int nt = (d + 15) / 16;
+        hipLaunchKernelGGL(k_joseph_f64, dim3(nt, nt), dim3(64 * GEMM_WAVES), 0, c->stream, j);
+    }
     HIPCHK(c, hipGetLastError());
+    (void)B2; (void)Pn;
     return MSCKF_OK;
 }
 
@@ -1127,6 +1141,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         for (const void* f : sm) lds_attr(f, LDS_MAX_BYTES - 1024, "k_solve_lds (one-sided) LDS attribute");
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF, true>), FOLD_LDS_BYTES, "k_sweep (p2p) LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 4, LS_RS4, false>), FOLD_LDS_BYTES, "k_lsweep<12,4> LDS attribute");

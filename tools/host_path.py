@@ -11,6 +11,15 @@ from msckf_amd.api import UpdateEngine, chi2_table
 N, F, M = [int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (30, 2000, 10))]
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 300
 prob = synth.make_problem(N, F, M, seed=0)
+probs = [prob] + [synth.make_problem(N, F, M, seed=sd) for sd in (1, 2, 3)]
+with UpdateEngine(max_clones=N, max_features=F, max_track=M) as eng:
+    for i in range(20):
+        r = eng.update_problem(probs[i % 4])
+    t0 = time.perf_counter()
+    for i in range(iters):
+        r = eng.update_problem(probs[i % 4])
+    t_rot = (time.perf_counter() - t0) / iters * 1e6
+    print(f"N={N} F={F} M={M}: update_problem over 4 rotating batches (plan cache misses) {t_rot:.0f} us = {1e6 / t_rot:.0f} updates/s")
 with UpdateEngine(max_clones=N, max_features=F, max_track=M) as eng:
     for _ in range(20):
         r = eng.update_problem(prob)
