@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes (HBM bytes; matrix-core /
 # VALU activity and wave occupancy).  --pmc passes never carry trace flags (gpurun refuses the combination).
-# usage: tools/profile_round.sh r02   -> gpurun_out/profiles_r02/{stats,fetch,write,mfma,sq}/...
-tag=${1:-r02}
+# usage: tools/profile_round.sh r03   -> gpurun_out/profiles_r02/{stats,fetch,write,mfma,sq}/...
+tag=${1:-r03}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
