@@ -2,7 +2,7 @@
 # usage (on the GPU box): tools/kstats.sh N F M iters [dtype]  -> per-kernel averages of one config (rocprofv3 --kernel-trace --stats)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r3/ks_$1_$2_$3
-mkdir -p $out
+rm -rf $out; mkdir -p $out
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 tools/one_config.py $1 $2 $3 $4 $5 > $out.log 2>&1
 tail -1 $out.log
 python3 - <<PY
