@@ -193,3 +193,135 @@ def test_max_span_of_a_batch():
     wide.obs_slot = slots
     assert UpdateEngine.max_span(wide) == 13
     assert UpdateEngine.max_span(synth.make_problem(5, 0, 3, seed=0)) == 0
+
+
+# ---- the RCCL driver's host logic on the CPU (the engine and the fabric are stand-ins, the compute is the oracle) ----
+
+class _Fabric:
+    def __init__(self):
+        self.records, self.result, self.log = {}, None, []
+
+
+class _FakeEngine:
+    """The calls `shard.RcclShardedUpdate` makes on an engine, recorded and answered from the oracle."""
+
+    def __init__(self, rank, world, fabric):
+        self.rank, self.world, self.fab = rank, world, fabric
+        self.shard = self.bounds = self.span = None
+        self.xchg = False
+
+    @staticmethod
+    def max_span(prob):
+        from msckf_amd.api import UpdateEngine
+        return UpdateEngine.max_span(prob)
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, rank, world, uid):
+        assert (rank, world) == (self.rank, self.world) and len(uid) == 128
+
+    def band_ok(self, prob):
+        return self.max_span(prob) <= 15
+
+    def set_group_exchange(self, on):
+        self.xchg = bool(on)
+
+    def set_exchange_span(self, span):
+        self.span = int(span)
+
+    def set_exchange_mask(self, bounds):
+        self.bounds = np.asarray(bounds).copy()
+
+    def load(self, prob):
+        assert self.bounds is not None and self.span is not None      # layout first, then the shard
+        self.shard = prob
+        self.n_clones = prob.N
+
+    def group_record_doubles(self):
+        return 1000 + self.shard.N
+
+    def comm_buffer(self, n):
+        assert n == self.group_record_doubles() * (self.world + 1) + 8
+        return 1 << 20
+
+    def run_compress(self):
+        self.fab.log.append(("compress", self.rank))
+
+    def device_pointer(self, which):
+        return 100 + which
+
+    def comm_gather(self, send, recv, count, root):
+        assert send == 103 and count == self.group_record_doubles() and root == 0
+        self.fab.records[self.rank] = self.shard
+
+    def merge_groups_flags(self, recv, n_rec, flags):
+        assert self.rank == 0 and n_rec == self.world and flags.shape == (self.world, self.shard.N)
+        from oracle import msckf_oracle as oracle
+        parts = [self.fab.records[r] for r in range(self.world)]          # every rank has deposited its record
+        vp = np.concatenate([[0]] + [p.view_ptr[1:] + sum(int(q.view_ptr[-1]) for q in parts[:i]) for i, p in enumerate(parts)])
+        for r, p in enumerate(parts):                                        # the flags say which groups a record carries
+            first = np.unique(np.minimum.reduceat(p.obs_slot, p.view_ptr[:-1])) if p.F else np.zeros(0, dtype=int)
+            assert np.array_equal(np.nonzero(flags[r])[0], first)
+        full = parts[0].__class__(
+            P=parts[0].P, cam_R=parts[0].cam_R, cam_t=parts[0].cam_t, cam_R0=parts[0].cam_R0, cam_t0=parts[0].cam_t0,
+            gravity=parts[0].gravity, K=parts[0].K, sigma=parts[0].sigma, view_ptr=vp.astype(np.int32),
+            obs_uv=np.concatenate([p.obs_uv for p in parts]), obs_slot=np.concatenate([p.obs_slot for p in parts]),
+            idp_base=np.concatenate([p.idp_base for p in parts]), idp_m=np.concatenate([p.idp_m for p in parts]),
+            idp_rho=np.concatenate([p.idp_rho for p in parts]))
+        self.fab.result = oracle.update(full, dense_noise=False)
+
+    def result_range_doubles(self):
+        d = 15 + 6 * self.shard.N
+        return 8 + d + d * d + (int(self.bounds[-1]) + 7) // 8
+
+    def comm_broadcast(self, ptr, count, root):
+        assert ptr == 105 and count == self.result_range_doubles() and root == 0
+        self.fab.log.append(("bcast", self.rank))
+
+    def shared_result(self):
+        from msckf_amd.api import UpdateResult
+        r = self.fab.result
+        return UpdateResult(int(r["status"]), r["dx"], r["P_new"], r["accepted"].astype(np.uint8),
+                            {"n_rejected": int(len(r["accepted"]) - r["accepted"].sum())})
+
+
+@pytest.mark.parametrize("world,kw", [(3, {"outlier_fraction": 0.1, "outlier_px": 400.0}), (5, {"variable_tracks": True})])
+def test_rccl_driver_host_logic(world, kw):
+    """`RcclShardedUpdate` at world > 1 on the CPU: every rank configures the same record layout before it loads its
+    shard, the shards tile the batch, the flags match the shards' groups, only rank 0 merges, every rank broadcasts the
+    same range and reads the same (status, dx, P+, accepted, rejected) -- the oracle's result on the whole batch."""
+    from msckf_amd import synth
+    from msckf_amd.shard import RcclShardedUpdate
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(12, 90, 8, seed=5, **kw)
+    ref = oracle.update(prob, dense_noise=False)
+    fab = _Fabric()
+    drv = [RcclShardedUpdate(_FakeEngine(r, world, fab), r, world, bytes(128)) for r in range(world)]
+    for dv in drv:
+        dv.load(prob)
+    assert all(np.array_equal(dv.bounds, drv[0].bounds) for dv in drv) and drv[0].bounds[-1] == prob.F
+    assert sum(dv.shard[1] - dv.shard[0] for dv in drv) == prob.F and all(dv.groups for dv in drv)
+    for r in list(range(1, world)) + [0]:            # the root's merge needs every record: run it last in this serial stand-in
+        drv[r].step()
+    outs = [dv.result() for dv in drv]
+    for st, dx, P, acc, nrej in outs:
+        assert st == ref["status"] and np.array_equal(acc, ref["accepted"]) and nrej == prob.F - int(ref["accepted"].sum())
+        assert rel_err(dx, ref["dx"]) < 1e-12 and rel_err(P, ref["P_new"]) < 1e-12
+    assert [x for x in fab.log if x[0] == "bcast"] == [("bcast", r) for r in list(range(1, world)) + [0]]
+
+
+def test_unique_id_file_carries_the_launch_tag(tmp_path):
+    """A file left by another launch (other tag) is ignored; this launch's file is read back; rank 0 removes it."""
+    from msckf_amd.shard import RcclShardedUpdate, exchange_unique_id
+    fab = _Fabric()
+    e0, e1 = _FakeEngine(0, 2, fab), _FakeEngine(1, 2, fab)
+    path = str(tmp_path / "id")
+    with open(path, "wb") as fh:
+        fh.write(b"\x07" * 16 + b"\x09" * 128)
+    with pytest.raises(TimeoutError):
+        exchange_unique_id(e1, 1, 2, path, timeout_s=0.1)
+    uid = exchange_unique_id(e0, 0, 2, path)
+    assert exchange_unique_id(e1, 1, 2, path) == uid == bytes(range(128))
+    RcclShardedUpdate(e0, 0, 2, uid, id_path=path)
+    assert not os.path.exists(path)
