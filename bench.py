@@ -31,6 +31,7 @@ Rank 0 prints ONE JSON line.  The oracle (oracle/msckf_oracle.py) is only timed
 as the CPU baseline; it is never on the measured GPU path.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -195,7 +196,7 @@ def main():
 
     use_dist = world > 1 or args.force_dist
     import msckf_amd  # noqa: F401
-    from msckf_amd import synth
+    from msckf_amd import synth, _ffi
     from msckf_amd.api import UpdateEngine
 
     if use_dist:
@@ -345,6 +346,31 @@ def main():
                                 "us_per_call_host_inclusive": us_assoc, "matches": prob.F, "kept": int((a_res == 0).sum()),
                                 "match_views": int(prob.view_ptr[-1]), "bytes_algorithmic": assoc_bytes,
                                 "hbm_gbs_algorithmic": assoc_bytes / (us_assoc * 1e-6) / 1e9}
+        # the per-frame loop of a filter that keeps P in HBM (f2): new tracks in, K1-K7, dx out, P+ committed on the device,
+        # poses of the corrected clones back in -- no covariance crosses PCIe.  Four different batches in rotation.
+        probs_loop = [prob] + [synth.make_problem(N, Fg, M, seed=sd) for sd in (1, 2, 3)]
+        eng.set_state(prob)
+
+        def frame(p):
+            eng.set_features(p)
+            eng.run()
+            dxv = np.empty(p.d)
+            stt = _ffi.Stats()
+            rc = eng._check(eng._lib.msckf_get_result(eng._h, _ffi.dptr(dxv), None, None, C.byref(stt)))
+            if rc == 0:
+                eng.commit_covariance()
+            eng.set_poses(p.cam_R, p.cam_t)
+            return dxv
+
+        for i in range(8):
+            frame(probs_loop[i % 4])
+        t6 = time.perf_counter()
+        for i in range(100):
+            frame(probs_loop[i % 4])
+        us_frame = (time.perf_counter() - t6) / 100 * 1e6
+        line["resident_filter_loop"] = {
+            "what": "set_features (new batch) -> run -> get_result(dx only) -> commit_covariance -> set_poses, covariance resident in HBM",
+            "us_per_frame": us_frame, "updates_per_s": 1e6 / us_frame, "batches": 4}
         # f2 / f3: the covariance steps either side of the update on the resident P (host clock
         # around async launches + one sync; augment / remove include their pose upload and sync)
         rng = np.random.default_rng(0)

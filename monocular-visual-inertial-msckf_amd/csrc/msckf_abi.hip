@@ -309,6 +309,9 @@ struct msckf_ctx {
     bool oneshot = false;                 // msckf_update: set_features uploads, launches K1-K4 and plans K5 meanwhile, no sync
     bool feature_launched = false;        // K1-K4 of the current batch is already in the stream (oneshot)
     HostPool* pool = nullptr;             // host worker threads for the pack loops (CPU work only)
+    long run_serial = 0;                  // bumped by every pipeline / merge launch
+    long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
+    int fetched_rc = 0;                   // ... and that code: msckf_commit_covariance need not read the gate results again
 };
 
 namespace {
@@ -1173,6 +1176,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     c->ran_gain = with_gain;
     c->acc_override = -1;
     c->acc_from_dev = false;
+    ++c->run_serial;
     return MSCKF_OK;
 }
 
@@ -1696,6 +1700,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     }
     c->us_d2h = (float)(now_us() - t0);
     c->hp[8] += tsync - t0; c->hp[9] += now_us() - tsync;
+    c->fetched_serial = c->run_serial; c->fetched_rc = rc;
     if (st) {
         std::memset(st, 0, sizeof(*st));
         st->n_features = c->F - counters[3]; st->n_accepted = n_acc;
@@ -1715,6 +1720,12 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
 int msckf_commit_covariance(msckf_ctx* c) {
     if (!c || !c->ran || !c->ran_gain) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->fetched_serial == c->run_serial) {          // msckf_get_result has already decided this run: no second read-back
+        if (c->fetched_rc != MSCKF_OK) return c->fetched_rc;
+        HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return MSCKF_OK;
+    }
     int counters[4] = {0, 0, 0, 0};
     if (int rc0 = gate_counts(c, counters, nullptr)) return rc0;
     // a non-positive Cholesky pivot leaves garbage in P_out: keep the prior (msckf_get_result reports the same code)
@@ -2149,6 +2160,7 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     HIPCHK(c, hipGetLastError());
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
+    ++c->run_serial;
     return MSCKF_OK;
 }
 
@@ -2372,6 +2384,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         }
         if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
         c->ran = true; c->ran_gain = false; c->acc_override = 0; c->acc_from_dev = false;
+        ++c->run_serial;
         return MSCKF_OK;
     }
     const int nb = (int)c->snodes.size();
@@ -2417,6 +2430,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
     c->acc_from_dev = count_on_device;
+    ++c->run_serial;
     return MSCKF_OK;
 }
 }  // namespace
