@@ -485,6 +485,18 @@ def bench_sharded(args, world, rank, local_rank):
         eng.close()
         return seconds, groups, status, int(acc.sum()), n_rej
 
+    # the same 8000-feature update on ONE GPU (rank 0's, unsharded, resident in HBM): what the strong-scaling figure is a
+    # speed-up over.  The other ranks wait in the bootstrap of the first sharded case.
+    one_gpu_us = None
+    if rank == 0:
+        p8 = synth.make_problem(N, 8000, M, seed=0)
+        with UpdateEngine(max_clones=N, max_features=8000, max_track=max(M, 2), device=local_rank) as e1:
+            e1.load(p8)
+            for _ in range(5):
+                e1.run()
+            e1.sync()
+            ms1, _ = e1.run_timed(30)
+            one_gpu_us = 1e3 * ms1 / 30
     s_seconds, s_groups, st2, s_acc, s_rej = run_case(8000, args.steps, args.warmup, "_strong")
     weak_steps = max(10, min(args.steps, 100))
     seconds, groups, st1, _, _ = run_case(Fg * world, weak_steps, min(args.warmup, 10), "_weak")
@@ -510,6 +522,9 @@ def bench_sharded(args, world, rank, local_rank):
                        "unit_definition": "one 8000-feature measurement update (K1-K7)", "seed": 0},
             "status": [int(st2), int(st1)],
             "accepted": s_acc, "rejected": s_rej,
+            "one_gpu_same_workload": {"us_per_update": one_gpu_us, "updates_per_s": 1e6 / one_gpu_us,
+                                      "what": "the unsharded 8000-feature update on rank 0's GPU, resident in HBM (HIP events)"},
+            "speedup_vs_one_gpu": (args.steps / s_seconds) / (1e6 / one_gpu_us),
             "weak_scaling": {
                 "workload": f"N={N} clones, {Fg} features per GPU ({Fg * world} per update), track={M}, fp64",
                 "updates_per_s": weak_steps / seconds, "ms_per_update": 1e3 * seconds / weak_steps,
