@@ -114,15 +114,15 @@ double now_us() {
 // are loops over F features (50 us of the 590 us call at the headline, 290 of 1040 at 10000 features) that split cleanly
 // over feature ranges.  A few persistent worker threads (created with the context, CPU work only -- they never make a
 // HIP call, whose first use costs a new thread ~100 ms) take chunks of a parallel_for next to the calling thread.  After a
-// run they keep polling for ~200 us before they sleep on the condition variable, so a filter calling at frame rate finds
-// them awake (a condition-variable wake-up alone costs what the parallel loop saves at the headline size).
-// MSCKF_HOST_THREADS=n sets the worker count (default 3, 0 = everything on the calling thread).  Measured on the
-// 2 x 64-core EPYC of the GPU box (tools/host_path.py, rotating batches): 10000 features 1040 -> 931 us per call
-// (validate 80 -> 28 us, gather 203 -> 112 us); at 2000 features the loops are 45 us in all and the split buys nothing, so
-// batches under 4096 features stay on the calling thread.
+// run they keep polling for MSCKF_HOST_SPIN_US (default 1000) microseconds before they sleep on the condition variable, so
+// a filter calling at frame rate finds them awake (a condition-variable wake-up alone costs what the parallel loop saves
+// at the headline size).  MSCKF_HOST_THREADS=n sets the worker count (default 3, 0 = everything on the calling thread),
+// MSCKF_HOST_PAR_MIN the smallest batch that is split (default 1024 features).  Measured on the 2 x 64-core EPYC of the
+// GPU box (tools/host_path.py, rotating batches): 10000 features 1040 -> 918 us per call (validate 80 -> 23 us, gather
+// 203 -> 93 us); 2000 features 587 -> 567 us (validate 18 -> 7, gather 32 -> 20).
 class HostPool {
 public:
-    explicit HostPool(int workers) {
+    explicit HostPool(int workers, int spin_us = 1000) : spin_us_(spin_us) {
         // the workers sit on the allowed CPUs next to the creating thread's (the context's one host thread): neighbours
         // share its L3 / NUMA node -- workers scattered over a two-socket box made the gather SLOWER than one thread
         std::vector<int> cpus;
@@ -179,7 +179,7 @@ private:
         for (;;) {
             // spin for a while, then sleep
             bool got = false;
-            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_);
             for (int spins = 0;; ++spins) {
                 if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; }
                 cpu_relax();
@@ -208,7 +208,28 @@ private:
     const std::function<void(int)>* fn_ = nullptr;
     int n_ = 0;
     bool stop_ = false;
+    int spin_us_ = 1000;
+
+public:
+    // memcpy split over the pool (the 300 KB covariance in and out of the pinned staging buffers)
+    void copy(void* dst, const void* src, size_t bytes) {
+        const int parts = workers() + 1;
+        if (parts == 1 || bytes < (size_t)128 * 1024) { std::memcpy(dst, src, bytes); return; }
+        const size_t piece = ((bytes / parts) + 4095) & ~(size_t)4095;
+        const int n = (int)((bytes + piece - 1) / piece);
+        const std::function<void(int)> fn = [&](int ch) {
+            const size_t o = (size_t)ch * piece;
+            std::memcpy(static_cast<char*>(dst) + o, static_cast<const char*>(src) + o, std::min(piece, bytes - o));
+        };
+        run(n, fn);
+    }
 };
+
+// batches from this many features on split their host loops over the pool
+inline int host_par_min() {
+    static const int v = [] { const char* e = std::getenv("MSCKF_HOST_PAR_MIN"); return e ? std::max(1, std::atoi(e)) : 1024; }();
+    return v;
+}
 
 }  // namespace
 
@@ -1308,7 +1329,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         const int hw = (int)std::thread::hardware_concurrency();
         nw = std::max(0, std::min(nw, std::max(0, hw - 1)));
         nw = std::min(nw, 15);
-        c->pool = new HostPool(nw);
+        const char* es = std::getenv("MSCKF_HOST_SPIN_US");
+        c->pool = new HostPool(nw, es ? std::max(0, std::atoi(es)) : 1000);
     }
     *out = c;
     return MSCKF_OK;
@@ -1357,7 +1379,7 @@ int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_
     std::memcpy(c->g, gravity, 24);
     std::memcpy(c->Kinv, Kinv, 72);
     const size_t d = c->d;
-    std::memcpy(c->hP, P, d * d * 8);
+    if (c->pool) c->pool->copy(c->hP, P, d * d * 8); else std::memcpy(c->hP, P, d * d * 8);
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->hP, d * d * 8, hipMemcpyHostToDevice, c->stream));
     if (N > 0) {
         c->h_cam[0].assign(cam_R, cam_R + (size_t)N * 9); c->h_cam[1].assign(cam_t, cam_t + (size_t)N * 3);
@@ -1424,7 +1446,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     int Mmax = 0;
     if (view_ptr[0] != 0) return MSCKF_ERR_ARG;
     {
-        const int nch = (c->pool && F >= 4096) ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
+        const int nch = (c->pool && F >= host_par_min()) ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
         std::vector<int> ch_err(nch, MSCKF_OK), ch_mmax(nch, 0);
         const int maxM = c->maxM;
         auto validate = [&](int ch) {
@@ -1508,7 +1530,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         pos += M;
     }
     {
-        const int nch = (c->pool && F >= 4096) ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
+        const int nch = (c->pool && F >= host_par_min()) ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
         const int* perm = c->perm.data();
         auto gather = [&](int ch) {
             const int s0 = (int)((long long)F * ch / nch), s1 = (int)((long long)F * (ch + 1) / nch);
@@ -1695,7 +1717,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     }
     if (P_out) {
         // no-op leaves the covariance untouched (reference early returns MSCKF.py:584-585)
-        if (rc == MSCKF_OK && c->ran_gain) std::memcpy(P_out, hres + c->res_p_off, d * d * 8);
+        if (rc == MSCKF_OK && c->ran_gain) { if (c->pool) c->pool->copy(P_out, hres + c->res_p_off, d * d * 8); else std::memcpy(P_out, hres + c->res_p_off, d * d * 8); }
         else HIPCHK(c, hipMemcpy(P_out, c->dP.p, d * d * 8, hipMemcpyDeviceToHost));
     }
     c->us_d2h = (float)(now_us() - t0);
