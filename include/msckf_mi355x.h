@@ -26,6 +26,10 @@
  *     F == 0: dx = 0, P_out = P, mirrors the early returns MSCKF.py:584-585,
  *     :591-592), < 0 = error (see msckf_strerror).
  *   - one context per host thread; calls on a context are serialised.
+ *   - msckf_create starts a few host worker threads per context (CPU work only, no HIP calls: the validation / gather
+ *     loops and the covariance staging copies of msckf_update are split over them; pinned next to the creating
+ *     thread).  Environment: MSCKF_HOST_THREADS (default 3, 0 = none), MSCKF_HOST_PAR_MIN (smallest batch that is
+ *     split, default 1024 features), MSCKF_HOST_SPIN_US (how long idle workers poll before they sleep, default 1000).
  */
 #ifndef MSCKF_MI355X_H
 #define MSCKF_MI355X_H
