@@ -526,9 +526,14 @@ def test_shipped_merge_path_logical_shards(N, F, M, S, kw):
     prob = synth.make_problem(N, F, M, seed=61, **kw)
     ref = oracle.update(prob, dense_noise=False)
     shards = partition_features(prob.view_ptr, S)
-    with UpdateEngine(max_clones=N + 3, max_features=max(F, 8), max_track=max(M, 2)) as e:    # (capacity above N on purpose)
+    biggest = max(hi - lo for lo, hi in shards)
+    # capacity above N on purpose (the result range follows the CURRENT window) and sized for ONE shard, as a rank's engine
+    # is: the gate bytes of the whole batch then do not fit the result range the context was created with -- it grows
+    with UpdateEngine(max_clones=N + 3, max_features=max(biggest, 8), max_track=max(M, 2)) as e:
         assert e.band_ok(prob)
         _shipped_merge(e, prob, shards, ref)
+        one = e.update_problem(prob.subset(*shards[0]))      # the engine still serves plain updates afterwards
+        assert one.status in (0, 1)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
