@@ -139,44 +139,65 @@ __global__ void k_set_int(int* p, int v) { *p = v; }
 template <int KK> struct STag { static constexpr int value = KK; };
 
 #ifdef SWEEP_PROF
-#define SWEEP_TICK(slot) do { const long long tn_ = __builtin_readcyclecounter(); prof[slot] += tn_ - tprev; tprev = tn_; } while (0)
+#define SWEEP_TICK(slot) do { __builtin_amdgcn_sched_barrier(0); const long long tn_ = __builtin_readcyclecounter(); prof[slot] += tn_ - tprev; tprev = tn_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SWEEP_TICK(slot) do { } while (0)
 #endif
 
-// NF concurrent folds, WPF wavefronts per fold (only 1 is enabled: splitting a fold's columns over two wavefronts
-// -- 16 per workgroup, half the FMAs each -- measured the same 0.83 us per step: the step is a dependent chain
-// barrier -> LDS -> reflector scalars / dots -> tau -> update -> column norm -> LDS, not an issue-rate limit).
-// P2P: no workgroup barrier per macro step.  A fold's step for R row c only needs every EARLIER fold to be past
-// row c; consecutive folds of the root are 7 rows apart, so there are 6 steps of slack between them.  Every fold
-// slot publishes (fold index, rows done) in one LDS word after each step; before a step a wavefront makes sure
-// the (up to NF - 1) folds in front of it have started and are past its row (a cached bound, re-read only when it
-// is reached).  Heavy and light chunks then average out instead of every step costing the slowest wavefront's
-// (the barrier wait was 660 of 1830 cycles per step).  Nodes whose folds share one first column (lag 1, no
-// slack) keep the barrier form.
+// 64-bit halves of the gfx950 lane swaps.  swap_rows32(x, y): x = [x rows 0,1 | y rows 0,1], y = [x rows 2,3 | y rows 2,3];
+// swap_rows16(x, y): x = [x r0, y r0, x r2, y r2], y = [x r1, y r1, x r3, y r3]  (rows = the four 16-lane DPP rows).
+__device__ __forceinline__ void swap_rows32(double& x, double& y) {
+    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)h[0], (int)l[0]);
+    y = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void swap_rows16(double& x, double& y) {
+    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)h[0], (int)l[0]);
+    y = __hiloint2double((int)h[1], (int)l[1]);
+}
+// d += (lane L of the 16-lane row of src) * w, no hazard padding (the caller opens a run of these with dpp_guard()).
+template <int L>
+__device__ __forceinline__ void fmac_bcast(double& d, double src, double w) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(w), "i"(L));
+}
+template <int L>
+__device__ __forceinline__ void fmac_bcast_self(double& d, double w) {     // d += (lane L of d's row) * w
+    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(w), "i"(L));
+}
+__device__ __forceinline__ void dpp_guard() { asm volatile("s_nop 1"); }
+
+// NF concurrent folds, one wavefront each.  Lane (rq, cq) = (lane >> 4, lane & 15): the 16 column lanes of one row
+// lane are one DPP row, so the pivot column -- held by column lane i & 15 of every row -- reaches the other 15 through
+// the row_newbcast operand of the FMA itself: the dots and the rank-1 update read it straight from the owner's
+// registers, nothing of the fold goes through LDS (rounds 1-2 published the column there and read it back: two LDS
+// trips and (RMAX + 1) / 2 wide reads per step on the step's dependent chain).  The broadcast lane is an immediate,
+// hence one instantiation of the step per column of a 16-column period (KK, J).  The four row lanes' partial dots
+// are reduce-scattered with the lane swaps (row r ends up with the dot of column slot r: 6 swaps and 3 additions)
+// and tau goes back the same way.
 template <int NF, int WPF, bool P2P = false>
 __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
-    static_assert(WPF == 1, "with two wavefronts per fold the pivot R(c,c) is rewritten by one while the other may still read it");
-    constexpr int NW = NF * WPF;        // wavefronts
-    constexpr int CL = 16 * WPF;        // column lanes of a fold
-    constexpr int CS = 64 / CL;         // column slots of a lane
+    static_assert(WPF == 1 && !P2P, "one wavefront per fold, one barrier per macro step");
+    constexpr int NW = NF;              // wavefronts
+    constexpr int CL = 16;              // column lanes of a fold
+    constexpr int CS = 4;               // column slots of a lane
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SweepNode nd = p.nodes[p.node_base + blockIdx.x];
     const int t = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
-    const int rq = lane & 3;            // row lane: the 4 lanes of a DPP quad
-    const int fs = wv / WPF;            // fold slot
-    const int cq = (lane >> 2) + 16 * (wv % WPF);   // column lane 0..CL-1
+    const int rq = lane >> 4;           // row lane: one DPP row of 16 lanes
+    const int fs = wv;                  // fold slot
+    const int cq = lane & 15;           // column lane
     double* Rb = smem;                                              // [wtot][SWEEP_RS]
-    double* vb = smem + (size_t)nd.wtot * SWEEP_RS + fs * SWEEP_VB; // published column of this fold slot
     const int nsteps = __builtin_amdgcn_readfirstlane(nd.nsteps);
     const int fold_end = __builtin_amdgcn_readfirstlane(nd.fold_end);
     long long tk0 = 0;
     if (p.stamps) tk0 = wall_clock64();
 
     for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
-    if (t < NF) reinterpret_cast<long long*>(smem + (size_t)nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + 2)[t] = -1LL << 32;   // fold index -1
     if (t < 2) smem[nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + t] = 0.0;
     // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
     const SweepFold f0 = p.folds[nd.fold_begin];
@@ -235,160 +256,80 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             for (int k = 0; k < CS; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
     };
 
-    // the owners of local column slot KN publish their column (row slots rr <= RP); its squared norm falls out
-    // of the next step's dots (the owners' own dot is v^T v)
-    auto publish = [&](auto tagk, auto tagr) {
-        constexpr int KN = decltype(tagk)::value;
-        constexpr int RP = decltype(tagr)::value < 15 ? decltype(tagr)::value : 15;
-        if constexpr (KN < CS) {
-            double* dst = vb + rq * 16;
-#pragma unroll
-            for (int rr = 0; rr <= RP; ++rr) dst[rr] = a[rr][KN];
-        }
-    };
-
-    // Every lane looks after ONE entry of the pivot row of R: row lane rq of a quad takes column slot rq, i.e. local
-    // column lco = cq + CL rq (the quad's four partial dots are reduce-scattered so that lane rq ends up with the
-    // dot of slot rq; tau is formed once per column and broadcast back over the quad).  ra / wa: LDS indices
-    // (doubles) where that entry is read / written; they advance by SWEEP_RS - 1 per step (next row, one column
-    // less to the left), the rhs by SWEEP_RS.  Columns outside the tile read a zero word and write a dump word.
-    static_assert(CS == 4, "one column slot per row lane of the quad");
+    // Every lane looks after ONE entry of the pivot row of R: row lane rq takes column slot rq, i.e. local column
+    // lco = cq + CL rq (the four partial dots are reduce-scattered so that row rq ends up with the dot of slot rq; tau
+    // is formed once per column and sent back over the rows).  ra / wa: LDS indices (doubles) where that entry is
+    // read / written; they advance by SWEEP_RS - 1 per step (next row, one column less to the left), the rhs by
+    // SWEEP_RS.  Columns outside the tile read a zero word and write a dump word.
     int ra = 0, wa = 0, rstep = 0;
     const int dump_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + wv * 64 + lane;
     const int zero_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64;
     const int lco = cq + CL * rq;
-    // ---- P2P progress words: [slot] = (fold index << 32) | rows done (first row not yet done by that fold) --------
-    // (read and written with explicit ds instructions: a volatile pointer into LDS compiles to FLAT accesses with
-    //  vmcnt waits, which is what made the first version of this variant slow)
-    const unsigned prog_addr = (unsigned)(size_t)(smem + (size_t)nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + 2);
-    auto prog_load = [&](int slot) -> long long {          // one lane asks, everybody gets the word
-        double v;
-        const unsigned a = prog_addr + (unsigned)slot * 8u;
-        asm volatile("s_mov_b64 exec, 1\n\tds_read_b64 %0, %1\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-        const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-        return ((long long)hi << 32) | (unsigned int)lo;
-    };
-    auto prog_store = [&](int slot, long long w) {         // (called where the whole wavefront is active)
-        const unsigned a = prog_addr + (unsigned)slot * 8u;
-        const double v = __longlong_as_double(w);
-        asm volatile("s_mov_b64 exec, 1\n\tds_write_b64 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(a), "v"(v) : "memory");
-    };
-    const int fbeg = nd.fold_begin + ((nd.fold_end > nd.fold_begin && f0.t0 == 0) ? 1 : 0);   // first fold that runs steps
-    int cur_fi = 0;                      // fold this wavefront is running
-    int safe_row = 0;                    // rows < safe_row are clear of every earlier fold (as of the last look)
-    auto publish_prog = [&](int done) {
-        if constexpr (P2P) {
-            // rows < the published bound are clear of THIS fold and (transitively, through its own cached bound) of every
-            // earlier one, so a follower normally looks at one word only.  LDS operations of a wavefront execute in
-            // issue order: the word lands behind this step's R entries.
-            asm volatile("" ::: "memory");
-            const int bound = (done == 0x7fffffff) ? done : min(done, safe_row);
-            prog_store(fs, ((long long)cur_fi << 32) | (unsigned int)bound);
-        }
-    };
-    auto peek_prev = [&]() -> long long {        // the word of the fold right in front (issued early, used after the dots)
-        if constexpr (P2P) {
-            const int pf = cur_fi - 1;
-            return (pf >= fbeg) ? prog_load((pf - fbeg) % NF) : (((long long)0x7fffffff) << 32);
-        }
-        return 0;
-    };
-    auto wait_row = [&](int c, long long w) {    // every earlier fold has left row c behind
-        if constexpr (P2P) {
-            int spins = 0;
-            while (c >= safe_row) {
-                const int pf = cur_fi - 1;
-                int safe;
-                const int idx1 = (int)(w >> 32), done1 = (int)(w & 0xffffffffLL);
-                if (pf < fbeg) {
-                    safe = 0x7fffffff;
-                } else if (idx1 == pf) {
-                    safe = done1;                                          // running: its bound is transitive
-                } else {
-                    // the fold in front has finished (or its slot has not started it yet): look at all of them
-                    safe = 0x7fffffff;
-#pragma unroll
-                    for (int j = 1; j < NF; ++j) {
-                        const int qf = cur_fi - j;
-                        if (qf >= fbeg) {
-                            const long long wj = prog_load((qf - fbeg) % NF);
-                            const int idx = (int)(wj >> 32), done = (int)(wj & 0xffffffffLL);
-                            const int lim = (idx > qf) ? 0x7fffffff : (idx == qf ? done : 0);   // finished / running / not started
-                            safe = min(safe, lim);
-                        }
-                    }
-                }
-                safe_row = __builtin_amdgcn_readfirstlane(safe);
-                if (c >= safe_row) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1 << 22)) break;                        // (bounded: never hang the GPU)
-                    w = peek_prev();
-                }
-            }
-            asm volatile("" ::: "memory");
-        }
-    };
+    const bool isr_lane = (rq == CS - 1) && (cq == CL - 1);
     auto init_addr = [&]() {
-        const bool isr = (rq == CS - 1) && (cq == CL - 1);
-        const bool valid = isr || lco < f_ew;
-        ra = valid ? f_off * SWEEP_RS + (isr ? 63 : lco) : zero_i;
+        const bool valid = isr_lane || lco < f_ew;
+        ra = valid ? f_off * SWEEP_RS + (isr_lane ? 63 : lco) : zero_i;
         wa = valid ? ra : dump_i;
-        rstep = valid ? (isr ? SWEEP_RS : SWEEP_RS - 1) : 0;
+        rstep = valid ? (isr_lane ? SWEEP_RS : SWEEP_RS - 1) : 0;
     };
 
-    auto step = [&](auto tagk, int i) {
+    auto step = [&](auto tagk, auto tagj) {
         constexpr int KK = decltype(tagk)::value;
+        constexpr int I = 8 * KK + decltype(tagj)::value;  // the fold's column
         constexpr int RMAX = 2 * KK + 1;                  // live row slots (rows <= 8 KK + 7)
-        constexpr int K0 = (8 * KK) / CL;                 // first live column slot
-        const int rrow = (f_off + i) * SWEEP_RS;          // pivot row of R (uniform)
-        // ---- reads ------------------------------------------------------------------
-        double v[RMAX + 1];
-        {
-            const double* src = vb + rq * 16;
+        constexpr int K0 = I / CL;                        // first live column slot: the pivot column's
+        constexpr int L = I % CL;                         // column lane that holds the pivot column
+        const int rrow = (f_off + I) * SWEEP_RS;          // pivot row of R (uniform)
+        const double x0 = smem[rrow];
+        const double rck = smem[ra];                      // R(c, off + lco)
+        int lcl = lco;
+        asm volatile("" : "+v"(lcl));                     // (or the 60 lane masks lco > I are hoisted out of the fold loop and spilled)
+        const bool on = (lcl > I) || isr_lane;            // left of / at the pivot: retired (the rhs never is)
+        // ---- dots: partial sums per live slot, the pivot column read through the row broadcast; at least four
+        // independent running sums (a dependent v_fma_f64 issues every 32 cycles, independent ones every ~10) ----
+        constexpr int NACC = (K0 == 3) ? 4 : (K0 == 2) ? 2 : 1;
+        double acc[CS][NACC];
 #pragma unroll
-            for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
+        for (int k = 0; k < CS; ++k)
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) acc[k][j] = 0.0;
+        dpp_guard();
+#pragma unroll
+        for (int rr = 0; rr <= RMAX; ++rr) {
+#pragma unroll
+            for (int k = K0; k < CS; ++k) fmac_bcast<L>(acc[k][rr % NACC], a[rr][K0], a[rr][k]);
         }
-        long long wprev = 0;
-        double x0 = 0.0, rck = 0.0;
-        if constexpr (P2P) {
-            wprev = peek_prev();                           // looked at behind the dots, which need no R
-        } else {
-            x0 = smem[rrow];
-            rck = smem[ra];                                // R(c, off + lco)
-        }
-        const bool on = (lco > i) || (rq == CS - 1 && cq == CL - 1);   // left of / at the pivot: retired (the rhs never is)
-        // ---- dots (one partial sum per live slot), reduce-scattered over the quad ---------------------
         double sp[CS];
 #pragma unroll
         for (int k = 0; k < CS; ++k) {
-            sp[k] = 0.0;
-            if (k >= K0) {
-                double s0 = v[0] * a[0][k];
-#pragma unroll
-                for (int rr = 1; rr <= RMAX; ++rr) s0 = fma(v[rr], a[rr][k], s0);
-                sp[k] = s0;
-            }
+            if constexpr (NACC == 4) sp[k] = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
+            else if constexpr (NACC == 2) sp[k] = acc[k][0] + acc[k][1];
+            else sp[k] = acc[k][0];
         }
-        double tot;                                       // lane rq: the full dot of slot rq
-        {
-            const bool b0 = (rq & 1) != 0, b1 = (rq & 2) != 0;
-            double pB = (b0 ? sp[3] : sp[2]) + quad_move<0xB1>(b0 ? sp[2] : sp[3]);
-            if constexpr (K0 <= 1) {
-                double pA = (b0 ? sp[1] : sp[0]) + quad_move<0xB1>(b0 ? sp[0] : sp[1]);
-                tot = (b1 ? pB : pA) + quad_move<0x4E>(b1 ? pA : pB);
-            } else {
-                tot = pB + quad_move<0x4E>(pB);           // slots 0, 1 are retired: lanes 0, 1 hold a copy nobody uses
-                (void)b1;
-            }
+#ifdef SWEEP_PROF
+        SWEEP_TICK(2);                                     // dots issued
+#endif
+        // ---- reduce-scatter over the four row lanes: row r gets the dot of slot r -----------------------
+        double tot;
+        if constexpr (K0 <= 1) {
+            swap_rows32(sp[0], sp[2]);
+            swap_rows32(sp[1], sp[3]);
+            double pA = sp[0] + sp[2], pB = sp[1] + sp[3];  // rows 0,1: slot 0 / 1;  rows 2,3: slot 2 / 3  (row pairs summed)
+            swap_rows16(pA, pB);
+            tot = pA + pB;
+        } else {
+            // slots 0, 1 are retired: only rows 2, 3 need a total (rows 0, 1 get a copy nobody uses)
+            swap_rows16(sp[2], sp[3]);
+            double g = sp[2] + sp[3], h = g;                // [s2 r0+r1, s3 r0+r1, s2 r2+r3, s3 r2+r3]
+            swap_rows32(g, h);
+            tot = g + h;
         }
-        if constexpr (P2P) {
-            wait_row(f_off + i, wprev);                    // the earlier folds are past this row of R
-            x0 = smem[rrow];
-            rck = smem[ra];
-        }
-        // |column i|^2 = the pivot column's dot with itself: the lanes that published v hold a[.][K0] == v
-        const double sg = readlane_d(tot, 4 * (i - CL * K0) + K0);
+        // |column I|^2 = the pivot column's dot with itself, on the lane that looks after it
+        const double sg = readlane_d(tot, 16 * K0 + L);
         const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
+#ifdef SWEEP_PROF
+        SWEEP_TICK(6);                                     // reduce, |column|^2 known
+#endif
         // ---- reflector scalars (every lane, uniform values) ---------------------------
         // Branch-free: sg > 1e-290 keeps ss = x0^2 + sg a normal number whose rsqrt / rcp seeds + one Newton step
         // are good to a few 1e-16 (the reflector stays orthogonal to that level); a column with nothing to
@@ -403,34 +344,32 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         // ---- tau of this lane's column, its R entry, then the rank-1 update of every slot ----------
         const double tau_own = (on ? beta : 0.0) * fma(v0, rck, tot);
         smem[on ? wa : dump_i] = fma(-tau_own, v0, rck);
-        if (rq == 0 && cq == 0) smem[rrow] = alpha;
+        if (lane == 0) smem[rrow] = alpha;
         ra += rstep; wa += rstep;
-        auto slot = [&](auto tags) {
-            constexpr int k = decltype(tags)::value;
-            if constexpr (k < CS) {
-                constexpr int CTRL = (k == 0) ? 0x00 : (k == 1) ? 0x55 : (k == 2) ? 0xAA : 0xFF;   // quad_perm [k,k,k,k]
-                const double tau = quad_move<CTRL>(tau_own);
-#pragma unroll
-                for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
-            }
-        };
-        // the slot of the next pivot column first, then its owners publish it while the other slots update
-        const int in = i + 1;
-        slot(STag<K0>{});
-        if (in < f_ew && (in & 7) != 0) {
-            if (cq == (in & (CL - 1))) publish(STag<K0>{}, STag<RMAX>{});         // same chunk: in / CL == K0
+        // -tau of slot k on every row: [t0 t1 t2 t3] by rows -> [t0 t0 t2 t2], [t1 t1 t3 t3] -> four uniform-by-row copies
+        double nt[CS];
+        {
+            double e = -tau_own, o = e;
+            swap_rows16(e, o);
+            nt[0] = e; nt[2] = e; nt[1] = o; nt[3] = o;
+            swap_rows32(nt[0], nt[2]);
+            swap_rows32(nt[1], nt[3]);
         }
-        slot(STag<K0 + 1>{});
-        slot(STag<K0 + 2>{});
-        slot(STag<K0 + 3>{});
-        if (in < f_ew && (in & 7) == 0) {
-            // first column of the next chunk: slot 8 (KK + 1) / CL, column lane 8 (KK + 1) % CL, two more row slots
-            constexpr int KN = (8 * (KK + 1)) / CL;
-            if (cq == (8 * (KK + 1)) % CL) publish(STag<KN>{}, STag<RMAX + 2>{});
+#ifdef SWEEP_PROF
+        SWEEP_TICK(3);                                     // reflector scalars, tau, R entry issued
+#endif
+        dpp_guard();
+#pragma unroll
+        for (int rr = 0; rr <= RMAX; ++rr) {
+            // (slot K0 last: it rewrites the register the other slots read through the broadcast; the owner's own
+            //  column has tau = 0 and stays what the next reader of that lane expects -- nobody: it is retired)
+#pragma unroll
+            for (int k = CS - 1; k > K0; --k) fmac_bcast<L>(a[rr][k], a[rr][K0], nt[k]);
+            fmac_bcast_self<L>(a[rr][K0], nt[K0]);
         }
     };
 
-    // one chunk of 8 columns: fetch the two row slots the chunk's LAST publish needs, then the steps
+    // one chunk of 8 columns: fetch the two row slots the NEXT chunk's first column needs, then the steps
     auto chunk = [&](auto tagk, bool have_next) {
         constexpr int KK = decltype(tagk)::value;
         if (8 * KK >= f_ew) return;
@@ -442,23 +381,23 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
             }
         }
         if (have_next && KK == max((f_ew - 1) / 8 - 1, 0)) fetch_next_head();
-        const int ihi = min(8 * KK + 8, f_ew);        // (steps run over the ENVELOPE: the tile's rows fill in right of the
-                                                                // source's last column wherever R already reaches further, and that fill has to be eliminated too)
-        for (int i = 8 * KK; i < ihi; ++i) {
-            SWEEP_TICK(0);                                 // left the barrier
-            step(tagk, i);
-#ifdef SWEEP_PROF
-            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the tick sees the LDS writes out
-#endif
-            SWEEP_TICK(4);                                 // updates, R writes, publish issued
-            if constexpr (P2P) {
-                publish_prog(i + 1 < f_ew ? f_off + i + 1 : 0x7fffffff);
-            } else {
+        // (steps run over the ENVELOPE: the tile's rows fill in right of the source's last column wherever R already
+        //  reaches further, and that fill has to be eliminated too)
+        auto one = [&](auto tagj) {
+            if (8 * KK + decltype(tagj)::value < f_ew) {
+                SWEEP_TICK(0);                             // left the barrier
+                step(tagk, tagj);
+                SWEEP_TICK(4);                             // updates issued
                 __syncthreads();
+                SWEEP_TICK(5);                             // barrier wait
+#ifdef SWEEP_PROF
+                prof[7] += 1;
+#endif
+                ++tcur;
             }
-            SWEEP_TICK(5);                                 // barrier wait
-            ++tcur;
-        }
+        };
+        one(STag<0>{}); one(STag<1>{}); one(STag<2>{}); one(STag<3>{});
+        one(STag<4>{}); one(STag<5>{}); one(STag<6>{}); one(STag<7>{});
     };
 
     __syncthreads();                                       // R zeroed
@@ -470,23 +409,12 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     }
     while (have) {
         f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
-        if constexpr (P2P) {
-            cur_fi = fi;
-            safe_row = 0;
-            publish_prog(f_off);                           // started: nothing done yet
-        } else {
-            while (tcur < f_t0 - 1) { __syncthreads(); ++tcur; }
-        }
+        while (tcur < f_t0) { __syncthreads(); ++tcur; }   // (the host schedules t0 >= 1 and one spare step per slot reuse)
         init_addr();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
-        if (cq == 0) publish(STag<0>{}, STag<1>{});
-        if constexpr (!P2P) {
-            __syncthreads();                               // column 0 is visible to the fold's other wavefront
-            ++tcur;                                        // (the host schedules t0 >= 1 and one spare step per slot reuse)
-        }
         fi += NF;
         const bool have_next = fi < fold_end;
         if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
@@ -500,9 +428,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         chunk(STag<7>{}, have_next);
         have = have_next;
     }
-    if constexpr (!P2P) {
-        while (tcur < nsteps) { __syncthreads(); ++tcur; }
-    }
+    while (tcur < nsteps) { __syncthreads(); ++tcur; }
 
     // ---- flush R: row-major wtot x (wtot+1), entries at and right of the diagonal ----
     __syncthreads();

@@ -76,10 +76,7 @@ constexpr int LDS_MAX_BYTES = 160 * 1024;        // gfx950: 160 KiB per workgrou
 #define MSCKF_SWEEP_WPF 1
 #endif
 constexpr int LS_BIG_BATCH = 4000;               // from this many features on the 60-column leaves run twelve row blocks at a time
-#ifndef MSCKF_SWEEP_P2P
-#define MSCKF_SWEEP_P2P 0      // measured: root 159 us with progress words vs 148 us with the barrier per macro step (headline)
-#endif
-constexpr bool SWEEP_P2P = MSCKF_SWEEP_P2P != 0;  // root sweep: point-to-point progress words instead of a barrier per step
+constexpr bool SWEEP_P2P = false;                // (round 2 measured progress words instead of the barrier per macro step: 159 vs 148 us at the root)
 constexpr int SWEEP_NW = MSCKF_SWEEP_NW;         // concurrent folds of k_sweep
 constexpr int SWEEP_WPF = MSCKF_SWEEP_WPF;       // wavefronts per fold (1 or 2)
 // Group exchange: a shard's record holds one triangle slot per first clone slot; the slot is as wide as the sweep tile of
@@ -1275,7 +1272,6 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
-    lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF, true>), FOLD_LDS_BYTES, "k_sweep (p2p) LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 4, LS_RS4, false>), FOLD_LDS_BYTES, "k_lsweep<12,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 6, LS_RS6>), FOLD_LDS_BYTES, "k_lsweep<6> LDS attribute");

@@ -18,8 +18,8 @@ eng.sync()
 buf = (C.c_longlong * 64)()
 eng._lib.msckf_debug_fold_stamps(eng._h, buf, -1000000)
 a = np.frombuffer(buf, dtype=np.int64).reshape(8, 8)
-names = ["loop / idle", "-", "-", "-", "step (reads .. publish)", "barrier wait"]
-steps = 60 * 21 / 8.0
-print("per-wave cycle sums (root sweep), cycles per step assuming %.0f steps per wave" % steps)
+names = ["idle", "-", "dots", "scalars+tau", "update", "barrier", "reduce"]
+print("per-wave cycles per active step (root sweep); idle = waiting for the fold's first step / the other wavefronts' last ones")
 for w in range(8):
-    print(f"wave {w}: " + "  ".join(f"{n}={a[w, i] / steps:7.0f}" for i, n in enumerate(names)), f" total/step={a[w, :6].sum() / steps:.0f}")
+    steps = max(1, int(a[w, 7]))
+    print(f"wave {w}: steps={steps:4d} " + "  ".join(f"{n}={a[w, i] / steps:6.0f}" for i, n in enumerate(names) if n != "-"), f" total/step={a[w, 1:7].sum() / steps:.0f}  idle total={a[w, 0]:.0f}")
