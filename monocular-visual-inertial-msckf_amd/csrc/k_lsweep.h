@@ -2,8 +2,8 @@
 // systolic fold of k_wsweep.h applied to the K4 blocks themselves.  A leaf node owns a run of sorted features
 // with the same first clone slot and a window of w columns (+ rhs); its workgroup keeps the leaf's R (w x W
 // band storage) in LDS and folds "row blocks" into it: up to RB = 4 RSLOTS stacked rows [H_o | r_o] of a few
-// consecutive accepted features, held in the REGISTERS of one wavefront (lane (rq, cq) = (lane & 3, lane >> 2)
-// owns rows {rq + 4 rr} and window columns {cq + 16 k}).  NF wavefronts fold NF row blocks at NF consecutive
+// consecutive accepted features, held in the REGISTERS of one wavefront (lane (rq, cq) = (lane >> 4, lane & 15)
+// owns rows {rq + 4 rr} and window columns {cq + 16 k}; the column step is sweep_step.h's).  NF wavefronts fold NF row blocks at NF consecutive
 // columns (block b runs column c at macro step t0(b) + c, t0(b) = 1 + (b / NF)(w + gap) + b % NF), one workgroup
 // barrier per macro step; the arithmetic is that of folding the blocks one after the other.  Unlike a
 // triangle's, all rows of a block are alive from the first column on; columns retire in chunks of 8 as in
@@ -77,12 +77,11 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
     const int t = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
-    const int rq = lane & 3, cq = lane >> 2;
+    const int rq = lane >> 4, cq = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(nd.w);
     const int nfeat = min(nd.src_end - nd.src_begin, LS_MAXF);
     constexpr int RB0 = W;
     double* Rb = smem + W;                                     // [W][W] (rows 0..w-1 used)
-    double* vb = smem + (size_t)(W + 1) * W + wv * VB;
     const int dump_i = (W + 1) * W + NF * VB + wv * 64 + lane;
     const int zero_i = (W + 1) * W + NF * VB + NF * 64;
     int* qrow = reinterpret_cast<int*>(smem + (size_t)(W + 1) * W + NF * VB + NF * 64 + 2);   // [LS_MAXF + 1] row prefix
@@ -187,22 +186,14 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
         else gather_t(dst, STag<0>{});
     };
 
-    auto publish = [&](auto tagk) {
-        constexpr int KN = decltype(tagk)::value;
-        if constexpr (KN < CS) {
-            double* dst = vb + rq * RSLOTS;
-#pragma unroll
-            for (int rr = 0; rr < RSLOTS; ++rr) dst[rr] = a[rr][KN];
-        }
-    };
-
     int tcur = 0;
-    int ra1 = 0, wa1 = 0, st1 = 0, ra2 = 0, wa2 = 0, st2 = 0;
+    // The R entries this lane looks after: slot rq (local column lco1) and, on the 90-column tile, slot 4 + (rq & 1)
+    // (rows 2, 3 mirror rows 0, 1: same reads, same tau, no write).
+    int ra1 = 0, wa1 = 0, st1 = 0, ra2 = 0, wa2 = 0, st2 = 0, sw2 = 0;
     const int lco1 = cq + CL * rq;
-    const int lco2 = cq + CL * (4 + rq);
+    const int lco2 = cq + CL * (4 + (rq & 1));
     const bool isr1 = (CS == 4) && (rq == 3) && (cq == CL - 1);
-    const bool isr2 = HAS2 && (4 + rq == CS - 1) && (cq == CL - 1);
-    const bool has2 = HAS2 && (rq < 2) && (4 + rq < CS);
+    const bool isr2 = HAS2 && (4 + (rq & 1) == CS - 1) && (cq == CL - 1);
     auto init_addr = [&]() {
         {
             const bool valid = isr1 || lco1 < w;
@@ -211,108 +202,25 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
             st1 = valid ? (isr1 ? W : W - 1) : 0;
         }
         if constexpr (HAS2) {
-            const bool valid = has2 && (isr2 || lco2 < w);
+            const bool valid = isr2 || lco2 < w;
             ra2 = valid ? RB0 + (isr2 ? W - 1 : lco2) : zero_i;
-            wa2 = valid ? ra2 : dump_i;
+            wa2 = (valid && rq < 2) ? ra2 : dump_i;
             st2 = valid ? (isr2 ? W : W - 1) : 0;
+            sw2 = (valid && rq < 2) ? st2 : 0;
         }
     };
 
-    auto step = [&](auto tagk, int i) {
-        constexpr int KK = decltype(tagk)::value;
-        constexpr int K0 = (8 * KK) / CL;
-        const int rrow = RB0 + i * W;
-        double v[RSLOTS];
-        {
-            const double* src = vb + rq * RSLOTS;
-#pragma unroll
-            for (int rr = 0; rr < RSLOTS; ++rr) v[rr] = src[rr];
-        }
-        const double x0 = smem[rrow];
-        const double rck1 = smem[ra1];
-        double rck2 = 0.0;
-        if constexpr (HAS2) rck2 = smem[ra2];
-        const bool on1 = (lco1 > i) || isr1;
-        const bool on2 = HAS2 && has2 && ((lco2 > i) || isr2);
-        double sp[CS];
-#pragma unroll
-        for (int k = 0; k < CS; ++k) {
-            sp[k] = 0.0;
-            if (k >= K0) {
-                double s0 = v[0] * a[0][k];
-#pragma unroll
-                for (int rr = 1; rr < RSLOTS; ++rr) s0 = fma(v[rr], a[rr][k], s0);
-                sp[k] = s0;
-            }
-        }
-        const bool b0 = (rq & 1) != 0, b1 = (rq & 2) != 0;
-        double tot1 = 0.0, tot2 = 0.0;
-        if constexpr (K0 <= 3) {
-            double pB = (b0 ? sp[3] : sp[2]) + quad_move<0xB1>(b0 ? sp[2] : sp[3]);
-            if constexpr (K0 <= 1) {
-                double pA = (b0 ? sp[1] : sp[0]) + quad_move<0xB1>(b0 ? sp[0] : sp[1]);
-                tot1 = (b1 ? pB : pA) + quad_move<0x4E>(b1 ? pA : pB);
-            } else {
-                tot1 = pB + quad_move<0x4E>(pB);
-            }
-        }
-        if constexpr (HAS2) {
-            double pC;
-            if constexpr (CS == 6) pC = (b0 ? sp[5] : sp[4]) + quad_move<0xB1>(b0 ? sp[4] : sp[5]);
-            else pC = sp[4] + quad_move<0xB1>(sp[4]);
-            tot2 = pC + quad_move<0x4E>(pC);
-        }
-        (void)b1;
-        double sg;
-        if constexpr (K0 <= 3) sg = readlane_d(tot1, 4 * (i - CL * K0) + K0);
-        else sg = readlane_d(tot2, 4 * (i - CL * K0) + (K0 - 4));
-        const bool live = sg > SWEEP_TINY;
-        // branch-free (k_sweep.h): sg > 1e-290 keeps ss normal; nothing to eliminate -> beta = 0, alpha = x0
-        const double ss = live ? fma(x0, x0, sg) : 1.0;
-        const double y = fast_rsqrt(ss);
-        const double nrm = ss * y;
-        const double beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;
-        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
-        const double v0 = x0 - alpha;
-        const double tau1 = (on1 ? beta : 0.0) * fma(v0, rck1, tot1);
-        smem[on1 ? wa1 : dump_i] = fma(-tau1, v0, rck1);
-        double tau2 = 0.0;
-        if constexpr (HAS2) {
-            tau2 = (on2 ? beta : 0.0) * fma(v0, rck2, tot2);
-            smem[on2 ? wa2 : dump_i] = fma(-tau2, v0, rck2);
-        }
-        if (rq == 0 && cq == 0) smem[rrow] = alpha;
+    auto step = [&](auto tagk, auto tagj) {
+        constexpr int I = 8 * decltype(tagk)::value + decltype(tagj)::value;   // the block's column
+        constexpr int K0 = I / CL, L = I % CL;
+        const int rrow = RB0 + I * W;
+        int l1 = lco1, l2 = lco2;
+        asm volatile("" : "+v"(l1), "+v"(l2));            // (keeps the lane masks of all columns from being hoisted and spilled)
+        const bool on1 = (l1 > I) || isr1;
+        const bool on2 = HAS2 && ((l2 > I) || isr2);
+        sweep_column_step<CS, RSLOTS, RSLOTS, K0, L>(a, smem, rrow, ra1, wa1, on1, ra2, wa2, on2, dump_i, lane);
         ra1 += st1; wa1 += st1;
-        if constexpr (HAS2) { ra2 += st2; wa2 += st2; }
-        auto slot = [&](auto tags) {
-            constexpr int k = decltype(tags)::value;
-            if constexpr (k < CS) {
-                double tau;
-                if constexpr (k < 4) {
-                    constexpr int CTRL = (k == 0) ? 0x00 : (k == 1) ? 0x55 : (k == 2) ? 0xAA : 0xFF;
-                    tau = quad_move<CTRL>(tau1);
-                } else {
-                    constexpr int CTRL = (k == 4) ? 0x00 : 0x55;
-                    tau = quad_move<CTRL>(tau2);
-                }
-#pragma unroll
-                for (int rr = 0; rr < RSLOTS; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
-            }
-        };
-        const int in = i + 1;
-        slot(STag<K0>{});
-        if (in < w && (in & 7) != 0) {
-            if (cq == (in & (CL - 1))) publish(STag<K0>{});
-        }
-        slot(STag<K0 + 1>{});
-        slot(STag<K0 + 2>{});
-        slot(STag<K0 + 3>{});
-        slot(STag<K0 + 4>{});
-        slot(STag<K0 + 5>{});
-        if (in < w && (in & 7) == 0) {
-            constexpr int KN = (8 * (KK + 1)) / CL;
-            if (cq == (8 * (KK + 1)) % CL) publish(STag<KN>{});
-        }
+        if constexpr (HAS2) { ra2 += st2; wa2 += sw2; }
     };
 
     bool gathered = false;              // the next block sits in nxt
@@ -331,12 +239,15 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
                     }
                 }
             }
-            const int ihi = min(8 * KK + 8, w);
-            for (int i = 8 * KK; i < ihi; ++i) {
-                step(tagk, i);
-                __syncthreads();
-                ++tcur;
-            }
+            auto one = [&](auto tagj) {
+                if (8 * KK + decltype(tagj)::value < w) {
+                    step(tagk, tagj);
+                    __syncthreads();
+                    ++tcur;
+                }
+            };
+            one(STag<0>{}); one(STag<1>{}); one(STag<2>{}); one(STag<3>{});
+            one(STag<4>{}); one(STag<5>{}); one(STag<6>{}); one(STag<7>{});
         }
     };
 
@@ -358,7 +269,7 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
             prep_B();
             gather(a);
         }
-        while (tcur < t0 - 1) { __syncthreads(); ++tcur; }
+        while (tcur < t0) { __syncthreads(); ++tcur; }
         init_addr();
         if constexpr (PREF) {
 #pragma unroll
@@ -366,9 +277,6 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
 #pragma unroll
                 for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
         }
-        if (cq == 0) publish(STag<0>{});
-        __syncthreads();
-        ++tcur;
         const int bn = b + NF;
         const int bnext = bn < nblk ? bn : -1;
         gathered = false;

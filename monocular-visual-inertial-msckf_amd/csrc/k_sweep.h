@@ -77,7 +77,10 @@ struct SweepArgs {
 constexpr int SWEEP_MAX_W = 60;        // widest source / envelope (local column 63 holds the rhs)
 constexpr int SWEEP_RS = 64;           // doubles per R row in LDS: entry (c, col) at [c][col - c], rhs at [c][63]
 constexpr double SWEEP_TINY = 1e-290;  // |column|^2 under this is treated as an exact zero column
-constexpr int SWEEP_VB = 72;           // per-wavefront published column: [rq][16] rows + |column|^2 at [64]
+constexpr int SWEEP_VB = 72;           // (LDS words per fold slot once used for the published column; kept: the dump / zero words sit behind)
+}  // namespace msckf
+#include "sweep_step.h"
+namespace msckf {
 
 __host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nf, int wpf) {
     return ((size_t)wtot * SWEEP_RS + (size_t)nf * SWEEP_VB + (size_t)nf * wpf * 64 + 2 + (size_t)nf) * 8;   // R | published columns | dumps | zero | progress
@@ -143,31 +146,6 @@ template <int KK> struct STag { static constexpr int value = KK; };
 #else
 #define SWEEP_TICK(slot) do { } while (0)
 #endif
-
-// 64-bit halves of the gfx950 lane swaps.  swap_rows32(x, y): x = [x rows 0,1 | y rows 0,1], y = [x rows 2,3 | y rows 2,3];
-// swap_rows16(x, y): x = [x r0, y r0, x r2, y r2], y = [x r1, y r1, x r3, y r3]  (rows = the four 16-lane DPP rows).
-__device__ __forceinline__ void swap_rows32(double& x, double& y) {
-    const auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
-    const auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
-    x = __hiloint2double((int)h[0], (int)l[0]);
-    y = __hiloint2double((int)h[1], (int)l[1]);
-}
-__device__ __forceinline__ void swap_rows16(double& x, double& y) {
-    const auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
-    const auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
-    x = __hiloint2double((int)h[0], (int)l[0]);
-    y = __hiloint2double((int)h[1], (int)l[1]);
-}
-// d += (lane L of the 16-lane row of src) * w, no hazard padding (the caller opens a run of these with dpp_guard()).
-template <int L>
-__device__ __forceinline__ void fmac_bcast(double& d, double src, double w) {
-    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(src), "v"(w), "i"(L));
-}
-template <int L>
-__device__ __forceinline__ void fmac_bcast_self(double& d, double w) {     // d += (lane L of d's row) * w
-    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(w), "i"(L));
-}
-__device__ __forceinline__ void dpp_guard() { asm volatile("s_nop 1"); }
 
 // NF concurrent folds, one wavefront each.  Lane (rq, cq) = (lane >> 4, lane & 15): the 16 column lanes of one row
 // lane are one DPP row, so the pivot column -- held by column lane i & 15 of every row -- reaches the other 15 through
@@ -280,93 +258,11 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         constexpr int K0 = I / CL;                        // first live column slot: the pivot column's
         constexpr int L = I % CL;                         // column lane that holds the pivot column
         const int rrow = (f_off + I) * SWEEP_RS;          // pivot row of R (uniform)
-        const double x0 = smem[rrow];
-        const double rck = smem[ra];                      // R(c, off + lco)
         int lcl = lco;
         asm volatile("" : "+v"(lcl));                     // (or the 60 lane masks lco > I are hoisted out of the fold loop and spilled)
         const bool on = (lcl > I) || isr_lane;            // left of / at the pivot: retired (the rhs never is)
-        // ---- dots: partial sums per live slot, the pivot column read through the row broadcast; at least four
-        // independent running sums (a dependent v_fma_f64 issues every 32 cycles, independent ones every ~10) ----
-        constexpr int NACC = (K0 == 3) ? 4 : (K0 == 2) ? 2 : 1;
-        double acc[CS][NACC];
-#pragma unroll
-        for (int k = 0; k < CS; ++k)
-#pragma unroll
-            for (int j = 0; j < NACC; ++j) acc[k][j] = 0.0;
-        dpp_guard();
-#pragma unroll
-        for (int rr = 0; rr <= RMAX; ++rr) {
-#pragma unroll
-            for (int k = K0; k < CS; ++k) fmac_bcast<L>(acc[k][rr % NACC], a[rr][K0], a[rr][k]);
-        }
-        double sp[CS];
-#pragma unroll
-        for (int k = 0; k < CS; ++k) {
-            if constexpr (NACC == 4) sp[k] = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
-            else if constexpr (NACC == 2) sp[k] = acc[k][0] + acc[k][1];
-            else sp[k] = acc[k][0];
-        }
-#ifdef SWEEP_PROF
-        SWEEP_TICK(2);                                     // dots issued
-#endif
-        // ---- reduce-scatter over the four row lanes: row r gets the dot of slot r -----------------------
-        double tot;
-        if constexpr (K0 <= 1) {
-            swap_rows32(sp[0], sp[2]);
-            swap_rows32(sp[1], sp[3]);
-            double pA = sp[0] + sp[2], pB = sp[1] + sp[3];  // rows 0,1: slot 0 / 1;  rows 2,3: slot 2 / 3  (row pairs summed)
-            swap_rows16(pA, pB);
-            tot = pA + pB;
-        } else {
-            // slots 0, 1 are retired: only rows 2, 3 need a total (rows 0, 1 get a copy nobody uses)
-            swap_rows16(sp[2], sp[3]);
-            double g = sp[2] + sp[3], h = g;                // [s2 r0+r1, s3 r0+r1, s2 r2+r3, s3 r2+r3]
-            swap_rows32(g, h);
-            tot = g + h;
-        }
-        // |column I|^2 = the pivot column's dot with itself, on the lane that looks after it
-        const double sg = readlane_d(tot, 16 * K0 + L);
-        const bool live = sg > SWEEP_TINY;                // wave-uniform; below: nothing to eliminate
-#ifdef SWEEP_PROF
-        SWEEP_TICK(6);                                     // reduce, |column|^2 known
-#endif
-        // ---- reflector scalars (every lane, uniform values) ---------------------------
-        // Branch-free: sg > 1e-290 keeps ss = x0^2 + sg a normal number whose rsqrt / rcp seeds + one Newton step
-        // are good to a few 1e-16 (the reflector stays orthogonal to that level); a column with nothing to
-        // eliminate gets beta = 0, alpha = x0 (identity).  |x0| > 1e150 does not occur (R entries are bounded by
-        // the column norms of a normalised-coordinate Jacobian stack).
-        const double ss = live ? fma(x0, x0, sg) : 1.0;
-        const double y = fast_rsqrt(ss);
-        const double nrm = ss * y;
-        const double beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;      // 1 / (nrm (nrm + |x0|))
-        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
-        const double v0 = x0 - alpha;
-        // ---- tau of this lane's column, its R entry, then the rank-1 update of every slot ----------
-        const double tau_own = (on ? beta : 0.0) * fma(v0, rck, tot);
-        smem[on ? wa : dump_i] = fma(-tau_own, v0, rck);
-        if (lane == 0) smem[rrow] = alpha;
+        sweep_column_step<CS, 16, RMAX + 1, K0, L>(a, smem, rrow, ra, wa, on, 0, 0, false, dump_i, lane);
         ra += rstep; wa += rstep;
-        // -tau of slot k on every row: [t0 t1 t2 t3] by rows -> [t0 t0 t2 t2], [t1 t1 t3 t3] -> four uniform-by-row copies
-        double nt[CS];
-        {
-            double e = -tau_own, o = e;
-            swap_rows16(e, o);
-            nt[0] = e; nt[2] = e; nt[1] = o; nt[3] = o;
-            swap_rows32(nt[0], nt[2]);
-            swap_rows32(nt[1], nt[3]);
-        }
-#ifdef SWEEP_PROF
-        SWEEP_TICK(3);                                     // reflector scalars, tau, R entry issued
-#endif
-        dpp_guard();
-#pragma unroll
-        for (int rr = 0; rr <= RMAX; ++rr) {
-            // (slot K0 last: it rewrites the register the other slots read through the broadcast; the owner's own
-            //  column has tau = 0 and stays what the next reader of that lane expects -- nobody: it is retired)
-#pragma unroll
-            for (int k = CS - 1; k > K0; --k) fmac_bcast<L>(a[rr][k], a[rr][K0], nt[k]);
-            fmac_bcast_self<L>(a[rr][K0], nt[K0]);
-        }
     };
 
     // one chunk of 8 columns: fetch the two row slots the NEXT chunk's first column needs, then the steps

@@ -4,16 +4,15 @@
 // after the other -- for
 //   * wider source triangles: a register tile of W = 16 CS columns (CS = 4: tracks of up to 10
 //     clone slots, CS = 6: up to 15 slots; local column W-1 holds the rhs), lane (rq, cq) =
-//     (lane & 3, lane >> 2) owns rows {rq + 4 rr}, rr < 4 CS, and local columns {cq + 16 k}, k < CS;
+//     (lane >> 4, lane & 15) owns rows {rq + 4 rr}, rr < 4 CS, and local columns {cq + 16 k}, k < CS;
 //   * any number of clones: the band R lives in a RING of RC rows x W doubles in LDS (entry (c, col)
 //     at [c mod RC][col - c], rhs at [c mod RC][W-1]).  The schedule is static, so the host
 //     (sweep_flush_table) knows for every macro step t which rows no present or future fold step
 //     touches any more; at the head of step t the wavefronts copy rows [flo(t), fhi(t)) to the
 //     output block and clear their ring slots for rows RC further down.
-// Per step the quad's partial dots are reduce-scattered: row lane rq ends up with the dot of column
-// slot rq and, for rq < 2 when CS > 4, of slot 4 + rq, i.e. every lane looks after one or two
-// entries of the pivot row of R (reads them, forms tau, writes them back; tau is broadcast over the
-// quad for the rank-1 update).
+// The column step is sweep_step.h's: the pivot column reaches the tile's lanes through the DPP row broadcast of
+// the FMAs, the row lanes' partial dots are reduce-scattered with the lane swaps and every lane looks after one
+// or two entries of the pivot row of R.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "k_sweep.h"
@@ -58,14 +57,13 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
     const int t = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
-    const int rq = lane & 3;
-    const int cq = lane >> 2;
+    const int rq = lane >> 4;
+    const int cq = lane & 15;
     const int RC = 1 << p.rc_log2, RCM = RC - 1;
     // (one row of padding in front of the ring: a lane whose column has retired keeps walking its band
     //  offset below zero; with the pivot in ring row 0 that address must still be inside the allocation)
     double* Rb = smem + W;                                    // [RC][W]
     constexpr int RB0 = W;                                    // index of the ring in smem
-    double* vb = smem + (size_t)(RC + 1) * W + wv * VB;       // published column of this fold slot
     const int dump_i = (RC + 1) * W + NF * VB + wv * 64 + lane;
     const int zero_i = (RC + 1) * W + NF * VB + NF * 64;
     int* ftab = reinterpret_cast<int*>(smem + (size_t)(RC + 1) * W + NF * VB + NF * 64 + 2);
@@ -134,15 +132,6 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
                 for (int k = 0; k < CS; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
         }
     };
-    auto publish = [&](auto tagk, auto tagr) {
-        constexpr int KN = decltype(tagk)::value;
-        constexpr int RP = decltype(tagr)::value < RSL - 1 ? decltype(tagr)::value : RSL - 1;
-        if constexpr (KN < CS) {
-            double* dst = vb + rq * RSL;
-#pragma unroll
-            for (int rr = 0; rr <= RP; ++rr) dst[rr] = a[rr][KN];
-        }
-    };
 
     // rows [lo, lo + n) are final at the head of macro step ts: out to HBM, ring slots cleared
     auto flush_rows = [&](int ts) {
@@ -172,143 +161,56 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
         flush_rows(tcur);
     };
 
-    // The R entries this lane looks after: primary slot rq (local column lco1), secondary slot 4 + rq for rq < 2.
+    // The R entries this lane looks after: slot rq (local column lco1) and, on the 90-column tile, slot 4 + (rq & 1)
+    // (rows 2, 3 mirror rows 0, 1: same reads, same tau, no write).
     int ra1 = 0, wa1 = 0, st1 = 0, wr1 = 0;
-    int ra2 = 0, wa2 = 0, st2 = 0, wr2 = 0;
+    int ra2 = 0, wa2 = 0, st2 = 0, wr2 = 0, sw2 = 0, ww2 = 0;
     const int lco1 = cq + CL * rq;
-    const int lco2 = cq + CL * (4 + rq);
+    const int lco2 = cq + CL * (4 + (rq & 1));
     const bool isr1 = (CS == 4) && (rq == 3) && (cq == CL - 1);
-    const bool isr2 = HAS2 && (4 + rq == CS - 1) && (cq == CL - 1);
-    const bool has1 = rq < CS;                          // CS >= 4: always
-    const bool has2 = HAS2 && (rq < 2) && (4 + rq < CS);
+    const bool isr2 = HAS2 && (4 + (rq & 1) == CS - 1) && (cq == CL - 1);
     auto init_addr = [&]() {
         const int r0 = RB0 + (f_off & RCM) * W;
         {
-            const bool valid = has1 && (isr1 || lco1 < f_ew);
+            const bool valid = isr1 || lco1 < f_ew;
             ra1 = valid ? r0 + (isr1 ? W - 1 : lco1) : zero_i;
             wa1 = valid ? ra1 : dump_i;
             st1 = valid ? (isr1 ? W : W - 1) : 0;
             wr1 = valid ? RC * W : 0;
         }
         if constexpr (HAS2) {
-            const bool valid = has2 && (isr2 || lco2 < f_ew);
+            const bool valid = isr2 || lco2 < f_ew;
+            const bool mine = valid && rq < 2;
             ra2 = valid ? r0 + (isr2 ? W - 1 : lco2) : zero_i;
-            wa2 = valid ? ra2 : dump_i;
+            wa2 = mine ? ra2 : dump_i;
             st2 = valid ? (isr2 ? W : W - 1) : 0;
             wr2 = valid ? RC * W : 0;
+            sw2 = mine ? st2 : 0;
+            ww2 = mine ? wr2 : 0;
         }
     };
 
-    auto step = [&](auto tagk, int i) {
+    auto step = [&](auto tagk, auto tagj) {
         constexpr int KK = decltype(tagk)::value;
-        constexpr int RMAX = (2 * KK + 1 < RSL - 1) ? 2 * KK + 1 : RSL - 1;     // live row slots
-        constexpr int K0 = (8 * KK) / CL;                                        // first live column slot
-        const int prow = (f_off + i) & RCM;
+        constexpr int I = 8 * KK + decltype(tagj)::value;                        // the fold's column
+        constexpr int NR = (2 * KK + 2 < RSL) ? 2 * KK + 2 : RSL;                // live row slots
+        constexpr int K0 = I / CL, L = I % CL;                                   // the pivot column's slot / column lane
+        const int prow = (f_off + I) & RCM;
         const int rrow = RB0 + prow * W;                   // pivot row of R (uniform)
-        // ---- reads ------------------------------------------------------------------
-        double v[RMAX + 1];
-        {
-            const double* src = vb + rq * RSL;
-#pragma unroll
-            for (int rr = 0; rr <= RMAX; ++rr) v[rr] = src[rr];
-        }
-        const double x0 = smem[rrow];
-        const double rck1 = smem[ra1];
-        double rck2 = 0.0;
-        if constexpr (HAS2) rck2 = smem[ra2];
-        const bool on1 = (lco1 > i) || isr1;
-        const bool on2 = HAS2 && has2 && ((lco2 > i) || isr2);
-        // ---- dots (one partial sum per live slot), reduce-scattered over the quad ---------------------
-        double sp[CS];
-#pragma unroll
-        for (int k = 0; k < CS; ++k) {
-            sp[k] = 0.0;
-            if (k >= K0) {
-                double s0 = v[0] * a[0][k];
-#pragma unroll
-                for (int rr = 1; rr <= RMAX; ++rr) s0 = fma(v[rr], a[rr][k], s0);
-                sp[k] = s0;
-            }
-        }
-        const bool b0 = (rq & 1) != 0, b1 = (rq & 2) != 0;
-        double tot1 = 0.0, tot2 = 0.0;                     // lane rq: full dot of slot rq / of slot 4 + (rq & 1)
-        if constexpr (K0 <= 3) {
-            double pB = (b0 ? sp[3] : sp[2]) + quad_move<0xB1>(b0 ? sp[2] : sp[3]);
-            if constexpr (K0 <= 1) {
-                double pA = (b0 ? sp[1] : sp[0]) + quad_move<0xB1>(b0 ? sp[0] : sp[1]);
-                tot1 = (b1 ? pB : pA) + quad_move<0x4E>(b1 ? pA : pB);
-            } else {
-                tot1 = pB + quad_move<0x4E>(pB);           // slots 0, 1 are retired
-            }
-        }
-        if constexpr (HAS2) {
-            double pC;
-            if constexpr (CS == 6) pC = (b0 ? sp[5] : sp[4]) + quad_move<0xB1>(b0 ? sp[4] : sp[5]);
-            else pC = sp[4] + quad_move<0xB1>(sp[4]);      // CS == 5: one secondary slot
-            tot2 = pC + quad_move<0x4E>(pC);
-        }
-        (void)b1;
-        // |column i|^2 = the pivot column's dot with itself: its owners hold a[.][K0] == v
-        double sg;
-        if constexpr (K0 <= 3) sg = readlane_d(tot1, 4 * (i - CL * K0) + K0);
-        else sg = readlane_d(tot2, 4 * (i - CL * K0) + (K0 - 4));
-        const bool live = sg > SWEEP_TINY;
-        // ---- reflector scalars (every lane, uniform values) ---------------------------
-        // branch-free (k_sweep.h): sg > 1e-290 keeps ss normal; nothing to eliminate -> beta = 0, alpha = x0
-        const double ss = live ? fma(x0, x0, sg) : 1.0;
-        const double y = fast_rsqrt(ss);
-        const double nrm = ss * y;
-        const double beta = live ? y * fast_rcp(nrm + fabs(x0)) : 0.0;
-        const double alpha = live ? ((x0 > 0.0) ? -nrm : nrm) : x0;
-        const double v0 = x0 - alpha;
-        // ---- tau of this lane's column(s), its R entries, then the rank-1 update of every slot ----------
-        const double tau1 = (on1 ? beta : 0.0) * fma(v0, rck1, tot1);
-        smem[on1 ? wa1 : dump_i] = fma(-tau1, v0, rck1);
-        double tau2 = 0.0;
-        if constexpr (HAS2) {
-            tau2 = (on2 ? beta : 0.0) * fma(v0, rck2, tot2);
-            smem[on2 ? wa2 : dump_i] = fma(-tau2, v0, rck2);
-        }
-        if (rq == 0 && cq == 0) smem[rrow] = alpha;
+        int l1 = lco1, l2 = lco2;
+        asm volatile("" : "+v"(l1), "+v"(l2));            // (keeps the lane masks of all columns from being hoisted and spilled)
+        const bool on1 = (l1 > I) || isr1;
+        const bool on2 = HAS2 && ((l2 > I) || isr2);
+        sweep_column_step<CS, RSL, NR, K0, L>(a, smem, rrow, ra1, wa1, on1, ra2, wa2, on2, dump_i, lane);
         ra1 += st1; wa1 += st1;
-        if constexpr (HAS2) { ra2 += st2; wa2 += st2; }
+        if constexpr (HAS2) { ra2 += st2; wa2 += sw2; }
         if (prow == RCM) {                                  // the next pivot row wraps around the ring
             ra1 -= wr1; wa1 -= wr1;
-            if constexpr (HAS2) { ra2 -= wr2; wa2 -= wr2; }
-        }
-        auto slot = [&](auto tags) {
-            constexpr int k = decltype(tags)::value;
-            if constexpr (k < CS) {
-                double tau;
-                if constexpr (k < 4) {
-                    constexpr int CTRL = (k == 0) ? 0x00 : (k == 1) ? 0x55 : (k == 2) ? 0xAA : 0xFF;   // quad_perm [k,k,k,k]
-                    tau = quad_move<CTRL>(tau1);
-                } else {
-                    constexpr int CTRL = (k == 4) ? 0x00 : 0x55;
-                    tau = quad_move<CTRL>(tau2);
-                }
-#pragma unroll
-                for (int rr = 0; rr <= RMAX; ++rr) a[rr][k] = fma(-tau, v[rr], a[rr][k]);
-            }
-        };
-        // the slot of the next pivot column first, then its owners publish it while the other slots update
-        const int in = i + 1;
-        slot(STag<K0>{});
-        if (in < f_ew && (in & 7) != 0) {
-            if (cq == (in & (CL - 1))) publish(STag<K0>{}, STag<RMAX>{});         // same chunk: in / CL == K0
-        }
-        slot(STag<K0 + 1>{});
-        slot(STag<K0 + 2>{});
-        slot(STag<K0 + 3>{});
-        slot(STag<K0 + 4>{});
-        slot(STag<K0 + 5>{});
-        if (in < f_ew && (in & 7) == 0) {
-            constexpr int KN = (8 * (KK + 1)) / CL;
-            if (cq == (8 * (KK + 1)) % CL) publish(STag<KN>{}, STag<RMAX + 2>{});
+            if constexpr (HAS2) { ra2 -= wr2; wa2 -= ww2; }
         }
     };
 
-    // one chunk of 8 columns: fetch the two row slots the chunk's LAST publish needs, then the steps
+    // one chunk of 8 columns: fetch the two row slots the NEXT chunk's first column needs, then the steps
     auto chunk = [&](auto tagk, bool have_next) {
         constexpr int KK = decltype(tagk)::value;
         if constexpr (KK < G::NCH) {
@@ -321,12 +223,16 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
                 }
             }
             if (have_next && KK == max((f_ew - 1) / 8 - 1, 0)) fetch_next_head();
-            const int ihi = min(8 * KK + 8, f_ew);        // (steps run over the ENVELOPE: the tile's rows fill in right of the
-                                                                // source's last column wherever R already reaches further, and that fill has to be eliminated too)
-            for (int i = 8 * KK; i < ihi; ++i) {
-                step(tagk, i);
-                barrier_step();
-            }
+            // (steps run over the ENVELOPE: the tile's rows fill in right of the source's last column wherever R
+            //  already reaches further, and that fill has to be eliminated too)
+            auto one = [&](auto tagj) {
+                if (8 * KK + decltype(tagj)::value < f_ew) {
+                    step(tagk, tagj);
+                    barrier_step();
+                }
+            };
+            one(STag<0>{}); one(STag<1>{}); one(STag<2>{}); one(STag<3>{});
+            one(STag<4>{}); one(STag<5>{}); one(STag<6>{}); one(STag<7>{});
         }
     };
 
@@ -340,7 +246,7 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
     }
     while (have) {
         f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
-        while (tcur < f_t0 - 1) barrier_step();
+        while (tcur < f_t0) barrier_step();
         init_addr();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
@@ -349,8 +255,7 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
                 if constexpr (PREFETCH_HEAD) a[rr][k] = nxt[rr][k];
                 else a[rr][k] = load_elem(f_src, f_w, rr, k);
             }
-        if (cq == 0) publish(STag<0>{}, STag<1>{});
-        barrier_step();                                    // (the host schedules t0 >= 1 and one spare step per slot reuse)
+        // (the host schedules t0 >= 1 and one spare step per slot reuse)
         fi += NF;
         const bool have_next = fi < fold_end;
         if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
