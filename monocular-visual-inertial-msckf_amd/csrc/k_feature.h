@@ -49,6 +49,7 @@ struct FeatureArgs {
     const unsigned char* select; // optional [F] flags of k_select: features without bit 0 are skipped
     double* gamma;               // [F]
     long long* stamps;           // optional diagnostics (8 per feature), may be null
+    long long zero_idx;          // index (scalars) of the 8 zero words behind the last block (k_lsweep loads them for absent entries)
 };
 
 // The 6M columns of a track's clone block are worked on in chunks of whole views, at most 64 columns each (one
@@ -88,6 +89,10 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     double* sV = sA + R2 * 6;              // [R2][3]   Householder vectors
     double* sZ = sV + R2 * 3;              // [3][C6]
 
+    if (f == 0 && lane < 8) {                  // the stack's zero words (saves the host a memset launch in front of this kernel)
+        if (p.stack_f32) static_cast<float*>(p.stack)[p.zero_idx + lane] = 0.0f;
+        else static_cast<double*>(p.stack)[p.zero_idx + lane] = 0.0;
+    }
     if (p.select && !(p.select[f] & 1)) {      // not in valid_features (MSCKF.py:453-455): no rows, not a rejection
         if (lane == 0) { p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3; }
         return;

@@ -46,21 +46,20 @@ constexpr int LS_RS6 = 8;       // row slots of the 90-column leaf tile: 32 rows
 template <int CS, int RSLOTS> struct LSweepGeom {
     static constexpr int W = 16 * CS;
     static constexpr int RB = 4 * RSLOTS;
-    static constexpr int VB = 4 * RSLOTS + 4;
 };
 
 template <int CS, int RSLOTS>
 __host__ __device__ inline size_t lsweep_lds_bytes(int nf) {
     using G = LSweepGeom<CS, RSLOTS>;
-    // pad row | R | published columns | dump | zero | qrow | blkfirst, nblk | per-wave row tables (base, M, cols)
-    return ((size_t)(G::W + 1) * G::W + (size_t)nf * G::VB + (size_t)nf * 64 + 2) * 8 + (size_t)(LS_MAXF + 2 + LS_MAXB + 4) * 4 +
+    // pad row | R | dump | zero | qrow | blkfirst, nblk | per-wave row tables (base, M, cols)
+    return ((size_t)(G::W + 1) * G::W + (size_t)nf * 64 + 2) * 8 + (size_t)(LS_MAXF + 2 + LS_MAXB + 4) * 4 +
            (size_t)nf * G::RB * (4 + 4 + 16);
 }
 
 template <int NF, int CS, int RSLOTS, bool PREF_ = (CS == 4)>
 __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
     using G = LSweepGeom<CS, RSLOTS>;
-    constexpr int W = G::W, RB = G::RB, VB = G::VB;
+    constexpr int W = G::W, RB = G::RB;
     constexpr int CL = 16;
     constexpr bool HAS2 = CS > 4;
     constexpr int NCH = 2 * CS;
@@ -82,9 +81,9 @@ __global__ __launch_bounds__(64 * NF) void k_lsweep(LSweepArgs p) {
     const int nfeat = min(nd.src_end - nd.src_begin, LS_MAXF);
     constexpr int RB0 = W;
     double* Rb = smem + W;                                     // [W][W] (rows 0..w-1 used)
-    const int dump_i = (W + 1) * W + NF * VB + wv * 64 + lane;
-    const int zero_i = (W + 1) * W + NF * VB + NF * 64;
-    int* qrow = reinterpret_cast<int*>(smem + (size_t)(W + 1) * W + NF * VB + NF * 64 + 2);   // [LS_MAXF + 1] row prefix
+    const int dump_i = (W + 1) * W + wv * 64 + lane;
+    const int zero_i = (W + 1) * W + NF * 64;
+    int* qrow = reinterpret_cast<int*>(smem + (size_t)(W + 1) * W + NF * 64 + 2);   // [LS_MAXF + 1] row prefix
     int* blkfirst = qrow + LS_MAXF + 2;                        // [LS_MAXB + 1]
     int* s_nblk = blkfirst + LS_MAXB + 2;
     int* rowbase = s_nblk + 2 + wv * RB;                       // per wave: [RB] block offset of the row (scalars, < 2^31)

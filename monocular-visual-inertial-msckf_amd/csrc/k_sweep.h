@@ -9,9 +9,11 @@
 //
 //   * a "fold" eliminates one source triangle (w rows, columns [off, off+w))
 //     against R with one Householder reflector per column, rows held in the
-//     REGISTERS of one wavefront (64 x 64 tile: lane (rq, cq) = (lane & 3, lane >> 2)
+//     REGISTERS of one wavefront (64 x 64 tile: lane (rq, cq) = (lane >> 4, lane & 15)
 //     owns rows {rq + 4 rr} and local columns {cq + 16 k}; the rhs sits at local
-//     column 63), so the dots reduce over a DPP quad only;
+//     column 63).  The column step itself is sweep_step.h's: the pivot column reaches
+//     the tile's other lanes through the DPP row broadcast of the FMAs, nothing of the
+//     tile goes through LDS;
 //   * step i of a fold touches R row off+i and nothing else of R, so fold g+1
 //     may run its step for column c one macro step after fold g ran its own:
 //     NW wavefronts work on NW different folds at NW different columns, one
@@ -19,22 +21,17 @@
 //     folding the triangles one after the other.
 //   * row r of a triangle comes alive at local column r and the columns left of
 //     the pivot are retired: with the step index cut into chunks of 8 (KK = i / 8)
-//     the live row slots (rr <= 2 KK + 1) and column slots (k >= KK / 2) are
-//     compile-time loop bounds; each wavefront runs its own straight-line
-//     sequence  [idle barriers] [chunk 0 .. chunk 7] [idle barriers] ...  and all
-//     wavefronts execute the same number of barriers (nsteps).
-//   * inside a step a lane forms one partial dot per live column slot (one running sum each: the step time
-//     follows the FP64 instruction count, not the FMA chain); the quad's partials are reduce-scattered so
-//     that row lane rq holds the dot of slot rq, i.e. every lane looks after ONE column of the pivot row:
-//     it reads that R entry, forms tau, writes the entry back, and tau is broadcast over the quad for the
-//     rank-1 update.  The pivot column's own dot is v^T v: its squared norm costs no extra reduction.
-//     (Round 3 measured the alternative -- the norm of the next pivot column taken right behind its update so that the
-//     reflector scalars run woven into the dots instead of behind them, every chain stage pinned between independent
-//     FMAs: +15 instructions per step, 94.6 -> 105 us per launch.  The step is bound by the NUMBER of instructions a
-//     wavefront issues (~9.5 cycles per FP64 instruction even with independent operands), not by its dependent chains.)
+//     the live row slots (rr <= 2 KK + 1) and column slots (k >= i / 16) are
+//     compile-time loop bounds -- and so is the broadcast lane i % 16: one instance
+//     of the step per column.  Each wavefront runs its own straight-line sequence
+//     [idle barriers] [chunk 0 .. chunk 7] [idle barriers] ...  and all wavefronts
+//     execute the same number of barriers (nsteps).
 //   * the rows of the source triangle are fetched two row slots per chunk, one
 //     chunk ahead of their first use; the first two row slots of the NEXT fold are
 //     fetched during the last chunks of the current one.
+//   (Round 3 history: the step was measured to follow the number of instructions a wavefront issues, not its
+//    dependent chains -- weaving the reflector scalars into the dots, +15 instructions, cost 94.6 -> 105 us per
+//    launch; halving the FMAs saved 3.5 %; taking the LDS trip of the pivot column out, -30 instructions, 95.5 -> 74 us.)
 //
 // The host (build_plan_band) orders the folds by first column and assigns
 //   t0[0] = 0 (adopted: its rows are copied into R),  t0[1] = 1,
@@ -77,13 +74,12 @@ struct SweepArgs {
 constexpr int SWEEP_MAX_W = 60;        // widest source / envelope (local column 63 holds the rhs)
 constexpr int SWEEP_RS = 64;           // doubles per R row in LDS: entry (c, col) at [c][col - c], rhs at [c][63]
 constexpr double SWEEP_TINY = 1e-290;  // |column|^2 under this is treated as an exact zero column
-constexpr int SWEEP_VB = 72;           // (LDS words per fold slot once used for the published column; kept: the dump / zero words sit behind)
 }  // namespace msckf
 #include "sweep_step.h"
 namespace msckf {
 
 __host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nf, int wpf) {
-    return ((size_t)wtot * SWEEP_RS + (size_t)nf * SWEEP_VB + (size_t)nf * wpf * 64 + 2 + (size_t)nf) * 8;   // R | published columns | dumps | zero | progress
+    return ((size_t)wtot * SWEEP_RS + (size_t)nf * wpf * 64 + 2) * 8;   // R | dump words | zero words
 }
 
 // Sum over the 4 lanes of a DPP quad; every lane of the quad gets the sum.
@@ -176,7 +172,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     if (p.stamps) tk0 = wall_clock64();
 
     for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
-    if (t < 2) smem[nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64 + t] = 0.0;
+    if (t < 2) smem[nd.wtot * SWEEP_RS + NW * 64 + t] = 0.0;
     // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
     const SweepFold f0 = p.folds[nd.fold_begin];
     const int adopt = (nd.fold_end > nd.fold_begin && f0.t0 == 0) ? 1 : 0;
@@ -240,8 +236,8 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     // read / written; they advance by SWEEP_RS - 1 per step (next row, one column less to the left), the rhs by
     // SWEEP_RS.  Columns outside the tile read a zero word and write a dump word.
     int ra = 0, wa = 0, rstep = 0;
-    const int dump_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + wv * 64 + lane;
-    const int zero_i = nd.wtot * SWEEP_RS + NF * SWEEP_VB + NW * 64;
+    const int dump_i = nd.wtot * SWEEP_RS + wv * 64 + lane;
+    const int zero_i = nd.wtot * SWEEP_RS + NW * 64;
     const int lco = cq + CL * rq;
     const bool isr_lane = (rq == CS - 1) && (cq == CL - 1);
     auto init_addr = [&]() {

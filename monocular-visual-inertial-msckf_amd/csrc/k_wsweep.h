@@ -35,19 +35,18 @@ template <int CS> struct WSweepGeom {
     static constexpr int MAX_W = W - 6;        // widest source / envelope
     static constexpr int RSL = 4 * CS;         // row slots of a lane
     static constexpr int NCH = 2 * CS;         // chunks of 8 columns
-    static constexpr int VB = 16 * CS + 8;     // published column: [rq][RSL] rows (+ pad)
 };
 
 template <int CS>
 __host__ __device__ inline size_t wsweep_lds_bytes(int rc, int nf, int nsteps) {
-    // pad | ring | published columns | dump words | zero words | flush table (ints)
-    return ((size_t)(rc + 1) * WSweepGeom<CS>::W + (size_t)nf * WSweepGeom<CS>::VB + (size_t)nf * 64 + 2) * 8 + ((size_t)nsteps + 2) * 4;
+    // pad | ring | dump words | zero words | flush table (ints)
+    return ((size_t)(rc + 1) * WSweepGeom<CS>::W + (size_t)nf * 64 + 2) * 8 + ((size_t)nsteps + 2) * 4;
 }
 
 template <int NF, int CS>
 __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
     using G = WSweepGeom<CS>;
-    constexpr int W = G::W, RSL = G::RSL, VB = G::VB;
+    constexpr int W = G::W, RSL = G::RSL;
     constexpr int CL = 16;
     constexpr bool HAS2 = CS > 4;          // lanes rq < 2 look after a second column slot (4 + rq)
     static_assert(CS >= 4 && CS <= 6, "column slots 4..6");
@@ -64,9 +63,9 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
     //  offset below zero; with the pivot in ring row 0 that address must still be inside the allocation)
     double* Rb = smem + W;                                    // [RC][W]
     constexpr int RB0 = W;                                    // index of the ring in smem
-    const int dump_i = (RC + 1) * W + NF * VB + wv * 64 + lane;
-    const int zero_i = (RC + 1) * W + NF * VB + NF * 64;
-    int* ftab = reinterpret_cast<int*>(smem + (size_t)(RC + 1) * W + NF * VB + NF * 64 + 2);
+    const int dump_i = (RC + 1) * W + wv * 64 + lane;
+    const int zero_i = (RC + 1) * W + NF * 64;
+    int* ftab = reinterpret_cast<int*>(smem + (size_t)(RC + 1) * W + NF * 64 + 2);
     const int nsteps = __builtin_amdgcn_readfirstlane(nd.nsteps);
     const int fold_end = __builtin_amdgcn_readfirstlane(nd.fold_end);
     const int wtot = __builtin_amdgcn_readfirstlane(nd.wtot);

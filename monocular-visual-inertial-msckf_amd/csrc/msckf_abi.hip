@@ -619,7 +619,8 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         const bool wide_leaf = 6 * max_span + 1 > 64;
         const int rb = wide_leaf ? LSweepGeom<6, LS_RS6>::RB : LSweepGeom<4, LS_RS4>::RB;
         const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
-        c->leaf_nf = (F >= LS_BIG_BATCH) ? 12 : 8;
+        static const int big_batch = [] { const char* e = std::getenv("MSCKF_LS_BIG_BATCH"); return e ? atoi(e) : LS_BIG_BATCH; }();
+        c->leaf_nf = (F >= big_batch) ? 12 : 8;
         const int unit = c->leaf_nf * fpb;
         static const int leaf_target = [] { const char* e = std::getenv("MSCKF_LEAF_TARGET"); return e ? std::max(1, atoi(e)) : 240; }();
         int want = (F + leaf_target - 1) / leaf_target;
@@ -966,6 +967,7 @@ int launch_feature(msckf_ctx* c) {
     a.rank = ptr<int>(c->dRank); a.accepted = ptr<unsigned char>(c->dAcc); a.gamma = ptr<double>(c->dGamma);
     a.select = c->use_select ? ptr<unsigned char>(c->dSelFlags) : nullptr;
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
+    a.zero_idx = c->stack_elems;
     const bool chunked = 2 * c->Mmax + 1 > 24;                 // k_feature<32> / <64>: column chunks, S in registers
     int lds_d = 0;                       // (the footprint is not monotone in the track length: whole-view chunks)
     for (int m = 1; m <= c->Mmax; ++m) lds_d = std::max(lds_d, feature_lds_doubles(m, chunked));
@@ -1588,7 +1590,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     if (rc != MSCKF_OK) return rc;
     // the tracks go first; in the one-shot call K1-K4 starts behind them while the host plans K5
     HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(static_cast<char*>(c->dStack.p) + (size_t)blk * stack_es, 0, 8 * stack_es, c->stream));   // k_lsweep's zero word
+    // (k_lsweep's zero words behind the stack are written by k_feature itself: one launch less in front of it)
     c->feature_launched = false;
     if (c->oneshot) {
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
