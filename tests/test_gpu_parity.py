@@ -59,6 +59,10 @@ def test_golden(eng, case):
     (53, 200, 6, 29, {}),                      # dc = 318: the widest two-block window (160 + 158)
     (2, 6, 2, 30, {}),                         # dc = 12: one partly filled 16 x 16 block in the Cholesky
     (3, 12, 3, 33, {}),                        # dc = 18: two blocks, the second with two columns
+    (10, 1, 5, 3, {}),                         # ONE feature: one leaf, one row block on the prefetched tile (round 3: the compiler
+    (10, 2, 5, 3, {}),                         #   put a register copy in front of a lone DPP statement of the column step --
+    (10, 6, 10, 3, {}),                        #   7.7e-6 on dx here, 1e-1 at 50 features; sweep_dpp_groups.h is the fix)
+    (40, 300, 10, 1, {}),                      # ring-buffered sweep (N > 37) behind 60-column leaves
 ])
 def test_against_oracle(eng, N, F, M, seed, kw):
     from msckf_amd import synth

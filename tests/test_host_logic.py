@@ -7,7 +7,7 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_DIR, load_golden, load_sequence, rel_err, sequence_cases
+from conftest import GOLDEN_DIR, ROOT, load_golden, load_sequence, rel_err, sequence_cases
 
 
 def make_reference_shaped(prob, ref):
@@ -325,3 +325,33 @@ def test_unique_id_file_carries_the_launch_tag(tmp_path):
     assert exchange_unique_id(e1, 1, 2, path) == uid == bytes(range(128))
     RcclShardedUpdate(e0, 0, 2, uid, id_path=path)
     assert not os.path.exists(path)
+
+
+def test_generated_sweep_groups_header_is_current():
+    """csrc/sweep_dpp_groups.h is generated (tools/gen_sweep_dpp_groups.py): the committed file is what the generator
+    writes, every statement stays within the 30 operands inline assembly allows, opens with the one s_nop 1 that covers
+    the VALU-write -> DPP-read hazard, and rewrites the broadcast register last in its row."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_sweep_dpp_groups", os.path.join(ROOT, "tools", "gen_sweep_dpp_groups.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = gen.render()
+    with open(gen.PATH) as f:
+        assert f.read() == text
+    stmts = re.findall(r'asm volatile\("(.*?)"\s*\n\s*: (.*?)\n\s*: (.*?)\);', text, flags=re.S)
+    assert len(stmts) == sum(gen.gmax_dots(ns) + gen.gmax_update(ns) for ns in range(1, 7))
+    for body, outs, ins in stmts:
+        n_ops = 2 * outs.count('"+v"') + ins.count('"v"') + ins.count('"i"')
+        assert n_ops <= 30
+        lines = body.split("\\n\\t")
+        assert lines[0] == "s_nop 1" and all(l.startswith("v_fmac_f64_dpp ") for l in lines[1:])
+    for ns in range(1, 7):
+        for g in range(1, gen.gmax_update(ns) + 1):
+            body = re.search(r'struct DppUpdate<%d, %d> \{.*?asm volatile\("(.*?)"' % (ns, g), text, flags=re.S).group(1)
+            lines = body.split("\\n\\t")[1:]
+            for r in range(g):
+                row = lines[r * ns:(r + 1) * ns]
+                bc = "%%%d" % (r * ns)                                   # the row's broadcast register (slot K0)
+                assert all(l.split()[2].rstrip(",") == bc for l in row)  # every FMA of the row reads it through DPP
+                assert [l.split()[1].rstrip(",") == bc for l in row] == [False] * (ns - 1) + [True]   # and only the last writes it
