@@ -68,7 +68,7 @@ __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
     const int head = (M + 2) / 2 + R2 * 6 + R2 * 3 + 3 * C6;
     if (!chunked) {
         const int stage = R2 * (C6 + 1), elim = (R2 + 1) * (R2 + 3);        // E | the elimination's tile (reuses E)
-        return head + (stage > elim ? stage : elim) + 8;
+        return head + (stage > elim ? stage : elim) + 3 * R2 + 8;               // + E Z^T (behind E: the elimination's tile replaces E while it is read)
     }
     return head + R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2) + 8;
 }
@@ -323,36 +323,67 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     }
     __syncthreads();
     if (p.stamps) tq[4] = wall_clock64();
-    // pass 2, lanes over rows: S[L][L'] = E[L,:] . H_o[L',:] straight into the lane's REGISTER row (no copy of S in LDS);
-    // column R2 is the rhs r_o, lane R2 holds the extra row r_o^T (read from the r_o column of the staging tile)
+    // pass 2, ALL lanes (rounds 1-3 had one lane per row of S: 20 of 64 busy at 10 views, 7.1 of the block's 26 us):
+    //   (a) E Z^T, one (row, t) pair per lane;  (b) the entries S[L][j] = E[L, view of j] . D[j] - (E Z^T)[L] . V[j], j >= L
+    //   (+ sigma^2 on the diagonal; S is symmetric: rows L and R2 - 1 - L together have R2 + 1 of them, so entry idx of
+    //   the R2 / 2 row pairs is a division by R2 + 1 away) dealt round-robin, kept in registers until every lane is done
+    //   with E, then written -- mirrored -- into the elimination's tile sT (which lies over E) together with the rhs
+    //   border: column R2 = r_o, row R2 = r_o^T.
     {
-        double ez0 = 0, ez1 = 0, ez2 = 0;
-        if (lane < R2) {
-            for (int c = 0; c < C6; ++c) {
-                const double e = sE[lane * ldE + c];
-                ez0 += e * sZ[c]; ez1 += e * sZ[C6 + c]; ez2 += e * sZ[2 * C6 + c];
-            }
+        double* sEz = sE + R2 * ldE;                              // [R2][3]
+        for (int idx = lane; idx < 3 * R2; idx += 64) {
+            const int L = idx / 3, t3 = idx - 3 * L;
+            const double* er = sE + L * ldE;
+            const double* zr = sZ + t3 * C6;
+            double e0 = 0.0, e1 = 0.0;
+            int c = 0;
+            for (; c + 1 < C6; c += 2) { e0 += er[c] * zr[c]; e1 += er[c + 1] * zr[c + 1]; }
+            if (c < C6) e0 += er[c] * zr[c];
+            sEz[idx] = e0 + e1;
         }
+        __syncthreads();
+        constexpr int NRES = ((RMAX / 2) * (RMAX + 1) + 63) / 64;   // R2 <= RMAX - 2, R2 even
+        double res[NRES];
+        const int ntri = (R2 >> 1) * (R2 + 1);
+        const float inv_p = 1.0f / (float)(R2 + 1);
+        auto entry = [&](int idx, int& L, int& j) {                // idx < ntri -> (L, j), j >= L
+            const int pr = (int)(((float)idx + 0.5f) * inv_p), q = idx - pr * (R2 + 1);
+            const bool lo = q < R2 - pr;
+            L = lo ? pr : R2 - 1 - pr;
+            j = lo ? pr + q : q - 1;
+        };
 #pragma unroll
-        for (int j = 0; j < RMAX; ++j) {
+        for (int it = 0; it < NRES; ++it) {
+            const int idx = lane + 64 * it;
             double x = 0.0;
-            if (j < R2) {                                           // (uniform)
-                if (lane < R2) {
-                    const int vw = j >> 1;
-                    double sacc = 0.0;
+            if (idx < ntri) {
+                int L, j;
+                entry(idx, L, j);
+                const int vw = j >> 1;
+                double sacc = 0.0;
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) sacc += sE[lane * ldE + 6 * vw + a] * sA[j * 6 + a];
-                    sacc -= ez0 * sV[j * 3 + 0] + ez1 * sV[j * 3 + 1] + ez2 * sV[j * 3 + 2];
-                    if (j == lane) sacc += p.sigma2;
-                    x = sacc;
-                } else if (lane == R2) {
-                    x = sE[j * ldE + C6];                           // r_o of row j
-                }
-            } else if (j == R2) {
-                if (lane < R2) x = ro;
+                for (int a = 0; a < 6; ++a) sacc += sE[L * ldE + 6 * vw + a] * sA[j * 6 + a];
+                sacc -= sEz[L * 3 + 0] * sV[j * 3 + 0] + sEz[L * 3 + 1] * sV[j * 3 + 1] + sEz[L * 3 + 2] * sV[j * 3 + 2];
+                if (j == L) sacc += p.sigma2;
+                x = sacc;
             }
-            srow[j] = x;
+            res[it] = x;
         }
+        __syncthreads();                                            // every read of E is done: sT may take its place
+        double* sT = sE;
+        const int ldT = R2 + 3;
+#pragma unroll
+        for (int it = 0; it < NRES; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < ntri) {
+                int L, j;
+                entry(idx, L, j);
+                sT[L * ldT + j] = res[it];
+                sT[j * ldT + L] = res[it];
+            }
+        }
+        if (lane < R2) { sT[lane * ldT + R2] = ro; sT[R2 * ldT + lane] = ro; }
+        if (lane == R2) sT[R2 * ldT + R2] = 0.0;
     }
     if (p.stamps) tq[5] = wall_clock64();
     } else {
@@ -496,10 +527,12 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
         double* sT = sZ + 3 * C6;                       // the staging area of K4 / the gate is free now
         const int ldT = R2 + 3;
         __syncthreads();
-        if (lane <= R2) {
+        if constexpr (CHUNKED) {                       // (the all-columns form wrote S there itself)
+            if (lane <= R2) {
 #pragma unroll
-            for (int j = 0; j < RMAX; ++j)
-                if (j <= R2) sT[lane * ldT + j] = srow[j];
+                for (int j = 0; j < RMAX; ++j)
+                    if (j <= R2) sT[lane * ldT + j] = srow[j];
+            }
         }
         __syncthreads();
         const int g = lane >> 4, l15 = lane & 15;
