@@ -257,7 +257,11 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         int lcl = lco;
         asm volatile("" : "+v"(lcl));                     // (or the 60 lane masks lco > I are hoisted out of the fold loop and spilled)
         const bool on = (lcl > I) || isr_lane;            // left of / at the pivot: retired (the rhs never is)
+#ifdef SWEEP_PROF
+        sweep_column_step<CS, 16, RMAX + 1, K0, L>(a, smem, rrow, ra, wa, on, 0, 0, false, dump_i, lane, prof, &tprev);
+#else
         sweep_column_step<CS, 16, RMAX + 1, K0, L>(a, smem, rrow, ra, wa, on, 0, 0, false, dump_i, lane);
+#endif
         ra += rstep; wa += rstep;
     };
 

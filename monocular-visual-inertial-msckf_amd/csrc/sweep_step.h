@@ -38,9 +38,17 @@ __device__ __forceinline__ void swap_rows16(double& x, double& y) {
 // slot rq (slot 4 + (rq & 1)) is read / written -- a zero word / the lane's dump word where it has none; on1 / on2:
 // the entry is right of the pivot (or the rhs).  Rows 2, 3 mirror rows 0, 1 for the second entry (same reads, same
 // tau; their wa2 is the dump word).
+// (-DSWEEP_PROF: prof[1..4] collect the ticks of the dots, the reduction, the scalars + tau + R writes, the tau hand-back;
+//  tools/sweep_prof.py prints them)
+#ifdef SWEEP_PROF
+#define SWEEP_STEP_TICK(slot) do { if (prof) { __builtin_amdgcn_sched_barrier(0); const long long tn_ = __builtin_readcyclecounter(); prof[slot] += tn_ - *tprev; *tprev = tn_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define SWEEP_STEP_TICK(slot) do { } while (0)
+#endif
 template <int CS, int RS, int NR, int K0, int L>
 __device__ __forceinline__ void sweep_column_step(double (&a)[RS][CS], double* smem, int rrow, int ra1, int wa1, bool on1,
-                                                  int ra2, int wa2, bool on2, int dump_i, int lane) {
+                                                  int ra2, int wa2, bool on2, int dump_i, int lane,
+                                                  long long* prof = nullptr, long long* tprev = nullptr) {
     static_assert(CS == 4 || CS == 6, "60- or 90-column tiles");
     static_assert(K0 < CS && NR <= RS && L < 16, "pivot inside the tile");
     constexpr bool HAS2 = CS > 4;
@@ -61,6 +69,7 @@ __device__ __forceinline__ void sweep_column_step(double (&a)[RS][CS], double* s
         for (int rr = 0; rr + G <= NR; rr += G) DppDots<NS, G>::template dots<L, K0>(sp, a, rr);
         if constexpr (NR % G != 0) DppDots<NS, NR % G>::template dots<L, K0>(sp, a, NR - NR % G);
     }
+    SWEEP_STEP_TICK(1);
     // ---- reduce-scatter over the four row lanes ---------------------------------------------------------
     double tot1 = 0.0, tot2 = 0.0;
     if constexpr (K0 <= 1) {
@@ -85,6 +94,7 @@ __device__ __forceinline__ void sweep_column_step(double (&a)[RS][CS], double* s
     // |pivot column|^2 = its dot with itself, on the lane that looks after it
     const double sg = HAS1 ? readlane_d(tot1, 16 * K0 + L) : readlane_d(tot2, 16 * (K0 - 4) + L);
     const bool live = sg > SWEEP_TINY;                    // wave-uniform; below: nothing to eliminate
+    SWEEP_STEP_TICK(2);
     // ---- reflector scalars (every lane, uniform values) ---------------------------
     // sg > 1e-290 keeps ss = x0^2 + sg a normal number whose rsqrt / rcp seeds + one Newton step are good to a few
     // 1e-16 (the reflector stays orthogonal to that level).  A dead column (nothing to eliminate: the identity) may
@@ -110,6 +120,7 @@ __device__ __forceinline__ void sweep_column_step(double (&a)[RS][CS], double* s
         smem[act ? wa2 : dump_i] = fma(-tau2, v0, rck2);
     }
     if (lane == 0 && live) smem[rrow] = x0 - v0;
+    SWEEP_STEP_TICK(3);
     // tau of slot k on every row, by the lane swaps
     double nt[CS];
     if constexpr (K0 <= 1) {
@@ -130,6 +141,7 @@ __device__ __forceinline__ void sweep_column_step(double (&a)[RS][CS], double* s
         nt[4] = tau2; nt[5] = tau2;                       // [t4 t5 t4 t5] by rows -> [t4 x4], [t5 x4]
         swap_rows16(nt[4], nt[5]);
     }
+    SWEEP_STEP_TICK(6);
     // a[rr][k] -= (pivot column, row slot rr) * tau_k  (slot K0 last in its row: it rewrites the register the other
     // slots read through the broadcast; the owner's own column has tau = 0 and stays as it is -- it is retired)
 #pragma unroll

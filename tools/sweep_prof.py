@@ -18,7 +18,7 @@ eng.sync()
 buf = (C.c_longlong * 64)()
 eng._lib.msckf_debug_fold_stamps(eng._h, buf, -1000000)
 a = np.frombuffer(buf, dtype=np.int64).reshape(8, 8)
-names = ["idle", "-", "dots", "scalars+tau", "update", "barrier", "reduce"]
+names = ["idle", "dots", "reduce", "scalars+tau+R", "update", "barrier", "tau hand-back"]
 print("per-wave cycles per active step (root sweep); idle = waiting for the fold's first step / the other wavefronts' last ones")
 for w in range(8):
     steps = max(1, int(a[w, 7]))
