@@ -19,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "wave_ops.h"
+#include "feature_dpp_groups.h"
 
 namespace msckf {
 
@@ -253,20 +254,53 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     // (tracks of up to 11 views: all 6M columns at once, S staged in LDS -- the faster form while it fits)
     const int ldE = C6 + 1;
     double* sE = sZ + 3 * C6;              // [R2][ldE] H_o | r_o (K4 staging), then H_o * P_sub (the r_o column stays)
+    // Z, the D rows and V once more in REGISTERS, 16 entries per register and every 16-lane row holding the same 16: the
+    // lane-invariant factor of an FMA then comes by the DPP row broadcast (feature_dpp_groups.h) instead of one LDS
+    // broadcast read per FMA -- ~460 of the ~700 LDS instructions of a 10-view block were such reads.
+    double zq[3][FEAT_ZR], aq[FEAT_AR], vq[FEAT_VR];
+    {
+        const int l15 = lane & 15;
+#pragma unroll
+        for (int i = 0; i < FEAT_ZR; ++i) {
+            const int cz = min(16 * i + l15, C6 - 1);
+            zq[0][i] = sZ[cz]; zq[1][i] = sZ[C6 + cz]; zq[2][i] = sZ[2 * C6 + cz];
+        }
+#pragma unroll
+        for (int i = 0; i < FEAT_AR; ++i) aq[i] = sA[min(16 * i + l15, R2 * 6 - 1)];
+#pragma unroll
+        for (int i = 0; i < FEAT_VR; ++i) vq[i] = sV[min(16 * i + l15, R2 * 3 - 1)];
+    }
+    // x[i] -= V[L0 + i] . (w0, w1, w2) for the rows of one group
+    auto corr = [&](auto tagl, double (&x)[4], double w0, double w1, double w2) {
+        FeatCorrRows<decltype(tagl)::value>::run(x, w0, w1, w2, vq);
+    };
     // ---------------- K4: write the compact block [H_o | r_o] ----------------
     // The rows are staged in sE (free until the gate's first pass) and leave as ONE contiguous range: the q
     // projected rows, row-major with 6M + 1 columns, every lane storing consecutive scalars.
     // Lanes over COLUMNS (60 of 64 busy at 10 views; round 2 had one lane per row, 20 busy): lane c holds Z[:, c] and
     // walks the rows, H_o[L][c] = D[L][c] - V[L,:] Z[:, c] with D[L][c] != 0 only for the two rows of c's own view.
     {
-        for (int c = lane; c < C6; c += 64) {
+        // (ALL lanes run the groups -- a DPP broadcast reads garbage from a source lane that EXEC has switched off --,
+        //  lanes past the last column work on a copy of it and do not store)
+        for (int cb = 0; cb < C6; cb += 64) {
+            const bool cok = cb + lane < C6;
+            const int c = min(cb + lane, C6 - 1);
             const double z0 = sZ[c], z1 = sZ[C6 + c], z2 = sZ[2 * C6 + c];
             const int vwc = c / 6, ac = c - 6 * vwc;
-            for (int L = 0; L < R2; ++L) {
-                double x = -(sV[L * 3 + 0] * z0 + sV[L * 3 + 1] * z1 + sV[L * 3 + 2] * z2);
-                if ((L >> 1) == vwc) x += sA[L * 6 + ac];
-                sE[L * ldE + c] = x;
-            }
+            const double d0 = sA[(2 * vwc) * 6 + ac], d1 = sA[(2 * vwc + 1) * 6 + ac];   // the two rows of c's own view
+            auto rows = [&](auto tagl) {
+                constexpr int L0 = decltype(tagl)::value;
+                if (L0 < R2) {
+                    double x[4] = {0.0, 0.0, 0.0, 0.0};
+                    corr(tagl, x, z0, z1, z2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int L = L0 + i;
+                        if (L < R2 && cok) sE[L * ldE + c] = x[i] + ((L == 2 * vwc) ? d0 : (L == 2 * vwc + 1) ? d1 : 0.0);
+                    }
+                }
+            };
+            rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
         }
         if (lane < R2) sE[lane * ldE + C6] = ro;
         __syncthreads();
@@ -285,7 +319,9 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     if (p.stamps) tq[3] = wall_clock64();
     // ---------------- K3: gate ------------------------------------------------
     // pass 1, lanes over columns c of P_sub: E = D P_sub (block rows) and ZP = Z P_sub
-    for (int c = lane; c < C6; c += 64) {
+    for (int cb = 0; cb < C6; cb += 64) {
+        const bool cok = cb + lane < C6;                     // (all lanes stay in: see K4)
+        const int c = min(cb + lane, C6 - 1);
         const int colg = 15 + 6 * sSlot[c / 6] + (c % 6);
         double zp0 = 0, zp1 = 0, zp2 = 0;
         double pv[6], pn[6];
@@ -294,32 +330,38 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
 #pragma unroll
             for (int a = 0; a < 6; ++a) pv[a] = prow[(size_t)a * p.ldp];
         }
-        for (int vw = 0; vw < M; ++vw) {
-            // prefetch the next 6 rows of this P_sub column while the current ones are consumed
-            if (vw + 1 < M) {
-                const double* prow = p.P + (size_t)(15 + 6 * sSlot[vw + 1]) * p.ldp + colg;
+        auto view = [&](auto tagv) {
+            constexpr int VW = decltype(tagv)::value;
+            if (VW < M) {                                            // (uniform)
+                // prefetch the next 6 rows of this P_sub column while the current ones are consumed
+                if (VW + 1 < M) {
+                    const double* prow = p.P + (size_t)(15 + 6 * sSlot[VW + 1]) * p.ldp + colg;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) pn[a] = prow[(size_t)a * p.ldp];
+                    for (int a = 0; a < 6; ++a) pn[a] = prow[(size_t)a * p.ldp];
+                }
+                double e0 = 0.0, e1 = 0.0;
+                FeatGateView<VW>::run(zp0, zp1, zp2, e0, e1, pv, zq, aq);
+                if (cok) { sE[(2 * VW) * ldE + c] = e0; sE[(2 * VW + 1) * ldE + c] = e1; }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pv[a] = pn[a];
             }
-            double e0 = 0, e1 = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                const int cc = 6 * vw + a;
-                zp0 += sZ[cc] * pv[a];
-                zp1 += sZ[C6 + cc] * pv[a];
-                zp2 += sZ[2 * C6 + cc] * pv[a];
-                e0 += sA[(2 * vw) * 6 + a] * pv[a];
-                e1 += sA[(2 * vw + 1) * 6 + a] * pv[a];
-            }
-            sE[(2 * vw) * ldE + c] = e0;
-            sE[(2 * vw + 1) * ldE + c] = e1;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) pv[a] = pn[a];
-        }
+        };
+        view(FTag<0>{}); view(FTag<1>{}); view(FTag<2>{}); view(FTag<3>{}); view(FTag<4>{}); view(FTag<5>{});
+        view(FTag<6>{}); view(FTag<7>{}); view(FTag<8>{}); view(FTag<9>{}); view(FTag<10>{});
         // E -= V ZP  (same column, all rows)
-        for (int L = 0; L < R2; ++L) {
-            sE[L * ldE + c] -= sV[L * 3 + 0] * zp0 + sV[L * 3 + 1] * zp1 + sV[L * 3 + 2] * zp2;
-        }
+        auto rows = [&](auto tagl) {
+            constexpr int L0 = decltype(tagl)::value;
+            if (L0 < R2) {
+                double x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = sE[min(L0 + i, R2 - 1) * ldE + c];
+                corr(tagl, x, zp0, zp1, zp2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (L0 + i < R2 && cok) sE[(L0 + i) * ldE + c] = x[i];
+            }
+        };
+        rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
     }
     __syncthreads();
     if (p.stamps) tq[4] = wall_clock64();

@@ -7,7 +7,9 @@
 // operand of v_fmac_f64 itself: the dots and the rank-1 update read it straight from its owner's registers and
 // nothing of the tile goes through LDS (rounds 1-2 published the column in LDS and read it back: two LDS trips and
 // NR / 2 wide reads on every step's dependent chain; headline k_sweep 95.5 -> 74.7 us per launch).  The broadcast
-// lane is an immediate, hence one instantiation per column of the tile.
+// lane is an immediate, hence one instantiation per column of the tile.  (A DPP broadcast reads garbage from a source lane
+// that EXEC has switched off: the step runs with all 64 lanes active -- k_feature.h, which borrowed the trick, learnt it
+// the hard way.)
 //
 // The four row lanes' partial dots are reduce-scattered with the gfx950 lane swaps: row r ends up with the dot of
 // column slot r (and, CS = 6, rows r and r + 2 with that of slot 4 + r, r < 2), i.e. every lane looks after ONE or

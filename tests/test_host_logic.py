@@ -355,3 +355,44 @@ def test_generated_sweep_groups_header_is_current():
                 bc = "%%%d" % (r * ns)                                   # the row's broadcast register (slot K0)
                 assert all(l.split()[2].rstrip(",") == bc for l in row)  # every FMA of the row reads it through DPP
                 assert [l.split()[1].rstrip(",") == bc for l in row] == [False] * (ns - 1) + [True]   # and only the last writes it
+
+
+def test_generated_feature_groups_header_is_current():
+    """csrc/feature_dpp_groups.h (tools/gen_feature_dpp_groups.py): committed file == generator output, <= 30 operands per
+    statement, one s_nop 1 in front, and the broadcast (register, lane) of every FMA addresses the table entry it stands for."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_feature_dpp_groups", os.path.join(ROOT, "tools", "gen_feature_dpp_groups.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text = gen.render()
+    with open(gen.PATH) as f:
+        assert f.read() == text
+    blocks = re.findall(r'struct (FeatGateView|FeatCorrRows)<(\d+)> \{.*?asm volatile\("(.*?)"\s*\n\s*: (.*?)\n\s*: (.*?)\);', text, flags=re.S)
+    assert len(blocks) == gen.MAXV + 6
+    for kind, num, body, outs, ins in blocks:
+        num = int(num)
+        in_list = [x.strip() for x in ins.split('", ')]
+        in_list = re.findall(r'"v"\((.*?)\)(?:,|$)', ins)
+        n_out = outs.count('"+v"')
+        assert 2 * n_out + len(in_list) <= 30
+        lines = body.split("\\n\\t")
+        assert lines[0] == "s_nop 1"
+        k = 0
+        for l in lines[1:]:
+            m = re.match(r"v_fmac_f64_dpp %(\d+), %(\d+), (-?)%(\d+) row_newbcast:(\d+) ", l)
+            acc, src, neg, oth, lane = int(m.group(1)), int(m.group(2)), m.group(3), int(m.group(4)), int(m.group(5))
+            name = in_list[src - n_out]
+            reg = int(re.findall(r"\[(\d+)\]", name)[-1])
+            entry = 16 * reg + lane
+            if kind == "FeatGateView":
+                a, which = divmod(k, 5)
+                if which < 3:
+                    assert name.startswith("zq[%d]" % which) and entry == 6 * num + a and acc == which
+                else:
+                    assert name.startswith("aq[") and entry == (2 * num + which - 3) * 6 + a and acc == which
+                assert in_list[oth - n_out] == "pv[%d]" % a and neg == ""
+                k += 1
+            else:
+                i, t = acc, oth - n_out
+                assert name.startswith("vq[") and entry == (num + i) * 3 + t and neg == "-" and in_list[oth - n_out] == "w%d" % t
