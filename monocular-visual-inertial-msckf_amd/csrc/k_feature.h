@@ -74,6 +74,11 @@ __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
     return head + R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2) + 8;
 }
 
+// The workgroup IS one wavefront (64 threads): its LDS instructions execute in program order, so a phase boundary needs no
+// s_barrier and, above all, no s_waitcnt vmcnt(0) -- __syncthreads() drained the P_sub reads the gate has in flight across
+// K4.  What is left is keeping the compiler from moving LDS accesses across the boundary.
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
+
 template <int V> struct FTag { static constexpr int value = V; };
 // RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
 template <int RMAX>
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
             sV[lane * 3 + 0] = vv0; sV[lane * 3 + 1] = vv1; sV[lane * 3 + 2] = vv2;
         }
     }
-    __syncthreads();
+    wave_sync();
 
     if (p.stamps) tq[2] = wall_clock64();
     const int q = R2 - rank;
@@ -274,6 +279,22 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     auto corr = [&](auto tagl, double (&x)[4], double w0, double w1, double w2) {
         FeatCorrRows<decltype(tagl)::value>::run(x, w0, w1, w2, vq);
     };
+    // The gate's first pass walks column c of P_sub (L2 reads, ~0.6 us each way); its first PD views are requested HERE,
+    // ahead of K4, and the later ones PD views ahead of their use (a view's 30 FMAs last ~0.1 us; with one view of
+    // lookahead the pass was ten load latencies long).
+    constexpr int PD = 4;
+    double pb[PD + 1][6];
+    int colg = 15 + 6 * sSlot[min(lane, C6 - 1) / 6] + (min(lane, C6 - 1) % 6);
+    auto fetch = [&](auto tagv) {
+        constexpr int VW = decltype(tagv)::value;
+        if (VW < M) {                                                // (uniform)
+            const double* prow = p.P + (size_t)(15 + 6 * sSlot[VW]) * p.ldp + colg;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) pb[VW % (PD + 1)][a] = prow[(size_t)a * p.ldp];
+        }
+    };
+    fetch(FTag<0>{}); fetch(FTag<1>{}); fetch(FTag<2>{}); fetch(FTag<3>{});
+    static_assert(PD == 4, "the prologue above issues PD views");
     // ---------------- K4: write the compact block [H_o | r_o] ----------------
     // The rows are staged in sE (free until the gate's first pass) and leave as ONE contiguous range: the q
     // projected rows, row-major with 6M + 1 columns, every lane storing consecutive scalars.
@@ -303,7 +324,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
             rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
         }
         if (lane < R2) sE[lane * ldE + C6] = ro;
-        __syncthreads();
+        wave_sync();
         const int nel = q * ldE;
         const double* srcrows = sE + rank * ldE;
         if (p.stack_f32) {
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
             double* blk = static_cast<double*>(p.stack) + p.blk_off[f];
             for (int e = lane; e < nel; e += 64) blk[e] = srcrows[e];
         }
-        __syncthreads();                       // sE is rewritten by the gate below
+        wave_sync();                       // sE is rewritten by the gate below
     }
 
     if (p.stamps) tq[3] = wall_clock64();
@@ -322,28 +343,18 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     for (int cb = 0; cb < C6; cb += 64) {
         const bool cok = cb + lane < C6;                     // (all lanes stay in: see K4)
         const int c = min(cb + lane, C6 - 1);
-        const int colg = 15 + 6 * sSlot[c / 6] + (c % 6);
         double zp0 = 0, zp1 = 0, zp2 = 0;
-        double pv[6], pn[6];
-        {
-            const double* prow = p.P + (size_t)(15 + 6 * sSlot[0]) * p.ldp + colg;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) pv[a] = prow[(size_t)a * p.ldp];
+        if (cb > 0) {                                                // (tracks of 11 views: two more columns)
+            colg = 15 + 6 * sSlot[c / 6] + (c % 6);
+            fetch(FTag<0>{}); fetch(FTag<1>{}); fetch(FTag<2>{}); fetch(FTag<3>{});
         }
         auto view = [&](auto tagv) {
             constexpr int VW = decltype(tagv)::value;
             if (VW < M) {                                            // (uniform)
-                // prefetch the next 6 rows of this P_sub column while the current ones are consumed
-                if (VW + 1 < M) {
-                    const double* prow = p.P + (size_t)(15 + 6 * sSlot[VW + 1]) * p.ldp + colg;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) pn[a] = prow[(size_t)a * p.ldp];
-                }
+                fetch(FTag<VW + PD>{});
                 double e0 = 0.0, e1 = 0.0;
-                FeatGateView<VW>::run(zp0, zp1, zp2, e0, e1, pv, zq, aq);
+                FeatGateView<VW>::run(zp0, zp1, zp2, e0, e1, pb[VW % (PD + 1)], zq, aq);
                 if (cok) { sE[(2 * VW) * ldE + c] = e0; sE[(2 * VW + 1) * ldE + c] = e1; }
-#pragma unroll
-                for (int a = 0; a < 6; ++a) pv[a] = pn[a];
             }
         };
         view(FTag<0>{}); view(FTag<1>{}); view(FTag<2>{}); view(FTag<3>{}); view(FTag<4>{}); view(FTag<5>{});
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
         };
         rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
     }
-    __syncthreads();
+    wave_sync();
     if (p.stamps) tq[4] = wall_clock64();
     // pass 2, ALL lanes (rounds 1-3 had one lane per row of S: 20 of 64 busy at 10 views, 7.1 of the block's 26 us):
     //   (a) E Z^T, one (row, t) pair per lane;  (b) the entries S[L][j] = E[L, view of j] . D[j] - (E Z^T)[L] . V[j], j >= L
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
             if (c < C6) e0 += er[c] * zr[c];
             sEz[idx] = e0 + e1;
         }
-        __syncthreads();
+        wave_sync();
         constexpr int NRES = ((RMAX / 2) * (RMAX + 1) + 63) / 64;   // R2 <= RMAX - 2, R2 even
         double res[NRES];
         const int ntri = (R2 >> 1) * (R2 + 1);
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
             }
             res[it] = x;
         }
-        __syncthreads();                                            // every read of E is done: sT may take its place
+        wave_sync();                                            // every read of E is done: sT may take its place
         double* sT = sE;
         const int ldT = R2 + 3;
 #pragma unroll
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
             }
             if (last) erow[cw] = ro;
         }
-        __syncthreads();
+        wave_sync();
         {
             const int nel = q * cwp;
             const float inv_cwp = 1.0f / (float)cwp;
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
                 else static_cast<double*>(p.stack)[dst] = x;
             }
         }
-        __syncthreads();                                 // sE is rewritten by the gate's first pass
+        wave_sync();                                 // sE is rewritten by the gate's first pass
         // ---- K3 pass 1, lanes over the chunk's columns c of P_sub: E = D P_sub (block rows) - V (Z P_sub) ----
         if (lane < cw) {
             const int c = c0 + lane;
@@ -515,7 +526,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
                 sE[L * ldE + lane] -= sV[L * 3 + 0] * zp0 + sV[L * 3 + 1] * zp1 + sV[L * 3 + 2] * zp2;
             }
         }
-        __syncthreads();
+        wave_sync();
         // ---- K3 pass 2, lanes over rows L: this chunk's part of S[L][L2] = E[L,:] H_o[L2,:]^T ----
         if (lane < R2) {
             const double* erow = sE + lane * ldE;
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
                 }
             }
         }
-        __syncthreads();                                 // the next chunk restages sE
+        wave_sync();                                 // the next chunk restages sE
     }
     if (p.stamps) tq[3] = tq[4] = tq[5] = wall_clock64();
     // S row of this lane: the -V Z part, sigma^2 on the diagonal, the rhs column r_o; lane R2 holds the extra row r_o^T
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
         // not masked out; rows at or above it are (their multiplier is zero).
         double* sT = sZ + 3 * C6;                       // the staging area of K4 / the gate is free now
         const int ldT = R2 + 3;
-        __syncthreads();
+        wave_sync();
         if constexpr (CHUNKED) {                       // (the all-columns form wrote S there itself)
             if (lane <= R2) {
 #pragma unroll
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
                     if (j <= R2) sT[lane * ldT + j] = srow[j];
             }
         }
-        __syncthreads();
+        wave_sync();
         const int g = lane >> 4, l15 = lane & 15;
         double ea[8], eb[8];
 #pragma unroll
