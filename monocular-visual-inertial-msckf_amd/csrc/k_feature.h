@@ -60,16 +60,15 @@ __host__ __device__ inline int feature_chunk_views(int M) {
     return (M + nch - 1) / nch;
 }
 // LDS doubles needed for a track of M views.  Two layouts (k_feature<RMAX>):
-//   all columns at once (launches whose tracks have at most 11 views): slots, D rows, V, Z, E (R2 x (6M+1)); S goes from
-//   E straight into registers, the elimination's staging tile reuses E (round 3: 17.9 -> 12.8 KB at 10 views, 12 instead
-//   of 8 wavefronts per CU);
+//   all columns at once (launches whose tracks have at most 15 views): slots, D rows, V, Z, E (R2 x (6M+1)), E Z^T; the
+//   elimination's staging tile reuses E (13.2 KB at 10 views: 12 wavefronts per CU; 27 KB at 15 views: 5);
 //   column chunks (longer tracks): slots, D rows, V, Z, one chunk of E / H_o (+ the rhs column), r_o -- S lives in registers.
 __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
     const int R2 = 2 * M, C6 = 6 * M;
     const int head = (M + 2) / 2 + R2 * 6 + R2 * 3 + 3 * C6;
     if (!chunked) {
-        const int stage = R2 * (C6 + 1), elim = (R2 + 1) * (R2 + 3);        // E | the elimination's tile (reuses E)
-        return head + (stage > elim ? stage : elim) + 3 * R2 + 8;               // + E Z^T (behind E: the elimination's tile replaces E while it is read)
+        const int stage = R2 * (6 * feature_chunk_views(M) + 1), elim = (R2 + 1) * (R2 + 3);   // one chunk of E | the elimination's tile (reuses it)
+        return head + (stage > elim ? stage : elim) + 3 * R2 + 8;               // + E Z^T (behind both)
     }
     return head + R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2) + 8;
 }
@@ -82,8 +81,13 @@ __device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
 template <int V> struct FTag { static constexpr int value = V; };
 // RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
 template <int RMAX>
-__global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs p) {      // (tracks of 12-15 views: 3 wavefronts per SIMD, the LDS footprint allows 9 per CU)
-    constexpr bool CHUNKED = RMAX > 24;
+__global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs p) {      // (<24>: <= 168 registers, the LDS footprint allows 12 wavefronts per CU; <32>: 219 registers, 8 per CU -- bounded to 168 it spills and is slower)
+    // CHUNKED: the gate works on column chunks (tracks of 16+ views, k_feature<64>).  Tracks of up to 15 views keep all 6M
+    // columns of E in LDS: 27 KB at 15 views -- five wavefronts per CU instead of the chunked form's nine, and still the
+    // faster one since the all-columns form was rebuilt in round 3 (per block at 15 views: 61 us chunked).
+    constexpr bool CHUNKED = RMAX > 32;
+    constexpr bool ONE_CHUNK = RMAX <= 24;        // k_feature<24>: tracks of up to 10 views, all 60 columns in one chunk
+    constexpr int MAXVK = ONE_CHUNK ? 10 : (RMAX - 2) / 2;   // longest track of this instance
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int f = blockIdx.x;
     const int lane = threadIdx.x;
@@ -256,58 +260,88 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
     const int q = R2 - rank;
     double srow[RMAX];
     if constexpr (!CHUNKED) {
-    // (tracks of up to 11 views: all 6M columns at once, S staged in LDS -- the faster form while it fits)
-    const int ldE = C6 + 1;
-    double* sE = sZ + 3 * C6;              // [R2][ldE] H_o | r_o (K4 staging), then H_o * P_sub (the r_o column stays)
+    // Tracks of up to 15 views (k_feature<24>: 11, <32>: 15).  K4 and the gate run over column chunks of whole views, at most
+    // 60 columns = one per lane (one chunk up to 10 views, two from 11 on): sE holds the chunk's columns of H_o (K4 staging),
+    // then of E = H_o P_sub; S never exists in LDS before the elimination's tile, which takes sE's place at the end.
+    const int CV = ONE_CHUNK ? M : feature_chunk_views(M);   // views per column chunk
+    const int ldE = 6 * CV + 1;
+    const int ldb = C6 + 1;
+    double* sE = sZ + 3 * C6;              // [R2][ldE]
     // Z, the D rows and V once more in REGISTERS, 16 entries per register and every 16-lane row holding the same 16: the
     // lane-invariant factor of an FMA then comes by the DPP row broadcast (feature_dpp_groups.h) instead of one LDS
     // broadcast read per FMA -- ~460 of the ~700 LDS instructions of a 10-view block were such reads.
     double zq[3][FEAT_ZR], aq[FEAT_AR], vq[FEAT_VR];
     {
         const int l15 = lane & 15;
+        constexpr int ZRU = (6 * MAXVK + 15) / 16, ARU = (12 * MAXVK + 15) / 16, VRU = (6 * MAXVK + 15) / 16;   // registers in use
+        static_assert(ZRU <= FEAT_ZR && ARU <= FEAT_AR && VRU <= FEAT_VR && MAXVK <= FEAT_DPP_MAXV, "tables of feature_dpp_groups.h");
 #pragma unroll
-        for (int i = 0; i < FEAT_ZR; ++i) {
+        for (int i = 0; i < ZRU; ++i) {
             const int cz = min(16 * i + l15, C6 - 1);
             zq[0][i] = sZ[cz]; zq[1][i] = sZ[C6 + cz]; zq[2][i] = sZ[2 * C6 + cz];
         }
 #pragma unroll
-        for (int i = 0; i < FEAT_AR; ++i) aq[i] = sA[min(16 * i + l15, R2 * 6 - 1)];
+        for (int i = 0; i < ARU; ++i) aq[i] = sA[min(16 * i + l15, R2 * 6 - 1)];
 #pragma unroll
-        for (int i = 0; i < FEAT_VR; ++i) vq[i] = sV[min(16 * i + l15, R2 * 3 - 1)];
+        for (int i = 0; i < VRU; ++i) vq[i] = sV[min(16 * i + l15, R2 * 3 - 1)];
     }
     // x[i] -= V[L0 + i] . (w0, w1, w2) for the rows of one group
     auto corr = [&](auto tagl, double (&x)[4], double w0, double w1, double w2) {
-        FeatCorrRows<decltype(tagl)::value>::run(x, w0, w1, w2, vq);
+        if constexpr (decltype(tagl)::value < 2 * MAXVK) FeatCorrRows<decltype(tagl)::value>::run(x, w0, w1, w2, vq);
     };
-    // The gate's first pass walks column c of P_sub (L2 reads, ~0.6 us each way); its first PD views are requested HERE,
-    // ahead of K4, and the later ones PD views ahead of their use (a view's 30 FMAs last ~0.1 us; with one view of
-    // lookahead the pass was ten load latencies long).
-    constexpr int PD = 4;
-    double pb[PD + 1][6];
-    int colg = 15 + 6 * sSlot[min(lane, C6 - 1) / 6] + (min(lane, C6 - 1) % 6);
-    auto fetch = [&](auto tagv) {
-        constexpr int VW = decltype(tagv)::value;
-        if (VW < M) {                                                // (uniform)
-            const double* prow = p.P + (size_t)(15 + 6 * sSlot[VW]) * p.ldp + colg;
+    // the upper triangle of S, dealt round-robin over the lanes: rows L and R2 - 1 - L together hold R2 + 1 entries j >= L, so
+    // entry idx of the R2 / 2 row pairs is one division by R2 + 1 away.  An entry's D part lies in ONE chunk (its view's).
+    constexpr int NRES = ((RMAX / 2) * (RMAX + 1) + 63) / 64;      // R2 <= RMAX - 2, R2 even
+    double res[NRES];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) pb[VW % (PD + 1)][a] = prow[(size_t)a * p.ldp];
-        }
+    for (int it = 0; it < NRES; ++it) res[it] = 0.0;
+    const int ntri = (R2 >> 1) * (R2 + 1);
+    const float inv_p = 1.0f / (float)(R2 + 1);
+    auto entry = [&](int idx, int& L, int& j) {                  // idx < ntri -> (L, j), j >= L
+        const int pr = (int)(((float)idx + 0.5f) * inv_p), q_ = idx - pr * (R2 + 1);
+        const bool lo = q_ < R2 - pr;
+        L = lo ? pr : R2 - 1 - pr;
+        j = lo ? pr + q_ : q_ - 1;
     };
-    fetch(FTag<0>{}); fetch(FTag<1>{}); fetch(FTag<2>{}); fetch(FTag<3>{});
-    static_assert(PD == 4, "the prologue above issues PD views");
-    // ---------------- K4: write the compact block [H_o | r_o] ----------------
-    // The rows are staged in sE (free until the gate's first pass) and leave as ONE contiguous range: the q
-    // projected rows, row-major with 6M + 1 columns, every lane storing consecutive scalars.
-    // Lanes over COLUMNS (60 of 64 busy at 10 views; round 2 had one lane per row, 20 busy): lane c holds Z[:, c] and
-    // walks the rows, H_o[L][c] = D[L][c] - V[L,:] Z[:, c] with D[L][c] != 0 only for the two rows of c's own view.
-    {
-        // (ALL lanes run the groups -- a DPP broadcast reads garbage from a source lane that EXEC has switched off --,
-        //  lanes past the last column work on a copy of it and do not store)
-        for (int cb = 0; cb < C6; cb += 64) {
-            const bool cok = cb + lane < C6;
-            const int c = min(cb + lane, C6 - 1);
+    double* sEz = sE + R2 * ldE;                                  // [R2][3] E Z^T, summed over the chunks
+#ifndef MSCKF_FEAT_PD
+#define MSCKF_FEAT_PD 4
+#endif
+    constexpr int PD = MSCKF_FEAT_PD;                             // views of lookahead of the P_sub column reads
+    double pb[PD + 1][6];
+    for (int vc0 = 0; vc0 < (ONE_CHUNK ? 1 : M); vc0 += (ONE_CHUNK ? 1 : CV)) {      // (provably one trip for k_feature<24>)
+        const int nv = ONE_CHUNK ? M : min(CV, M - vc0);          // views of this chunk
+        const int c0 = 6 * vc0, cw = 6 * nv;                      // its columns [c0, c0 + cw), cw <= 60
+        const bool last = vc0 + nv >= M;
+        const int cwp = cw + (last ? 1 : 0);                      // + the rhs column
+        // ALL lanes run the DPP groups below (a DPP broadcast reads garbage from a source lane EXEC has switched off): lanes
+        // past the chunk's last column work on a copy of it and do not store
+        const bool cok = lane < cw;
+        const int lc = min(lane, cw - 1), c = c0 + lc;
+        const int vwc = c / 6, ac = c - 6 * vwc;
+        const int colg = 15 + 6 * sSlot[vwc] + ac;
+        // The gate's first pass walks column c of P_sub (L2 reads, ~0.6 us each way): its first PD views are requested HERE,
+        // ahead of K4, the later ones PD views ahead of their use (a view's 30 FMAs last ~0.1 us; with one view of lookahead
+        // the pass was ten load latencies long).
+        auto fetch = [&](auto tagv) {
+            constexpr int VW = decltype(tagv)::value;
+            if (VW < M) {                                            // (uniform)
+                const double* prow = p.P + (size_t)(15 + 6 * sSlot[VW]) * p.ldp + colg;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) pb[VW % (PD + 1)][a] = prow[(size_t)a * p.ldp];
+            }
+        };
+        fetch(FTag<0>{});
+        if constexpr (PD > 1) fetch(FTag<1>{});
+        if constexpr (PD > 2) fetch(FTag<2>{});
+        if constexpr (PD > 3) fetch(FTag<3>{});
+        static_assert(PD >= 1 && PD <= 4, "the prologue above issues PD views");
+        // ---------------- K4: the chunk's columns of the compact block [H_o | r_o] ----------------
+        // staged in sE (lane c holds Z[:, c] and walks the rows: H_o[L][c] = D[L][c] - V[L,:] Z[:, c], D[L][c] != 0 only for the
+        // two rows of c's own view), then out as contiguous row segments of the stack block (row-major q x (6M + 1), the q
+        // projected rows only)
+        {
             const double z0 = sZ[c], z1 = sZ[C6 + c], z2 = sZ[2 * C6 + c];
-            const int vwc = c / 6, ac = c - 6 * vwc;
             const double d0 = sA[(2 * vwc) * 6 + ac], d1 = sA[(2 * vwc + 1) * 6 + ac];   // the two rows of c's own view
             auto rows = [&](auto tagl) {
                 constexpr int L0 = decltype(tagl)::value;
@@ -317,114 +351,118 @@ __global__ __launch_bounds__(64, RMAX == 32 ? 3 : 2) void k_feature(FeatureArgs 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int L = L0 + i;
-                        if (L < R2 && cok) sE[L * ldE + c] = x[i] + ((L == 2 * vwc) ? d0 : (L == 2 * vwc + 1) ? d1 : 0.0);
+                        if (L < R2 && cok) sE[L * ldE + lc] = x[i] + ((L == 2 * vwc) ? d0 : (L == 2 * vwc + 1) ? d1 : 0.0);
                     }
                 }
             };
             rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
+            rows(FTag<24>{}); rows(FTag<28>{});
+            if (last && lane < R2) sE[lane * ldE + cw] = ro;
+            wave_sync();
+            const int nel = q * cwp;
+            if (cw == C6) {
+                // one chunk: the q projected rows are ONE contiguous range of sE and of the stack block
+                const double* srcrows = sE + rank * ldE;
+                if (p.stack_f32) {
+                    float* blk = static_cast<float*>(p.stack) + p.blk_off[f];
+                    for (int e = lane; e < nel; e += 64) blk[e] = (float)srcrows[e];
+                } else {
+                    double* blk = static_cast<double*>(p.stack) + p.blk_off[f];
+                    for (int e = lane; e < nel; e += 64) blk[e] = srcrows[e];
+                }
+            } else {
+                const float inv_cwp = 1.0f / (float)cwp;
+                for (int e = lane; e < nel; e += 64) {
+                    const int L = (int)(((float)e + 0.5f) * inv_cwp), cc = e - L * cwp;      // e / cwp, exact for e < 2^20
+                    const double x = sE[(rank + L) * ldE + cc];
+                    const long long dst = p.blk_off[f] + (long long)L * ldb + c0 + cc;
+                    if (p.stack_f32) static_cast<float*>(p.stack)[dst] = (float)x;
+                    else static_cast<double*>(p.stack)[dst] = x;
+                }
+            }
+            wave_sync();                       // sE is rewritten by the gate below
         }
-        if (lane < R2) sE[lane * ldE + C6] = ro;
+        if (p.stamps && vc0 == 0) tq[3] = wall_clock64();
+        // ---------------- K3: gate.  Pass 1, one column c of P_sub per lane: E = D P_sub (block rows) - V (Z P_sub) -------------
+        {
+            double zp0 = 0, zp1 = 0, zp2 = 0;
+            auto view = [&](auto tagv) {
+                constexpr int VW = decltype(tagv)::value;
+                if (VW < M) {                                            // (uniform)
+                    fetch(FTag<VW + PD>{});
+                    double e0 = 0.0, e1 = 0.0;
+                    if constexpr (VW < MAXVK) FeatGateView<VW>::run(zp0, zp1, zp2, e0, e1, pb[VW % (PD + 1)], zq, aq);
+                    if (cok) { sE[(2 * VW) * ldE + lc] = e0; sE[(2 * VW + 1) * ldE + lc] = e1; }
+                }
+            };
+            view(FTag<0>{}); view(FTag<1>{}); view(FTag<2>{}); view(FTag<3>{}); view(FTag<4>{}); view(FTag<5>{});
+            view(FTag<6>{}); view(FTag<7>{}); view(FTag<8>{}); view(FTag<9>{}); view(FTag<10>{});
+            view(FTag<11>{}); view(FTag<12>{}); view(FTag<13>{}); view(FTag<14>{});
+            // E -= V ZP  (same column, all rows)
+            auto rows = [&](auto tagl) {
+                constexpr int L0 = decltype(tagl)::value;
+                if (L0 < R2) {
+                    double x[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) x[i] = sE[min(L0 + i, R2 - 1) * ldE + lc];
+                    corr(tagl, x, zp0, zp1, zp2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (L0 + i < R2 && cok) sE[(L0 + i) * ldE + lc] = x[i];
+                }
+            };
+            rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
+            rows(FTag<24>{}); rows(FTag<28>{});
+        }
         wave_sync();
-        const int nel = q * ldE;
-        const double* srcrows = sE + rank * ldE;
-        if (p.stack_f32) {
-            float* blk = static_cast<float*>(p.stack) + p.blk_off[f];
-            for (int e = lane; e < nel; e += 64) blk[e] = (float)srcrows[e];
-        } else {
-            double* blk = static_cast<double*>(p.stack) + p.blk_off[f];
-            for (int e = lane; e < nel; e += 64) blk[e] = srcrows[e];
-        }
-        wave_sync();                       // sE is rewritten by the gate below
-    }
-
-    if (p.stamps) tq[3] = wall_clock64();
-    // ---------------- K3: gate ------------------------------------------------
-    // pass 1, lanes over columns c of P_sub: E = D P_sub (block rows) and ZP = Z P_sub
-    for (int cb = 0; cb < C6; cb += 64) {
-        const bool cok = cb + lane < C6;                     // (all lanes stay in: see K4)
-        const int c = min(cb + lane, C6 - 1);
-        double zp0 = 0, zp1 = 0, zp2 = 0;
-        if (cb > 0) {                                                // (tracks of 11 views: two more columns)
-            colg = 15 + 6 * sSlot[c / 6] + (c % 6);
-            fetch(FTag<0>{}); fetch(FTag<1>{}); fetch(FTag<2>{}); fetch(FTag<3>{});
-        }
-        auto view = [&](auto tagv) {
-            constexpr int VW = decltype(tagv)::value;
-            if (VW < M) {                                            // (uniform)
-                fetch(FTag<VW + PD>{});
-                double e0 = 0.0, e1 = 0.0;
-                FeatGateView<VW>::run(zp0, zp1, zp2, e0, e1, pb[VW % (PD + 1)], zq, aq);
-                if (cok) { sE[(2 * VW) * ldE + c] = e0; sE[(2 * VW + 1) * ldE + c] = e1; }
-            }
-        };
-        view(FTag<0>{}); view(FTag<1>{}); view(FTag<2>{}); view(FTag<3>{}); view(FTag<4>{}); view(FTag<5>{});
-        view(FTag<6>{}); view(FTag<7>{}); view(FTag<8>{}); view(FTag<9>{}); view(FTag<10>{});
-        // E -= V ZP  (same column, all rows)
-        auto rows = [&](auto tagl) {
-            constexpr int L0 = decltype(tagl)::value;
-            if (L0 < R2) {
-                double x[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) x[i] = sE[min(L0 + i, R2 - 1) * ldE + c];
-                corr(tagl, x, zp0, zp1, zp2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (L0 + i < R2 && cok) sE[(L0 + i) * ldE + c] = x[i];
-            }
-        };
-        rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
-    }
-    wave_sync();
-    if (p.stamps) tq[4] = wall_clock64();
-    // pass 2, ALL lanes (rounds 1-3 had one lane per row of S: 20 of 64 busy at 10 views, 7.1 of the block's 26 us):
-    //   (a) E Z^T, one (row, t) pair per lane;  (b) the entries S[L][j] = E[L, view of j] . D[j] - (E Z^T)[L] . V[j], j >= L
-    //   (+ sigma^2 on the diagonal; S is symmetric: rows L and R2 - 1 - L together have R2 + 1 of them, so entry idx of
-    //   the R2 / 2 row pairs is a division by R2 + 1 away) dealt round-robin, kept in registers until every lane is done
-    //   with E, then written -- mirrored -- into the elimination's tile sT (which lies over E) together with the rhs
-    //   border: column R2 = r_o, row R2 = r_o^T.
-    {
-        double* sEz = sE + R2 * ldE;                              // [R2][3]
+        if (p.stamps && vc0 == 0) tq[4] = wall_clock64();
+        // ---------------- pass 2, ALL lanes (rounds 1-3 had one lane per row of S: 20 of 64 busy at 10 views) -----------------
+        //   (a) the chunk's part of E Z^T, one (row, t) pair per lane;
+        //   (b) the D part of the entries S[L][j], j >= L, whose view lies in this chunk: E[L, view of j] . D[j]
         for (int idx = lane; idx < 3 * R2; idx += 64) {
             const int L = idx / 3, t3 = idx - 3 * L;
             const double* er = sE + L * ldE;
-            const double* zr = sZ + t3 * C6;
+            const double* zr = sZ + t3 * C6 + c0;
             double e0 = 0.0, e1 = 0.0;
-            int c = 0;
-            for (; c + 1 < C6; c += 2) { e0 += er[c] * zr[c]; e1 += er[c + 1] * zr[c + 1]; }
-            if (c < C6) e0 += er[c] * zr[c];
-            sEz[idx] = e0 + e1;
+            int cc = 0;
+            for (; cc + 1 < cw; cc += 2) { e0 += er[cc] * zr[cc]; e1 += er[cc + 1] * zr[cc + 1]; }
+            if (cc < cw) e0 += er[cc] * zr[cc];
+            sEz[idx] = (vc0 == 0 ? 0.0 : sEz[idx]) + (e0 + e1);
         }
-        wave_sync();
-        constexpr int NRES = ((RMAX / 2) * (RMAX + 1) + 63) / 64;   // R2 <= RMAX - 2, R2 even
-        double res[NRES];
-        const int ntri = (R2 >> 1) * (R2 + 1);
-        const float inv_p = 1.0f / (float)(R2 + 1);
-        auto entry = [&](int idx, int& L, int& j) {                // idx < ntri -> (L, j), j >= L
-            const int pr = (int)(((float)idx + 0.5f) * inv_p), q = idx - pr * (R2 + 1);
-            const bool lo = q < R2 - pr;
-            L = lo ? pr : R2 - 1 - pr;
-            j = lo ? pr + q : q - 1;
-        };
 #pragma unroll
         for (int it = 0; it < NRES; ++it) {
             const int idx = lane + 64 * it;
-            double x = 0.0;
             if (idx < ntri) {
                 int L, j;
                 entry(idx, L, j);
-                const int vw = j >> 1;
-                double sacc = 0.0;
+                const int vw = (j >> 1) - vc0;
+                if (vw >= 0 && vw < nv) {
+                    double sacc = 0.0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) sacc += sE[L * ldE + 6 * vw + a] * sA[j * 6 + a];
-                sacc -= sEz[L * 3 + 0] * sV[j * 3 + 0] + sEz[L * 3 + 1] * sV[j * 3 + 1] + sEz[L * 3 + 2] * sV[j * 3 + 2];
-                if (j == L) sacc += p.sigma2;
-                x = sacc;
+                    for (int a = 0; a < 6; ++a) sacc += sE[L * ldE + 6 * vw + a] * sA[j * 6 + a];
+                    res[it] = sacc;
+                }
             }
-            res[it] = x;
         }
-        wave_sync();                                            // every read of E is done: sT may take its place
+        wave_sync();                                                // the next chunk restages sE / the tile below replaces it
+    }
+    // S = (D parts) - (E Z^T) V^T + sigma^2 I, mirrored into the elimination's tile sT (which lies over sE) with the rhs border:
+    // column R2 = r_o, row R2 = r_o^T, corner 0
+    {
         double* sT = sE;
         const int ldT = R2 + 3;
+#pragma unroll
+        for (int it = 0; it < NRES; ++it) {
+            const int idx = lane + 64 * it;
+            if (idx < ntri) {
+                int L, j;
+                entry(idx, L, j);
+                double x = res[it] - (sEz[L * 3 + 0] * sV[j * 3 + 0] + sEz[L * 3 + 1] * sV[j * 3 + 1] + sEz[L * 3 + 2] * sV[j * 3 + 2]);
+                if (j == L) x += p.sigma2;
+                res[it] = x;
+            }
+        }
+        wave_sync();                                                // (sEz lies behind the tile: (R2 + 1)(R2 + 3) <= R2 ldE is not guaranteed)
 #pragma unroll
         for (int it = 0; it < NRES; ++it) {
             const int idx = lane + 64 * it;

@@ -968,11 +968,11 @@ int launch_feature(msckf_ctx* c) {
     a.select = c->use_select ? ptr<unsigned char>(c->dSelFlags) : nullptr;
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
     a.zero_idx = c->stack_elems;
-    const bool chunked = 2 * c->Mmax + 1 > 24;                 // k_feature<32> / <64>: column chunks, S in registers
+    const bool chunked = 2 * c->Mmax + 1 > 32;                 // k_feature<64>: column chunks, S in registers
     int lds_d = 0;                       // (the footprint is not monotone in the track length: whole-view chunks)
     for (int m = 1; m <= c->Mmax; ++m) lds_d = std::max(lds_d, feature_lds_doubles(m, chunked));
     const size_t lds = (size_t)lds_d * 8;
-    if (2 * c->Mmax + 1 <= 24) hipLaunchKernelGGL(k_feature<24>, dim3(c->F), dim3(64), lds, c->stream, a);
+    if (c->Mmax <= 10) hipLaunchKernelGGL(k_feature<24>, dim3(c->F), dim3(64), lds, c->stream, a);            // one chunk of <= 60 columns
     else if (2 * c->Mmax + 1 <= 32) hipLaunchKernelGGL(k_feature<32>, dim3(c->F), dim3(64), lds, c->stream, a);
     else hipLaunchKernelGGL(k_feature<64>, dim3(c->F), dim3(64), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());

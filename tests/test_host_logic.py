@@ -369,7 +369,7 @@ def test_generated_feature_groups_header_is_current():
     with open(gen.PATH) as f:
         assert f.read() == text
     blocks = re.findall(r'struct (FeatGateView|FeatCorrRows)<(\d+)> \{.*?asm volatile\("(.*?)"\s*\n\s*: (.*?)\n\s*: (.*?)\);', text, flags=re.S)
-    assert len(blocks) == gen.MAXV + 6
+    assert len(blocks) == gen.MAXV + 8
     for kind, num, body, outs, ins in blocks:
         num = int(num)
         in_list = [x.strip() for x in ins.split('", ')]
