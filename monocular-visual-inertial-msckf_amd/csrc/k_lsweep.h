@@ -42,6 +42,7 @@ constexpr int LS_MAXB = 128;    // row blocks per leaf node
 constexpr int LS_FB = 12;       // features per row block
 constexpr int LS_RS4 = 9;       // row slots of the 60-column leaf tile: 36 rows (two tracks of 10 views)
 constexpr int LS_RS6 = 8;       // row slots of the 90-column leaf tile: 32 rows (one track of up to 16 views)
+constexpr int LS_RS6T = 14;     // ... of its tall form: 56 rows (two tracks of 15 views), eight wavefronts (168 registers of tile)
 
 template <int CS, int RSLOTS> struct LSweepGeom {
     static constexpr int W = 16 * CS;

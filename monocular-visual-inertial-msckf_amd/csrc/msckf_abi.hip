@@ -281,7 +281,8 @@ struct msckf_ctx {
     bool plan_xchg = false;
     std::vector<int> plan_fmin, plan_fmax, plan_view;
     long long stack_elems = 0;            // scalars of the current batch's stack blocks (a zero word follows them)
-    int leaf_nf = 8;                      // row blocks in flight per 60-column leaf workgroup (8 or 12)
+    int leaf_nf = 8;
+    bool leaf_tall = false;               // 90-column leaves with 56-row blocks (k_lsweep<8, 6, LS_RS6T>)                      // row blocks in flight per 60-column leaf workgroup (8 or 12)
     bool leaf_narrow = false, leaf_wide = false;      // band plan: leaf nodes with w + 1 <= 64 / > 64 exist
     size_t root_off = 0;                  // offset (doubles) of the root block [T | r_n] in rbuf
     size_t zero_off = 0;                  // 16 doubles of the workspace no kernel writes: they read 0.0
@@ -617,10 +618,14 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     int leaf_feats = 128;
     {
         const bool wide_leaf = 6 * max_span + 1 > 64;
-        const int rb = wide_leaf ? LSweepGeom<6, LS_RS6>::RB : LSweepGeom<4, LS_RS4>::RB;
-        const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
+        static const int tall_mode = [] { const char* e = std::getenv("MSCKF_LS_TALL"); return e ? atoi(e) : 1; }();
         static const int big_batch = [] { const char* e = std::getenv("MSCKF_LS_BIG_BATCH"); return e ? atoi(e) : LS_BIG_BATCH; }();
-        c->leaf_nf = (F >= big_batch) ? 12 : 8;
+        // (the same for the 60-column leaves -- three tracks per block, eight wavefronts, prefetched tile -- is slower than twelve
+        //  wavefronts of two: 142 against 116 us at 10000 features)
+        c->leaf_tall = wide_leaf && tall_mode != 0;
+        const int rb = wide_leaf ? (c->leaf_tall ? LSweepGeom<6, LS_RS6T>::RB : LSweepGeom<6, LS_RS6>::RB) : LSweepGeom<4, LS_RS4>::RB;
+        const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
+        c->leaf_nf = (F >= big_batch && !c->leaf_tall) ? 12 : 8;
         const int unit = c->leaf_nf * fpb;
         static const int leaf_target = [] { const char* e = std::getenv("MSCKF_LEAF_TARGET"); return e ? std::max(1, atoi(e)) : 240; }();
         int want = (F + leaf_target - 1) / leaf_target;
@@ -854,7 +859,10 @@ int launch_leaves_band(msckf_ctx* c) {
     }
     if (c->leaf_wide) {
         a.wide = 1;
-        if (c->leaf_nf == 12) {          // large batches: twelve row blocks in flight (three wavefronts per SIMD)
+        if (c->leaf_tall) {              // two long tracks per row block, eight wavefronts (the tile alone is 168 registers)
+            const size_t lds = lsweep_lds_bytes<6, LS_RS6T>(8);
+            hipLaunchKernelGGL((k_lsweep<8, 6, LS_RS6T>), grid, dim3(64 * 8), lds, c->stream, a);
+        } else if (c->leaf_nf == 12) {          // large batches: twelve row blocks in flight (three wavefronts per SIMD)
             const size_t lds = lsweep_lds_bytes<6, LS_RS6>(12);
             hipLaunchKernelGGL((k_lsweep<12, 6, LS_RS6, false>), grid, dim3(64 * 12), lds, c->stream, a);
         } else {
@@ -1278,6 +1286,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 4, LS_RS4, false>), FOLD_LDS_BYTES, "k_lsweep<12,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 6, LS_RS6>), FOLD_LDS_BYTES, "k_lsweep<6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 6, LS_RS6, false>), FOLD_LDS_BYTES, "k_lsweep<12,6> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 6, LS_RS6T>), FOLD_LDS_BYTES, "k_lsweep<8,6,tall> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 4>), FOLD_LDS_BYTES, "k_wsweep<4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_wsweep<SWEEP_NW, 6>), FOLD_LDS_BYTES, "k_wsweep<6> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_chol<512>), LDS_MAX_BYTES - 1024, "k_chol LDS attribute");
