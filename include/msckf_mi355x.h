@@ -30,6 +30,9 @@
  *     loops and the covariance staging copies of msckf_update are split over them; pinned next to the creating
  *     thread).  Environment: MSCKF_HOST_THREADS (default 3, 0 = none), MSCKF_HOST_PAR_MIN (smallest batch that is
  *     split, default 1024 features), MSCKF_HOST_SPIN_US (how long idle workers poll before they sleep, default 1000).
+ *   - tuning switches of the K5 plan (diagnostics; the defaults are the measured best): MSCKF_LEAF_TARGET (leaf workgroups
+ *     aimed at per batch, default 240), MSCKF_LS_BIG_BATCH (from this many features on the 60-column leaves run twelve
+ *     wavefronts, default 4000), MSCKF_LS_TALL (90-column leaves with 56-row blocks, default 1; 0 = 32-row blocks).
  */
 #ifndef MSCKF_MI355X_H
 #define MSCKF_MI355X_H
