@@ -103,6 +103,15 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         if (p.stack_f32) static_cast<float*>(p.stack)[p.zero_idx + lane] = 0.0f;
         else static_cast<double*>(p.stack)[p.zero_idx + lane] = 0.0;
     }
+    // sums over the wavefront of values that are zero outside the 2M row lanes: two 16-lane rows are enough up to 16 views
+    auto wsum = [&](double x) -> double {
+        if constexpr (RMAX <= 34) {
+            x = row16_sum(x);
+            return readlane_d(x, 0) + readlane_d(x, 16);
+        } else {
+            return wave_sum(x);
+        }
+    };
     if (p.select && !(p.select[f] & 1)) {      // not in valid_features (MSCKF.py:453-455): no rows, not a rejection
         if (lane == 0) { p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3; }
         return;
@@ -186,9 +195,9 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             if (k >= R2) break;
             const bool act = (lane >= k) && (lane < R2);
             // column norms of the remaining columns over rows >= k
-            double n0 = wave_sum(act ? c0 * c0 : 0.0);
-            double n1 = (k < 2) ? wave_sum(act ? c1 * c1 : 0.0) : -1.0;
-            double n2 = (k < 1) ? wave_sum(act ? c2 * c2 : 0.0) : -1.0;
+            double n0 = wsum(act ? c0 * c0 : 0.0);
+            double n1 = (k < 2) ? wsum(act ? c1 * c1 : 0.0) : -1.0;
+            double n2 = (k < 1) ? wsum(act ? c2 * c2 : 0.0) : -1.0;
             // pivot: bring the largest remaining column to the front (c0)
             if (n1 > n0 && n1 >= n2) { double t_ = c0; c0 = c1; c1 = t_; n0 = n1; }
             else if (n2 > n0 && n2 > n1) { double t_ = c0; c0 = c2; c2 = t_; n0 = n2; }
@@ -201,11 +210,11 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             const double beta = 1.0 / (nrm * (nrm + fabs(xk)));
             // apply to the remaining columns
             if (k < 2) {
-                const double d1 = wave_sum(vk * (act ? c1 : 0.0));
+                const double d1 = wsum(vk * (act ? c1 : 0.0));
                 if (act) c1 -= beta * d1 * vk;
             }
             if (k < 1) {
-                const double d2 = wave_sum(vk * (act ? c2 : 0.0));
+                const double d2 = wsum(vk * (act ? c2 : 0.0));
                 if (act) c2 -= beta * d2 * vk;
             }
             if (k == 0) { vv0 = vk; beta0 = beta; }
@@ -217,16 +226,16 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         }
     }
     // T of the compact WY form Q = I - V T V^T (forward, columnwise)
-    const double v01 = wave_sum(vv0 * vv1);
-    const double v02 = wave_sum(vv0 * vv2);
-    const double v12 = wave_sum(vv1 * vv2);
+    const double v01 = wsum(vv0 * vv1);
+    const double v02 = wsum(vv0 * vv2);
+    const double v12 = wsum(vv1 * vv2);
     const double T00 = beta0, T11 = beta1, T22 = beta2;
     const double T01 = -beta1 * T00 * v01;
     const double T02 = -beta2 * (T00 * v02 + T01 * v12);
     const double T12 = -beta2 * T11 * v12;
 
     // residual: r_o = r - V T^T V^T r
-    const double wr0 = wave_sum(vv0 * res), wr1 = wave_sum(vv1 * res), wr2 = wave_sum(vv2 * res);
+    const double wr0 = wsum(vv0 * res), wr1 = wsum(vv1 * res), wr2 = wsum(vv2 * res);
     const double zr0 = T00 * wr0;
     const double zr1 = T01 * wr0 + T11 * wr1;
     const double zr2 = T02 * wr0 + T12 * wr1 + T22 * wr2;
