@@ -145,9 +145,12 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         const double zx = p.Kinv[0] * u + p.Kinv[1] * v + p.Kinv[2];
         const double zy = p.Kinv[3] * u + p.Kinv[4] * v + p.Kinv[5];
         const double zw = p.Kinv[6] * u + p.Kinv[7] * v + p.Kinv[8];
+        // (one division each for 1 / pz, 1 / zw and 1 / den; the other quotients of Camera.py are products with them: an IEEE
+        //  division is ~15 instructions here, and ~1e-16 relative is what the products differ by)
         const double ia = 1.0 / pz;
-        const double jb = -px / (pz * pz);
-        const double jc = -py / (pz * pz);
+        const double jb = -px * (ia * ia);
+        const double jc = -py * (ia * ia);
+        const double izw = 1.0 / zw;
         // u = [R0^T g ; (W_f - t0) x g]   (MSCKF.py:528-530)
         const double gx = p.g[0], gy = p.g[1], gz = p.g[2];
         const double u0 = R0[0] * gx + R0[3] * gy + R0[6] * gz;
@@ -160,11 +163,11 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         const double den = u0 * u0 + u1 * u1 + u2 * u2 + u3 * u3 + u4 * u4 + u5 * u5;
         double J0, J1, J2;   // this lane's row of J (Camera.py:57-58)
         if ((lane & 1) == 0) {
-            res = zx / zw - px / pz;
+            res = zx * izw - px * ia;
             J0 = ia; J1 = 0.0; J2 = jb;
             a0 = -jb * py; a1 = -ia * pz + jb * px; a2 = ia * py;          // J skew(Ci_f), row 0
         } else {
-            res = zy / zw - py / pz;
+            res = zy * izw - py * ia;
             J0 = 0.0; J1 = ia; J2 = jc;
             a0 = ia * pz - jc * py; a1 = jc * px; a2 = -ia * px;           // row 1
         }
@@ -175,8 +178,9 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         a3 = -h0; a4 = -h1; a5 = -h2;
         if (den > 1e-6) {      // observability-constrained projection (MSCKF.py:532-534)
             const double au = a0 * u0 + a1 * u1 + a2 * u2 + a3 * u3 + a4 * u4 + a5 * u5;
-            a0 -= au * u0 / den; a1 -= au * u1 / den; a2 -= au * u2 / den;
-            a3 -= au * u3 / den; a4 -= au * u4 / den; a5 -= au * u5 / den;
+            const double aud = au * (1.0 / den);
+            a0 -= aud * u0; a1 -= aud * u1; a2 -= aud * u2;
+            a3 -= aud * u3; a4 -= aud * u4; a5 -= aud * u5;
         }
     }
 
@@ -201,13 +205,15 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             // pivot: bring the largest remaining column to the front (c0)
             if (n1 > n0 && n1 >= n2) { double t_ = c0; c0 = c1; c1 = t_; n0 = n1; }
             else if (n2 > n0 && n2 > n1) { double t_ = c0; c0 = c2; c2 = t_; n0 = n2; }
-            const double nrm = sqrt(n0);
+            // (rsqrt / rcp seeds + one Newton step each, as in the sweeps: a few 1e-16; a zero column gives NaN and leaves below)
+            const double ry = fast_rsqrt(n0);
+            const double nrm = n0 * ry;
             if (k == 0) r00 = nrm;
             if (!(nrm > tol_scale * r00) || nrm == 0.0) break;   // numerically rank deficient
             const double xk = lane_bcast(c0, k);
             const double alpha = (xk > 0.0) ? -nrm : nrm;
             const double vk = act ? ((lane == k) ? (xk - alpha) : c0) : 0.0;
-            const double beta = 1.0 / (nrm * (nrm + fabs(xk)));
+            const double beta = ry * fast_rcp(nrm + fabs(xk));   // 1 / (nrm (nrm + |xk|))
             // apply to the remaining columns
             if (k < 2) {
                 const double d1 = wsum(vk * (act ? c1 : 0.0));
