@@ -79,6 +79,50 @@ __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
 __device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
 
 template <int V> struct FTag { static constexpr int value = V; };
+
+// The elimination's rank-1 update of NJ column quads in ONE statement (one s_nop 1 for the DPP hazard instead of one per FMA):
+// eb_j += (lane LK of ea_j's row) * wB, then ea_j += (lane LK of ea_j's row) * wA -- ea_j, the broadcast source, last.
+#define MSCKF_FD "row_newbcast:%c[lk] row_mask:0xf bank_mask:0xf\n\t"
+template <int LK> __device__ __forceinline__ void elim_pairs(double (&b)[1], double (&a)[1], double wB, double wA) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %[wb] " MSCKF_FD "v_fmac_f64_dpp %1, %1, %[wa] " MSCKF_FD
+                 : "+v"(b[0]), "+v"(a[0]) : [wb] "v"(wB), [wa] "v"(wA), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_pairs(double (&b)[2], double (&a)[2], double wB, double wA) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %[wb] " MSCKF_FD "v_fmac_f64_dpp %1, %3, %[wb] " MSCKF_FD
+                 "v_fmac_f64_dpp %2, %2, %[wa] " MSCKF_FD "v_fmac_f64_dpp %3, %3, %[wa] " MSCKF_FD
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(a[0]), "+v"(a[1]) : [wb] "v"(wB), [wa] "v"(wA), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_pairs(double (&b)[3], double (&a)[3], double wB, double wA) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %[wb] " MSCKF_FD "v_fmac_f64_dpp %1, %4, %[wb] " MSCKF_FD "v_fmac_f64_dpp %2, %5, %[wb] " MSCKF_FD
+                 "v_fmac_f64_dpp %3, %3, %[wa] " MSCKF_FD "v_fmac_f64_dpp %4, %4, %[wa] " MSCKF_FD "v_fmac_f64_dpp %5, %5, %[wa] " MSCKF_FD
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : [wb] "v"(wB), [wa] "v"(wA), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_pairs(double (&b)[4], double (&a)[4], double wB, double wA) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %4, %[wb] " MSCKF_FD "v_fmac_f64_dpp %1, %5, %[wb] " MSCKF_FD "v_fmac_f64_dpp %2, %6, %[wb] " MSCKF_FD
+                 "v_fmac_f64_dpp %3, %7, %[wb] " MSCKF_FD
+                 "v_fmac_f64_dpp %4, %4, %[wa] " MSCKF_FD "v_fmac_f64_dpp %5, %5, %[wa] " MSCKF_FD "v_fmac_f64_dpp %6, %6, %[wa] " MSCKF_FD
+                 "v_fmac_f64_dpp %7, %7, %[wa] " MSCKF_FD
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+                 : [wb] "v"(wB), [wa] "v"(wA), [lk] "i"(LK));
+}
+// ... and of the lower row slot alone (pivots 16+): eb_j += (lane LK of eb_j's row) * wB
+template <int LK> __device__ __forceinline__ void elim_self(double (&b)[1], double wB) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[wb] " MSCKF_FD : "+v"(b[0]) : [wb] "v"(wB), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_self(double (&b)[2], double wB) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[wb] " MSCKF_FD "v_fmac_f64_dpp %1, %1, %[wb] " MSCKF_FD
+                 : "+v"(b[0]), "+v"(b[1]) : [wb] "v"(wB), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_self(double (&b)[3], double wB) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[wb] " MSCKF_FD "v_fmac_f64_dpp %1, %1, %[wb] " MSCKF_FD "v_fmac_f64_dpp %2, %2, %[wb] " MSCKF_FD
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : [wb] "v"(wB), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_self(double (&b)[4], double wB) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %[wb] " MSCKF_FD "v_fmac_f64_dpp %1, %1, %[wb] " MSCKF_FD "v_fmac_f64_dpp %2, %2, %[wb] " MSCKF_FD
+                 "v_fmac_f64_dpp %3, %3, %[wb] " MSCKF_FD
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : [wb] "v"(wB), [lk] "i"(LK));
+}
+#undef MSCKF_FD
 // RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
 template <int RMAX>
 __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs p) {      // (<24>: <= 168 registers, the LDS footprint allows 12 wavefronts per CU; <32>: 219 registers, 8 per CU -- bounded to 168 it spills and is slower)
@@ -642,9 +686,10 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         }
         wave_sync();
         const int g = lane >> 4, l15 = lane & 15;
-        double ea[8], eb[8];
+        constexpr int NQ = (RMAX + 3) / 4;               // column quads that can hold a column j <= R2 (k_feature<24>: 6, <32>: 8)
+        double ea[NQ], eb[NQ];
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
+        for (int jj = 0; jj < NQ; ++jj) {
             const int j = 4 * jj + g;
             ea[jj] = (j <= R2 && l15 <= R2) ? sT[l15 * ldT + j] : 0.0;
             eb[jj] = (j <= R2 && l15 + 16 <= R2) ? sT[(l15 + 16) * ldT + j] : 0.0;
@@ -669,14 +714,34 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
                     if constexpr (k < 16) {
                         const double ma = bperm_d(ea[jk], src4);
                         const double wA = (l15 > k) ? -(ma * rp) : 0.0;                // rows 0 .. 15; the pivot row is lane lk's ea
+                        // column quads jk .. NQ - 1, up to four per statement
+                        constexpr int NJ = NQ - jk, N1 = NJ < 4 ? NJ : 4, N2 = NJ - N1;
+                        if constexpr (NJ > 0) {
+                            double bq[N1], aq_[N1];
 #pragma unroll
-                        for (int jj = jk; jj < 8; ++jj) {
-                            fmac_row_bcast16<lk>(eb[jj], ea[jj], wB);
-                            fmac_row_bcast16<lk>(ea[jj], ea[jj], wA);
+                            for (int i = 0; i < N1; ++i) { bq[i] = eb[jk + i]; aq_[i] = ea[jk + i]; }
+                            elim_pairs<lk>(bq, aq_, wB, wA);
+#pragma unroll
+                            for (int i = 0; i < N1; ++i) { eb[jk + i] = bq[i]; ea[jk + i] = aq_[i]; }
+                        }
+                        if constexpr (N2 > 0) {
+                            double bq[N2], aq_[N2];
+#pragma unroll
+                            for (int i = 0; i < N2; ++i) { bq[i] = eb[jk + 4 + i]; aq_[i] = ea[jk + 4 + i]; }
+                            elim_pairs<lk>(bq, aq_, wB, wA);
+#pragma unroll
+                            for (int i = 0; i < N2; ++i) { eb[jk + 4 + i] = bq[i]; ea[jk + 4 + i] = aq_[i]; }
                         }
                     } else {                                                             // rows 0 .. 15 are done; the pivot row is lane lk's eb
+                        constexpr int NJ = NQ - jk;                                      // (jk >= 4: at most four quads)
+                        if constexpr (NJ > 0) {
+                            double bq[NJ];
 #pragma unroll
-                        for (int jj = jk; jj < 8; ++jj) fmac_row_bcast16<lk>(eb[jj], eb[jj], wB);
+                            for (int i = 0; i < NJ; ++i) bq[i] = eb[jk + i];
+                            elim_self<lk>(bq, wB);
+#pragma unroll
+                            for (int i = 0; i < NJ; ++i) eb[jk + i] = bq[i];
+                        }
                     }
                 }
             }
