@@ -408,14 +408,16 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
                     double x[4] = {0.0, 0.0, 0.0, 0.0};
                     corr(tagl, x, z0, z1, z2);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int L = L0 + i;
-                        if (L < R2 && cok) sE[L * ldE + lc] = x[i] + ((L == 2 * vwc) ? d0 : (L == 2 * vwc + 1) ? d1 : 0.0);
-                    }
+                    for (int i = 0; i < 4; ++i)
+                        if (L0 + i < R2 && cok) sE[(L0 + i) * ldE + lc] = x[i];
                 }
             };
             rows(FTag<0>{}); rows(FTag<4>{}); rows(FTag<8>{}); rows(FTag<12>{}); rows(FTag<16>{}); rows(FTag<20>{});
             rows(FTag<24>{}); rows(FTag<28>{});
+            if (cok) {                                               // + D: only the two rows of c's own view have an entry in column c
+                sE[(2 * vwc) * ldE + lc] += d0;
+                sE[(2 * vwc + 1) * ldE + lc] += d1;
+            }
             if (last && lane < R2) sE[lane * ldE + cw] = ro;
             wave_sync();
             const int nel = q * cwp;
@@ -427,7 +429,12 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
                     for (int e = lane; e < nel; e += 64) blk[e] = (float)srcrows[e];
                 } else {
                     double* blk = static_cast<double*>(p.stack) + p.blk_off[f];
-                    for (int e = lane; e < nel; e += 64) blk[e] = srcrows[e];
+                    int e = lane;
+                    for (; e + 192 < nel; e += 256) {             // four LDS reads in flight per trip
+                        const double x0 = srcrows[e], x1 = srcrows[e + 64], x2 = srcrows[e + 128], x3 = srcrows[e + 192];
+                        blk[e] = x0; blk[e + 64] = x1; blk[e + 128] = x2; blk[e + 192] = x3;
+                    }
+                    for (; e < nel; e += 64) blk[e] = srcrows[e];
                 }
             } else {
                 const float inv_cwp = 1.0f / (float)cwp;
@@ -482,11 +489,15 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             const int L = idx / 3, t3 = idx - 3 * L;
             const double* er = sE + L * ldE;
             const double* zr = sZ + t3 * C6 + c0;
-            double e0 = 0.0, e1 = 0.0;
-            int cc = 0;
-            for (; cc + 1 < cw; cc += 2) { e0 += er[cc] * zr[cc]; e1 += er[cc + 1] * zr[cc + 1]; }
-            if (cc < cw) e0 += er[cc] * zr[cc];
-            sEz[idx] = (vc0 == 0 ? 0.0 : sEz[idx]) + (e0 + e1);
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+            for (int v6 = 0; v6 < cw; v6 += 6) {                 // a view's six columns at a time: twelve LDS reads in flight
+                double ev[6], zv[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { ev[a] = er[v6 + a]; zv[a] = zr[v6 + a]; }
+                e0 += ev[0] * zv[0]; e1 += ev[1] * zv[1]; e2 += ev[2] * zv[2];
+                e0 += ev[3] * zv[3]; e1 += ev[4] * zv[4]; e2 += ev[5] * zv[5];
+            }
+            sEz[idx] = (vc0 == 0 ? 0.0 : sEz[idx]) + ((e0 + e1) + e2);
         }
 #pragma unroll
         for (int it = 0; it < NRES; ++it) {
