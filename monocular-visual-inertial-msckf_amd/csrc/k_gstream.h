@@ -1,0 +1,391 @@
+// K6-K7 as a SEQUENTIAL BLOCK update that follows the root sweep of K5 row block by row block.
+//   reference MSCKF.py:604-607 : S = T P T^T + R_n ; K = P T^T S^-1 ; dx = K r_n
+//   reference MSCKF.py:612-614 : P+ = (I-KT) P (I-KT)^T + K R_n K^T ; P+ <- (P+ + P+^T)/2
+// With R_n = sigma^2 I (MSCKF.py:598: Q^T (sigma^2 I) Q) the rows of the compressed system [T | r_n] are
+// measurements with independent unit-variance-times-sigma^2 noise, so the batch update above equals processing
+// them in blocks of 16 rows, each against the covariance the previous blocks left (the block Cholesky of S in
+// disguise: with S = L L^T, X = P T^T L^-T one has K = X L^-1, P+ = P - X X^T, dx = X L^-1 r_n, and column block
+// I of X is  X_I = (P^(I) T_I^T) L_II^-T  with  P^(I) = P - sum_{J<I} X_J X_J^T,  L_II L_II^T = T_I P^(I) T_I^T + sigma^2 I):
+//
+//     Y_I = P^(I)[:, clone columns of T_I] T_I^T          d x 16      (T_I: 16 rows of T, a band of `ncb` 16-column blocks)
+//     A_I = T_I Y_I[clone rows] + sigma^2 I               16 x 16, SPD
+//     X_I = Y_I L_II^-T,  L_II = chol(A_I)
+//     P^(I+1) = P^(I) - X_I X_I^T
+//
+// Row block I of T is final as soon as the root sweep has passed it, i.e. this whole stage runs BESIDE the sweep
+// (it polls the progress word the sweep's flusher publishes) and only the last block trails it: K6-K7 used to be
+// 102 us of launches behind K5 (two 180-deep products, a 180-column Cholesky, two triangular sweeps, the Joseph
+// products), every one of them waiting for the complete T.  Checked against the reference's own outputs in
+// tests (1e-15 on P+ in NumPy on all golden fixtures, recipe B included: each A_I is a 16 x 16 matrix of modest
+// condition, where the reference inverts the whole S).
+//
+// dx needs no code of its own: the state is augmented by one row that starts as zero and is treated like a state
+// row whose "Y" entry gets r_I added; after the last block it holds -dx (row 15 of strip 0, which has 15 real rows).
+//
+// Work split: workgroup r owns COLUMN strip r of P (strip 0 = the 15 IMU rows + the dx row, strip s >= 1 = clone
+// columns 16 (s-1) ..): tiles P(s, r) live in matrix-core accumulator registers of wavefront s (lane (g, c) holds
+// rows {g + 4 i} of column c) for the whole kernel; by symmetry the same registers ARE the A operand of P(r, s).
+// Per row block: the wavefronts whose strip meets T_I's columns form partials of Y_I[r] (4 MFMAs each), one
+// wavefront publishes the sum (2 KB, write-through stores + flag), every wavefront s fetches Y_I[s] from strip s's
+// workgroup -- ONE all-to-all exchange per row block --, A_I and its elimination are computed redundantly in every
+// workgroup (one wavefront, the in-wave elimination of k_chol16; the others follow its multipliers through LDS
+// exactly like k_chol16's panel owners) and the rank-16 update of the strip is 4 MFMAs per tile.
+// Inter-workgroup visibility: every exchanged byte is stored sc1 (write-through), drained (s_waitcnt vmcnt(0))
+// before its flag is stored sc1 by one lane, and loaded sc1 by the wave that polled the flag
+// (MI355X_MICROARCH.md, inter-workgroup visibility: valid forms, first table row).  Flags carry the launch's epoch:
+// nothing has to be cleared between launches.  Every poll is bounded (status 2 = timeout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wave_ops.h"
+#include "k_gain.h"
+
+namespace msckf {
+
+typedef __attribute__((address_space(1))) unsigned long long gs_gu64;
+__device__ __forceinline__ unsigned long long gs_ld(const void* p) {
+    return __hip_atomic_load((const gs_gu64*)(const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double gs_ldd(const double* p) { return __longlong_as_double((long long)gs_ld(p)); }
+__device__ __forceinline__ void gs_st(void* p, unsigned long long v) {
+    __hip_atomic_store((gs_gu64*)(unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gs_std(double* p, double v) { gs_st(p, (unsigned long long)__double_as_longlong(v)); }
+
+constexpr int GS_WAVES = 16;                 // wavefronts per workgroup: tile wavefronts 0 .., wavefront 15 also eliminates
+constexpr int GS_PUB_WAVE = 14;              // publishes the strip's Y tile
+constexpr int GS_MAX_NS = 32;                // strips (two tiles per wavefront)
+constexpr long long GS_TIMEOUT_TICKS = 50000000LL;   // 0.5 s of the 100 MHz wall clock
+
+struct GStreamArgs {
+    const double* P; int ldp;                // prior covariance, d x d
+    const double* T; int ldt;                // root block [T | r_n]: dc rows x (dc + 1), row-major, zero below the diagonal
+    const unsigned long long* progress;      // (epoch << 32) | rows of T that are final; null: all rows are (standalone)
+    unsigned epoch;
+    double* ex;                              // exchange tiles [nb][ns][256]
+    unsigned long long* exflag;              // [nb][ns]: (epoch << 32) | (I + 1)
+    double* dx; double* Pout; int ldo;
+    int* status;                             // [0]: 0 ok, 1 a pivot was not a positive normal number, 2 timeout
+    double sigma2;
+    int d, dc, nb, ns, ncb;                  // nb row blocks of T, ns = nb + 1 strips, ncb column blocks per row block
+};
+
+__host__ __device__ inline size_t gstream_lds_doubles(int ns, int ncb) {
+    // multipliers [2][16][17] | 1 / l_cc [2][16] | control words | Y partials [ncb][256] | A partials [ncb][256] | X [ns][256]
+    return 544 + 32 + 16 + (size_t)2 * ncb * 256 + (size_t)ns * 256;
+}
+
+// In-wave elimination of a 16 x 16 SPD block in the accumulator layout (k_chol16's D phase, see k_gain.h): per pivot
+// the row of multipliers m_c = -a_cp / a_pp and the progress word go to sw_half ([16][17] doubles), 1 / l_cc to sri.
+// Returns true when a pivot is not a positive normal number.
+__device__ __forceinline__ bool gs_eliminate(double (&d)[4], unsigned sw_half, double* sri, int lane) {
+    const int g = lane >> 4, cc = lane & 15, cc4 = cc * 4;
+    const unsigned w_out = sw_half + lane * 8;
+    int rlo, rhi;
+    double piv;
+    asm volatile("s_nop 1\n\tds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4"
+                 : "=&v"(rlo), "=&v"(rhi) : "v"(cc4), "v"(__double2loint(d[0])), "v"(__double2hiint(d[0])) : "memory");
+    piv = readlane_d(d[0], 0);
+    auto pivot = [&](auto tagp) {
+        constexpr int P = decltype(tagp)::value;
+        constexpr int GN = (P + 1) & 3, IN = ((P + 1) >> 2) & 3;     // where row / pivot P + 1 live
+        int ccl = cc;
+        asm volatile("" : "+v"(ccl));
+        double r = __builtin_amdgcn_rcp(piv);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rlo), "+v"(rhi), "+v"(r)::"memory");
+        const double lc = __hiloint2double(rhi, rlo);
+        const double lcm = (ccl > P) ? -lc : 0.0;
+        const double e = fma(-piv, r, 1.0);
+        const double w = lcm * r;
+        const double w2 = fma(w, e, w);
+        if constexpr (P < 15) {
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d[IN]) : "v"(w2), "i"(P));
+            asm volatile("s_mov_b64 exec, 0x1ffff\n\tds_write_b64 %2, %3 offset:%4\n\ts_mov_b64 exec, -1\n\t"
+                         "ds_bpermute_b32 %0, %5, %6 offset:%8\n\tds_bpermute_b32 %1, %5, %7 offset:%8"
+                         : "=&v"(rlo), "=&v"(rhi)
+                         : "v"(w_out), "v"(w2), "i"(P * 17 * 8), "v"(cc4), "v"(__double2loint(d[IN])), "v"(__double2hiint(d[IN])), "i"(64 * GN)
+                         : "memory");
+            piv = readlane_d(d[IN], 16 * GN + P + 1);
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f64_dpp %0, %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                         : "+v"(d[(IN + 1) & 3]), "+v"(d[(IN + 2) & 3]), "+v"(d[(IN + 3) & 3]) : "v"(w2), "i"(P));
+        }
+    };
+    __builtin_amdgcn_s_setprio(3);
+    pivot(CTag<0>{}); pivot(CTag<1>{}); pivot(CTag<2>{}); pivot(CTag<3>{});
+    pivot(CTag<4>{}); pivot(CTag<5>{}); pivot(CTag<6>{}); pivot(CTag<7>{});
+    pivot(CTag<8>{}); pivot(CTag<9>{}); pivot(CTag<10>{}); pivot(CTag<11>{});
+    pivot(CTag<12>{}); pivot(CTag<13>{}); pivot(CTag<14>{}); pivot(CTag<15>{});
+    // the pivots are the diagonal as it stands now: lane (g, c) picks register c >> 2 and takes it from row group c & 3
+    double pivs;
+    {
+        const double sel = (cc < 8) ? ((cc < 4) ? d[0] : d[1]) : ((cc < 12) ? d[2] : d[3]);
+        const int src4 = (16 * (cc & 3) + cc) * 4;
+        const int plo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(sel)), phi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(sel));
+        pivs = __hiloint2double(phi, plo);
+    }
+    const bool bad = __ballot(!(pivs > 1e-200 && pivs < 1e200)) != 0ull;
+    const double ri = bad ? 1.0 : fast_rsqrt(pivs);
+    asm volatile("" ::: "memory");
+    if (g == 0) sri[cc] = ri;
+    __builtin_amdgcn_s_setprio(0);
+    return bad;
+}
+
+// A tile (any 16 rows x the block's 16 columns, accumulator layout) follows the pivots of gs_eliminate:
+// a <- a L^-T (k_chol16's panel owners), four pivots per poll of the progress words.
+__device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const double* sri, int lane) {
+    const int cc = lane & 15;
+    const unsigned w_cc = w_in + cc * 8;
+    auto follow4 = [&](auto tagp) {
+        constexpr int P0 = decltype(tagp)::value;
+        constexpr int PL = (P0 + 3 < 14) ? P0 + 3 : 14;              // the last pivot with multipliers
+        double* ap = a0;
+        const unsigned win_l = w_in, wcc_l = w_cc;
+        int spins = 0;
+        do {
+            double flag;
+            asm volatile("s_mov_b64 exec, 1\n\tds_read_b64 %0, %1 offset:%2\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(flag) : "v"(win_l), "i"(PL * 17 * 8 + 128) : "memory");
+            const int flo = __builtin_amdgcn_readfirstlane(__double2loint(flag));
+            const int fhi = __builtin_amdgcn_readfirstlane(__double2hiint(flag));
+            if (flo != (int)(CHOL16_UNSET & 0xffffffffLL) || fhi != (int)(CHOL16_UNSET >> 32)) break;
+            __builtin_amdgcn_s_sleep(2);
+        } while (++spins < (1 << 22));
+        double m0, m1, m2, m3 = 0.0;
+        asm volatile("ds_read_b64 %0, %3 offset:%4\n\tds_read_b64 %1, %3 offset:%5\n\tds_read_b64 %2, %3 offset:%6"
+                     : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(wcc_l), "i"(P0 * 17 * 8), "i"((P0 + 1) * 17 * 8), "i"((P0 + 2) * 17 * 8) : "memory");
+        if constexpr (P0 + 3 < 15) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m3) : "v"(wcc_l), "i"((P0 + 3) * 17 * 8) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)::"memory");
+#define GS_FOLLOW1(PP, M)                                                                                                \
+    asm volatile("s_nop 1\n\t"                                                                                          \
+                 "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
+                 "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"                                 \
+                 : "+v"(ap[0]), "+v"(ap[1]), "+v"(ap[2]), "+v"(ap[3]) : "v"(M), "i"(PP))
+        GS_FOLLOW1(P0, m0);
+        GS_FOLLOW1(P0 + 1, m1);
+        GS_FOLLOW1(P0 + 2, m2);
+        if constexpr (P0 + 3 < 15) GS_FOLLOW1(P0 + 3, m3);
+#undef GS_FOLLOW1
+    };
+    follow4(CTag<0>{}); follow4(CTag<4>{}); follow4(CTag<8>{}); follow4(CTag<12>{});
+    double ri = 0.0;
+    {
+        const unsigned ri_addr = lds_addr(sri + cc);
+        int spins = 0;
+        do {
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ri) : "v"(ri_addr) : "memory");
+            if (ri != 0.0) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (++spins < (1 << 22));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a0[i] *= ri;
+}
+
+template <int TPW>
+__global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = lane >> 4, cc = lane & 15;
+    const int r = blockIdx.x;
+    const int d = p.d, dc = p.dc, nb = p.nb, ns = p.ns, ncb = p.ncb;
+    double* sW = smem;                                   // [2][16][17]
+    double* sRi = smem + 544;                            // [2][16]
+    volatile int* sCtl = reinterpret_cast<volatile int*>(smem + 576);   // [0] bad pivot, [1] timeout
+    double* sPartY = smem + 592;                         // [ncb][256]
+    double* sPartA = sPartY + (size_t)ncb * 256;         // [ncb][256]
+    double* sX = sPartA + (size_t)ncb * 256;             // [ns][256], operand order [column][row]
+    const unsigned sw_addr = lds_addr(sW);
+    auto g0 = [&](int s) { return s == 0 ? 0 : 15 + 16 * (s - 1); };
+    auto nrows = [&](int s) { return s == 0 ? 15 : min(16, d - (15 + 16 * (s - 1))); };
+    const int gr = g0(r), nr = nrows(r);
+    const unsigned long long ep = (unsigned long long)p.epoch << 32;
+
+    // tiles P(s, r), s = wv + 16 q, symmetrised as they are loaded (the reference symmetrises its result, MSCKF.py:614)
+    double Pt[TPW][4];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int s = wv + 16 * q;
+        const int gsr = g0(min(s, ns - 1)), ms = (s < ns) ? nrows(s) : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = g + 4 * i;
+            const bool ok = (m < ms) && (cc < nr);
+            const size_t row = ok ? gsr + m : 0, col = ok ? gr + cc : 0;
+            const double x1 = p.P[row * p.ldp + col], x2 = p.P[col * p.ldp + row];
+            Pt[q][i] = ok ? 0.5 * (x1 + x2) : 0.0;
+        }
+    }
+    if (t < 32) { sRi[t] = 0.0; sW[(t >> 4) * 272 + (t & 15) * 17 + 16] = __longlong_as_double(CHOL16_UNSET); }
+    if (t < 4) sCtl[t] = 0;
+    __syncthreads();
+
+    const long long t_start = wall_clock64();
+    bool failed = false;
+    for (int I = 0; I < nb; ++I) {
+        const int need = min(16 * (I + 1), dc);
+        // ---- A: row block I of T is final -------------------------------------------------------------------
+        if (p.progress && wv == GS_WAVES - 1) {
+            for (;;) {
+                const unsigned long long v = gs_ld(p.progress);
+                if ((v >> 32) == p.epoch && (int)(v & 0xffffffffu) >= need) break;
+                if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) sCtl[1] = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        if (sCtl[1]) { failed = true; break; }
+        const int s_lo = I + 1, s_hi = min(I + ncb, ns - 1);          // strips that hold T_I's columns
+        // ---- B: partials of Y_I[r] = sum_s P(r, s) T_{I,s}^T ------------------------------------------------
+        double Tt[TPW][4];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int s = wv + 16 * q;
+            if (s >= s_lo && s <= s_hi) {
+                const int trow = 16 * I + cc;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int col = 16 * (s - 1) + 4 * u + g;
+                    const bool ok = trow < dc && col < dc;
+                    const double x = gs_ldd(p.T + (ok ? (size_t)trow * p.ldt + col : 0));
+                    Tt[q][u] = ok ? x : 0.0;
+                }
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pt[q][u], Tt[q][u], acc, 0, 0, 0);
+                double* dst = sPartY + (size_t)(s - s_lo) * 256 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[64 * i] = acc[i];
+            }
+        }
+        double rhs = 0.0;
+        if (wv == GS_PUB_WAVE && r == 0 && g == 3) {                   // r_n of this block: the dx row's share of Y
+            const int trow = 16 * I + cc;
+            const double x = gs_ldd(p.T + (trow < dc ? (size_t)trow * p.ldt + dc : 0));
+            rhs = trow < dc ? x : 0.0;
+        }
+        __syncthreads();
+        // ---- C: publish Y_I[r] ---------------------------------------------------------------------------------
+        if (wv == GS_PUB_WAVE) {
+            double y[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int sl = 0; sl <= s_hi - s_lo; ++sl) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) y[i] += sPartY[(size_t)sl * 256 + 64 * i + lane];
+            }
+            y[3] += rhs;                                               // (row 15 of strip 0; zero elsewhere)
+            double* dst = p.ex + ((size_t)I * ns + r) * 256 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gs_std(dst + 64 * i, y[i]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) gs_st(p.exflag + (size_t)I * ns + r, ep | (unsigned)(I + 1));
+        }
+        // ---- D: fetch Y_I[s]; partials of A_I = sum_s T_{I,s} Y_I[s] -------------------------------------------
+        double Yt[TPW][4];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int s = wv + 16 * q;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Yt[q][i] = 0.0;
+            if (s < ns) {
+                const unsigned long long want = ep | (unsigned)(I + 1);
+                const unsigned long long* fl = p.exflag + (size_t)I * ns + s;
+                bool ok = true;
+                for (;;) {
+                    if (gs_ld(fl) == want) break;
+                    if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) sCtl[1] = 1; ok = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (ok) {
+                    const double* src = p.ex + ((size_t)I * ns + s) * 256 + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Yt[q][i] = gs_ldd(src + 64 * i);
+                }
+                if (s >= s_lo && s <= s_hi) {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tt[q][u], Yt[q][u], acc, 0, 0, 0);
+                    double* dst = sPartA + (size_t)(s - s_lo) * 256 + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dst[64 * i] = acc[i];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- E: eliminate A_I (one wavefront), every tile follows: X_I[s] = Y_I[s] L_II^-T ----------------------
+        const int half = I & 1;
+        const unsigned sw_half = sw_addr + half * (16 * 17 * 8);
+        double* sri = sRi + half * 16;
+        if (wv == GS_WAVES - 1) {
+            double a[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int sl = 0; sl <= s_hi - s_lo; ++sl) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] += sPartA[(size_t)sl * 256 + 64 * i + lane];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (g + 4 * i == cc) a[i] += p.sigma2;
+            // the other half's words are reset for the next block (its followers have passed this block's first barrier)
+            if (lane < 16) { sW[(half ^ 1) * 272 + lane * 17 + 16] = __longlong_as_double(CHOL16_UNSET); sRi[(half ^ 1) * 16 + lane] = 0.0; }
+            const bool bad = gs_eliminate(a, sw_half, sri, lane);
+            if (bad && lane == 0) sCtl[0] = 1;
+        }
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int s = wv + 16 * q;
+            if (s < ns) {
+                gs_follow(Yt[q], sw_half, sri, lane);
+                double* dst = sX + (size_t)s * 256 + cc * 16 + g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[4 * i] = Yt[q][i];      // [column][row]
+            }
+        }
+        __syncthreads();
+        if (sCtl[0] | sCtl[1]) { failed = true; break; }
+        // ---- F: P(s, r) -= X_I[s] X_I[r]^T ----------------------------------------------------------------------
+        {
+            const double* xr = sX + (size_t)r * 256 + g * 16 + cc;
+            double bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bv[u] = xr[64 * u];
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                const int s = wv + 16 * q;
+                if (s < ns) {
+                    const double* xs = sX + (size_t)s * 256 + g * 16 + cc;
+                    double av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) av[u] = -xs[64 * u];
+                    v4d acc = {Pt[q][0], Pt[q][1], Pt[q][2], Pt[q][3]};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Pt[q][i] = acc[i];
+                }
+            }
+        }
+    }
+    if (failed) {
+        if (r == 0 && t == 0) p.status[0] = sCtl[1] ? 2 : 1;
+        return;
+    }
+    if (r == 0 && t == 0) p.status[0] = 0;
+    // ---- P+ tiles and dx (= minus the augmented row) -----------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int s = wv + 16 * q;
+        if (s < ns) {
+            const int gsr = g0(s), ms = nrows(s);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = g + 4 * i;
+                if (m < ms && cc < nr) p.Pout[(size_t)(gsr + m) * p.ldo + gr + cc] = Pt[q][i];
+            }
+            if (s == 0 && g == 3 && cc < nr) p.dx[gr + cc] = -Pt[q][3];
+        }
+    }
+}
+
+}  // namespace msckf

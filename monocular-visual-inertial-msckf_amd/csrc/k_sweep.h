@@ -69,6 +69,10 @@ struct SweepArgs {
     long long* stamps;          // optional: 8 ticks per node, may be null
     int stamp_base;
     const double* zero;         // a double that reads 0.0 (tail of the workspace)
+    // k_sweep<.., FL = true> (the root sweep of an update whose K6-K7 follows it row block by row block, k_gstream.h):
+    const int* flush_tab;       // nsteps + 1 entries lo | n << 16: rows [lo, lo + n) of R are final at the head of macro step t
+    unsigned long long* progress;   // (epoch << 32) | rows of the output block that are final AND visible device-wide
+    unsigned epoch;
 };
 
 constexpr int SWEEP_MAX_W = 60;        // widest source / envelope (local column 63 holds the rhs)
@@ -151,10 +155,11 @@ template <int KK> struct STag { static constexpr int value = KK; };
 // hence one instantiation of the step per column of a 16-column period (KK, J).  The four row lanes' partial dots
 // are reduce-scattered with the lane swaps (row r ends up with the dot of column slot r: 6 swaps and 3 additions)
 // and tau goes back the same way.
-template <int NF, int WPF, bool P2P = false>
-__global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
+template <int NF, int WPF, bool P2P = false, bool FL = false>
+__global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepArgs p) {
     static_assert(WPF == 1 && !P2P, "one wavefront per fold, one barrier per macro step");
-    constexpr int NW = NF;              // wavefronts
+    constexpr int NW = NF;              // fold wavefronts
+    constexpr int NT = 64 * (NF + (FL ? 1 : 0));   // threads: with FL one more wavefront, the flusher
     constexpr int CL = 16;              // column lanes of a fold
     constexpr int CS = 4;               // column slots of a lane
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
     long long tk0 = 0;
     if (p.stamps) tk0 = wall_clock64();
 
-    for (int e = t; e < nd.wtot * SWEEP_RS; e += 64 * NW) Rb[e] = 0.0;
+    for (int e = t; e < nd.wtot * SWEEP_RS; e += NT) Rb[e] = 0.0;
     if (t < 2) smem[nd.wtot * SWEEP_RS + NW * 64 + t] = 0.0;
     // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
     const SweepFold f0 = p.folds[nd.fold_begin];
@@ -180,9 +185,77 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         __syncthreads();
         const double* src = p.rbuf + f0.src_off;
         const int ldw = f0.w + 1;
-        for (int e = t; e < f0.w * ldw; e += 64 * NW) {
+        for (int e = t; e < f0.w * ldw; e += NT) {
             const int r = e / ldw, lc = e - r * ldw;
             if (lc >= r) Rb[(size_t)(f0.off + r) * SWEEP_RS + (lc == f0.w ? 63 : lc - r)] = src[e];
+        }
+    }
+
+    if constexpr (FL) {
+        // The flusher: at the head of every macro step it writes the rows of R that no present or future fold step touches
+        // (the schedule is static: flush_tab, made by the host's sweep_flush_table) to the output block with write-through
+        // stores and publishes how many rows are final.  A row's count goes out three steps after its stores, behind a
+        // COUNTED wait (vector-memory instructions of one wavefront complete in issue order on gfx9-family parts, so
+        // `vmcnt(M)` with M <= the instructions issued since leaves exactly the younger ones in flight): a `vmcnt(0)` per
+        // step would hold the flusher -- and with it the step's barrier -- for a store's round trip.  It joins the
+        // barriers bare (s_barrier without the waits of __syncthreads()).
+        if (wv == NF) {
+            const int ldo = nd.wtot + 1;
+            double* out = p.rbuf + nd.out_off;
+            const int wtot = __builtin_amdgcn_readfirstlane(nd.wtot);
+            const unsigned long long ep = (unsigned long long)p.epoch << 32;
+            int c1 = 0, c2 = 0;                     // vector-memory instructions issued one / two steps ago
+            int l1 = 0, l2 = 0, l3 = 0;             // rows final one / two / three steps ago
+            int published = 0;
+            int e_next = p.flush_tab[0];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // R zeroed / adopted
+            asm volatile("" ::: "memory");
+            for (int ts = 0; ts <= nsteps; ++ts) {
+                const int e = __builtin_amdgcn_readfirstlane(e_next);
+                if (ts < nsteps) e_next = p.flush_tab[ts + 1];
+                const int lo = e & 0xFFFF, n = e >> 16;
+                for (int c = lo; c < lo + n; ++c) {
+                    const double x = Rb[(size_t)c * SWEEP_RS + lane];
+                    const int col = (lane == 63) ? wtot : c + lane;
+                    if (lane == 63 || col < wtot) {
+                        __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)(out + (size_t)c * ldo + col),
+                                           (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                int issued = n;
+                if (l3 > published) {
+                    // the stores of rows < l3 were issued three steps ago or earlier: c2 + c1 + n instructions since
+                    const int m = c2 + c1 + n;
+                    switch (m < 7 ? m : 7) {
+                        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                    }
+                    if (lane == 0)
+                        __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress, ep | (unsigned)l3,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    published = l3;
+                    ++issued;
+                }
+                l3 = l2; l2 = l1; l1 = lo + n;
+                c2 = c1; c1 = issued;
+                if (ts < nsteps) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress, ep | (unsigned)wtot,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
         }
     }
 
@@ -325,6 +398,7 @@ __global__ __launch_bounds__(64 * NF * WPF) void k_sweep(SweepArgs p) {
         have = have_next;
     }
     while (tcur < nsteps) { __syncthreads(); ++tcur; }
+    if constexpr (FL) return;                              // (the flusher writes the output block, row by row as it becomes final)
 
     // ---- flush R: row-major wtot x (wtot+1), entries at and right of the diagonal ----
     __syncthreads();

@@ -25,6 +25,7 @@
 #include "k_feature.h"
 #include "k_fold.h"
 #include "k_gain.h"
+#include "k_gstream.h"
 #include "k_select.h"
 #include "k_sweep.h"
 #include "k_wsweep.h"
@@ -328,6 +329,17 @@ struct msckf_ctx {
     bool oneshot = false;                 // msckf_update: set_features uploads, launches K1-K4 and plans K5 meanwhile, no sync
     bool feature_launched = false;        // K1-K4 of the current batch is already in the stream (oneshot)
     HostPool* pool = nullptr;             // host worker threads for the pack loops (CPU work only)
+    // K6-K7 beside the root sweep (k_gstream.h): the sequential block update polls the rows the sweep's flusher publishes
+    hipStream_t stream2 = nullptr;        // k_gain_stream runs here while the root sweep runs on `stream`
+    hipEvent_t ev_pre = nullptr, ev_gain = nullptr;
+    Buf dGsEx, dGsFlag, dGsProg;          // exchange tiles [nb][ns][256], their flags, the sweep's progress word
+    Buf dRootFlush, dXRootFlush;          // flush tables of the root sweeps (rows final at the head of every macro step): local plan, merge plan
+    std::vector<int> h_root_flush;        // ... of the local plan's root (band plan, k_sweep form)
+    std::vector<int> x_root_flush;        // ... of the merge plan's root (msckf_run_merge_groups)
+    unsigned gs_epoch = 0;                // tag of the current launch pair in the progress word and the exchange flags
+    bool gs_enabled = true;               // MSCKF_GAIN_STREAM=0: the round-3 K6-K7 (separate launches behind the root sweep)
+    bool gs_overlap = true;               // MSCKF_GAIN_OVERLAP=0: k_gain_stream alone, behind the root sweep
+    int root_band = 0;                    // widest row of the root block in columns (the local plan's / the merge plan's)
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
     int fetched_rc = 0;                   // ... and that code: msckf_commit_covariance need not read the gate results again
@@ -759,6 +771,14 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     c->rbuf_doubles = off;
     c->xchg_planned = xchg;
     c->h_flush.clear(); c->h_flush_off.clear();
+    c->h_root_flush.clear();
+    c->root_band = 0;
+    if (!group_tri.empty()) {
+        // the root's rows become final one by one as the sweep passes them: K6-K7 (k_gstream.h) follows them block by block
+        const SweepNode& rn = c->snodes.back();
+        for (int g = rn.fold_begin; g < rn.fold_end; ++g) c->root_band = std::max(c->root_band, c->sfolds[g].ew);
+        if (mode == 0) sweep_flush_table(c->sfolds, rn.fold_begin, rn.fold_end, rn.nsteps, rn.wtot, 1 << 29, c->h_root_flush);
+    }
     if (mode > 0) {
         const int rc = 1 << (mode == 1 ? WS_RC_LOG2_4 : WS_RC_LOG2_6);
         for (const SweepNode& nd : c->snodes) {
@@ -774,7 +794,12 @@ void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     c->xchg_planned = false;
     c->band_plan = build_plan_band(c, fmin, fmax, view_sorted, valid);
-    if (!c->band_plan) { c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0; build_plan(c, fmin, fmax, view_sorted, valid); }
+    if (!c->band_plan) {
+        c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
+        c->h_root_flush.clear();
+        build_plan(c, fmin, fmax, view_sorted, valid);
+        c->root_band = c->dc;                                             // a dense triangle
+    }
 }
 
 int upload_plan(msckf_ctx* c);
@@ -948,6 +973,10 @@ int upload_plan(msckf_ctx* c) {
                                  hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, c->sfolds.data(), c->sfolds.size() * sizeof(SweepFold),
                                  hipMemcpyHostToDevice, c->stream));
+        if (c->band_plan && !c->h_root_flush.empty()) {
+            if (int rc = ensure(c, c->dRootFlush, c->h_root_flush.size() * 4)) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->dRootFlush.p, c->h_root_flush.data(), c->h_root_flush.size() * 4, hipMemcpyHostToDevice, c->stream));
+        }
         if (c->sweep_mode > 0 && c->band_plan) {
             if (int rc = ensure(c, c->dFlush, c->h_flush.size() * 4)) return rc;
             if (int rc = ensure(c, c->dFlushOff, c->h_flush_off.size() * 4)) return rc;
@@ -1154,6 +1183,59 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
     return MSCKF_OK;
 }
 
+// ---- K6-K7 as the sequential block update of k_gstream.h ---------------------------------------------------------
+// 16-column blocks a 16-row block of the root spans when its rows are `band` columns wide
+inline int gstream_ncb(int dc, int band) {
+    const int nb = (dc + 15) / 16;
+    return std::max(1, std::min(nb, (std::min(band, dc) + 15 + 15) / 16));
+}
+bool gstream_ok(const msckf_ctx* c, int band) {
+    if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || c->dc < 1) return false;
+    const int nb = (c->dc + 15) / 16, ns = nb + 1;
+    if (ns > GS_MAX_NS) return false;
+    return gstream_lds_doubles(ns, gstream_ncb(c->dc, band)) * 8 <= (size_t)(LDS_MAX_BYTES - 1024);
+}
+// Tblk: the root block [T | r_n]; band: its widest row in columns; beside: the root sweep is running (or about to) on
+// c->stream with its flusher publishing rows under c->gs_epoch -- else T is complete and nothing is polled
+int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band, bool beside, hipStream_t st) {
+    const int d = c->d, dc = c->dc, nb = (dc + 15) / 16, ns = nb + 1, ncb = gstream_ncb(dc, band);
+    GStreamArgs a{};
+    a.P = ptr<double>(c->dP); a.ldp = d;
+    a.T = Tblk; a.ldt = dc + 1;
+    a.progress = beside ? ptr<unsigned long long>(c->dGsProg) : nullptr;
+    a.epoch = c->gs_epoch;
+    a.ex = ptr<double>(c->dGsEx); a.exflag = ptr<unsigned long long>(c->dGsFlag);
+    a.dx = ptr<double>(c->dDx); a.Pout = ptr<double>(c->dPout); a.ldo = d;
+    a.status = ptr<int>(c->dStatus);
+    a.sigma2 = c->sigma * c->sigma;
+    a.d = d; a.dc = dc; a.nb = nb; a.ns = ns; a.ncb = ncb;
+    // (at least 100 KB of LDS: the workgroups of this kernel never share a CU with the root sweep's)
+    const size_t lds = std::max<size_t>(gstream_lds_doubles(ns, ncb) * 8, (size_t)100 * 1024);
+    if (ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
+    HIPCHK(c, hipGetLastError());
+    c->gain_blocked = false;
+    return MSCKF_OK;
+}
+// The root sweep (k_sweep form) with its flusher on c->stream and K6-K7 beside it on c->stream2; c->stream continues
+// behind both.  `a` carries the tables and the node index; mid_ev (optional) is recorded behind the sweep.
+int launch_root_and_gain(msckf_ctx* c, SweepArgs a, int wtot, const int* flush_tab, const double* Tblk, int band, hipEvent_t mid_ev) {
+    ++c->gs_epoch;
+    a.flush_tab = flush_tab;
+    a.progress = ptr<unsigned long long>(c->dGsProg);
+    a.epoch = c->gs_epoch;
+    a.stamps = nullptr;
+    HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
+    hipLaunchKernelGGL((k_sweep<SWEEP_NW, 1, false, true>), dim3(1), dim3(64 * (SWEEP_NW + 1)), sweep_lds_bytes(wtot, SWEEP_NW, 1), c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    if (mid_ev) HIPCHK(c, hipEventRecord(mid_ev, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pre, 0));
+    if (int rc = launch_gain_stream(c, Tblk, band, true, c->stream2)) return rc;
+    HIPCHK(c, hipEventRecord(c->ev_gain, c->stream2));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gain, 0));
+    return MSCKF_OK;
+}
+
 // Gate results of the last run, summed on the host:
 // {accepted, stacked rows, not-SPD gate matrices, not selected by k_select}.
 int gate_counts(msckf_ctx* c, int out[4], std::vector<unsigned char>* acc_sorted, bool copied = false) {
@@ -1187,7 +1269,10 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c)) != MSCKF_OK) return rc;
     if (c->F > 0 && !c->band_plan && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
-    if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, with_gain || !c->xchg_planned)) != MSCKF_OK) return rc;
+    // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront, k_gain_stream on the second stream
+    const bool gs = with_gain && c->F > 0 && c->root >= 0 && gstream_ok(c, c->root_band);
+    const bool beside = gs && c->band_plan && c->sweep_mode == 0 && c->gs_overlap && !c->h_root_flush.empty();
+    if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, (with_gain || !c->xchg_planned) && !beside)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
         // (with msckf_set_exchange_mask the shard's gate bytes ride behind it, in input order)
         hipLaunchKernelGGL(k_count_accepted, dim3(1), dim3(256), 0, c->stream, ptr<unsigned char>(c->dAcc), c->F,
@@ -1195,9 +1280,22 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
                            c->xmask_doubles > 0 ? reinterpret_cast<unsigned char*>(ptr<double>(c->dRbuf) + c->N + 1) : nullptr);
         HIPCHK(c, hipGetLastError());
     }
-    if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
-    if (with_gain && c->F > 0 && c->root >= 0) {
-        if ((rc = launch_gain(c, root_block(c))) != MSCKF_OK) return rc;
+    if (beside) {
+        SweepArgs a{};
+        a.nodes = ptr<SweepNode>(c->dSweepNodes);
+        a.folds = ptr<SweepFold>(c->dSweepFolds);
+        a.rbuf = ptr<double>(c->dRbuf);
+        a.zero = ptr<double>(c->dRbuf) + c->zero_off;
+        a.node_base = c->n_group_merges;
+        if ((rc = launch_root_and_gain(c, a, c->snodes.back().wtot, ptr<int>(c->dRootFlush), root_block(c), c->root_band,
+                                       stage_ev ? stage_ev[2] : nullptr)) != MSCKF_OK) return rc;
+    } else {
+        if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
+        if (with_gain && c->F > 0 && c->root >= 0) {
+            if (gs) { ++c->gs_epoch; rc = launch_gain_stream(c, root_block(c), c->root_band, false, c->stream); }
+            else rc = launch_gain(c, root_block(c));
+            if (rc != MSCKF_OK) return rc;
+        }
     }
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[3], c->stream));
     c->ran = true;
@@ -1251,12 +1349,21 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { msckf_destroy(c); return MSCKF_ERR_HIP; }
+    {
+        const char* e1 = std::getenv("MSCKF_GAIN_STREAM");
+        const char* e2 = std::getenv("MSCKF_GAIN_OVERLAP");
+        c->gs_enabled = !(e1 && std::atoi(e1) == 0);
+        c->gs_overlap = !(e2 && std::atoi(e2) == 0);
+    }
     // every failure here is reported at create time (a dropped attribute would only surface later as an
     // opaque launch error of the first kernel that needs the LDS)
     hipError_t cerr = hipSuccess;
     const char* cwhat = "";
     auto CK = [&](hipError_t e, const char* what) { if (cerr == hipSuccess && e != hipSuccess) { cerr = e; cwhat = what; } };
     for (auto& e : c->ev) CK(hipEventCreate(&e), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_gain, hipEventDisableTiming), "hipEventCreate");
     auto lds_attr = [&](const void* f, int bytes, const char* what) {
         CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
     };
@@ -1282,6 +1389,9 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, 1, false, true>), FOLD_LDS_BYTES, "k_sweep (flusher) LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_gain_stream<1>), LDS_MAX_BYTES - 1024, "k_gain_stream<1> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_gain_stream<2>), LDS_MAX_BYTES - 1024, "k_gain_stream<2> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 4, LS_RS4, false>), FOLD_LDS_BYTES, "k_lsweep<12,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 6, LS_RS6>), FOLD_LDS_BYTES, "k_lsweep<6> LDS attribute");
@@ -1329,6 +1439,12 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     E(c->dU, (size_t)dc * dc * 8); E(c->dInvd, (size_t)dc * 8); E(c->dK, (size_t)d * dc * 8);
     E(c->dB2, (size_t)d * d * 8); E(c->dD, (size_t)d * dc * 8); E(c->dPn, (size_t)d * d * 8);
     E(c->dCholWork, (size_t)dc * (dc + 1) / 2 * 8);
+    {   // k_gain_stream: exchange tiles and (epoch-tagged, hence zeroed once) flags, the root sweep's progress word
+        const size_t nbm = (size_t)(dc + 15) / 16, nsm = nbm + 1;
+        E(c->dGsEx, nbm * nsm * 256 * 8);
+        E(c->dGsFlag, (nbm * nsm + 8) * 8, true);
+        E(c->dGsProg, 64, true);
+    }
     if (rc != MSCKF_OK) { msckf_destroy(c); return rc; }
     {
         const char* e = std::getenv("MSCKF_HOST_THREADS");
@@ -1356,17 +1472,22 @@ void msckf_destroy(msckf_ctx* c) {
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
                   &c->dRank, &c->dAcc, &c->dGamma, &c->dKeep, &c->dNodes, &c->dRbuf, &c->dStamps, &c->dSweepNodes, &c->dSweepFolds, &c->dY, &c->dS, &c->dL,
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
-                  &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf, &c->dAssocUV, &c->dAssocRes};
+                  &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf, &c->dAssocUV, &c->dAssocRes,
+                  &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dRootFlush, &c->dXRootFlush};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    if (c->ev_gain) (void)hipEventDestroy(c->ev_gain);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1714,6 +1835,10 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     if (!(c->ran_gain && n_acc > 0)) status[0] = status[1] = 0;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || (c->gain_blocked && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
+    if (rc == MSCKF_ERR_NOT_SPD && status[0] == 2) {       // k_gain_stream gave up waiting for rows of T or for another workgroup
+        c->last_error = "k_gain_stream: timeout (the root sweep or a workgroup of the update did not make progress)";
+        rc = MSCKF_ERR_HIP;
+    }
     if (accepted && c->F > 0) {
         for (int s = 0; s < c->F; ++s) accepted[c->perm[s]] = (acc_sorted[s] == 1) ? 1 : 0;
     }
@@ -1763,6 +1888,7 @@ int msckf_commit_covariance(msckf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
+    if (status[0] == 2) return MSCKF_ERR_HIP;                                  // k_gain_stream timed out
     if (status[0] != 0 || (c->gain_blocked && status[1] != 0)) return MSCKF_ERR_NOT_SPD;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2183,7 +2309,9 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     const double* root = rb + all.back().out_off;
     // counters[0] decides OK / NOOP in get_result: mark "accepted" when any block is non-empty
     (void)N;
-    int rc = launch_gain(c, root);
+    int rc;
+    if (gstream_ok(c, dc)) { ++c->gs_epoch; rc = launch_gain_stream(c, root, dc, false, c->stream); }
+    else rc = launch_gain(c, root);
     if (rc != MSCKF_OK) return rc;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, ptr<int>(c->dStatus) + 2, (int)total_accepted);   // (shared result)
     HIPCHK(c, hipGetLastError());
@@ -2373,6 +2501,8 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
             sweep_schedule(fl, b, (int)fl.size(), &r.nsteps);
             r.out_off = (long long)o_root;
             c->x_snodes.push_back(r);
+            c->x_root_flush.clear();
+            if (xmode == 0) sweep_flush_table(fl, b, (int)fl.size(), r.nsteps, r.wtot, 1 << 29, c->x_root_flush);
         }
         // tables: local plan first (its launches may follow this call), the merge plan behind it
         std::vector<SweepNode> all_n(c->snodes);
@@ -2401,6 +2531,10 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         if (int rc = ensure(c, c->dSweepFolds, std::max<size_t>(all_f.size(), 1) * sizeof(SweepFold))) return rc;
         if (!all_n.empty()) HIPCHK(c, hipMemcpyAsync(c->dSweepNodes.p, all_n.data(), all_n.size() * sizeof(SweepNode), hipMemcpyHostToDevice, c->stream));
         if (!all_f.empty()) HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, all_f.data(), all_f.size() * sizeof(SweepFold), hipMemcpyHostToDevice, c->stream));
+        if (!c->x_root_flush.empty()) {
+            if (int rc = ensure(c, c->dXRootFlush, c->x_root_flush.size() * 4)) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->dXRootFlush.p, c->x_root_flush.data(), c->x_root_flush.size() * 4, hipMemcpyHostToDevice, c->stream));
+        }
         HIPCHK(c, hipMemsetAsync(rb + o_mrg, 0, (o_end - o_mrg) * 8, c->stream));   // merged triangles, root block, zero words
         HIPCHK(c, hipStreamSynchronize(c->stream));                                  // all_n / all_f are locals
         c->x_key = key; c->x_nrec = n_rec; c->x_root_off = o_root; c->x_zero_off = o_zero; c->x_rec_base = rec_base;
@@ -2430,12 +2564,15 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
             launch_wsweep<6>(c, nb + c->x_n_merges, 1, WS_RC_LOG2_6, rs, rb + c->x_zero_off);
         }
         HIPCHK(c, hipGetLastError());
-        int rcg = launch_gain(c, rb + c->x_root_off);
+        int rcg;
+        if (gstream_ok(c, XW)) { ++c->gs_epoch; rcg = launch_gain_stream(c, rb + c->x_root_off, XW, false, c->stream); }
+        else rcg = launch_gain(c, rb + c->x_root_off);
         if (rcg != MSCKF_OK) return rcg;
         if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
         c->ran = true; c->ran_gain = true;
         c->acc_override = total_accepted;
         c->acc_from_dev = count_on_device;
+        ++c->run_serial;
         return MSCKF_OK;
     }
     SweepArgs a{};
@@ -2451,9 +2588,15 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
                            sweep_lds_bytes(SWEEP_MAX_W, SWEEP_NW, SWEEP_WPF), c->stream, a);
     }
     a.node_base = nb + c->x_n_merges;
-    hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF, SWEEP_P2P>), dim3(1), block, sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF), c->stream, a);
-    HIPCHK(c, hipGetLastError());
-    int rc = launch_gain(c, rb + c->x_root_off);
+    int rc;
+    if (gstream_ok(c, XW) && c->gs_overlap && !c->x_root_flush.empty()) {
+        rc = launch_root_and_gain(c, a, dc, ptr<int>(c->dXRootFlush), rb + c->x_root_off, XW, nullptr);
+    } else {
+        hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF, SWEEP_P2P>), dim3(1), block, sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF), c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        if (gstream_ok(c, XW)) { ++c->gs_epoch; rc = launch_gain_stream(c, rb + c->x_root_off, XW, false, c->stream); }
+        else rc = launch_gain(c, rb + c->x_root_off);
+    }
     if (rc != MSCKF_OK) return rc;
     if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
     c->ran = true; c->ran_gain = true;
@@ -2624,10 +2767,12 @@ int msckf_get_shared_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* ac
     int status[4];
     std::memcpy(status, c->hRes, 16);
     const int dc = c->dc;
-    const bool blocked = dc > 4 * CHOL_TILE_MAX_NT && dc <= 2 * GAIN_BLK && dc - GAIN_BLK >= 4;    // as launch_gain decides
+    // (as launch_gain decides; k_gain_stream -- dtype f64 -- uses the first status word only)
+    const bool blocked = !(c->gs_enabled && c->cfg.dtype == MSCKF_DTYPE_F64 && (dc + 15) / 16 + 1 <= GS_MAX_NS) &&
+                         dc > 4 * CHOL_TILE_MAX_NT && dc <= 2 * GAIN_BLK && dc - GAIN_BLK >= 4;
     const int n_acc = status[2];
     int rc = (n_acc <= 0) ? MSCKF_NOOP : MSCKF_OK;
-    if (rc == MSCKF_OK && (status[0] != 0 || (blocked && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
+    if (rc == MSCKF_OK && (status[0] != 0 || (blocked && status[1] != 0))) rc = status[0] == 2 ? MSCKF_ERR_HIP : MSCKF_ERR_NOT_SPD;
     const char* hres = static_cast<const char*>(c->hRes);
     if (dx) {
         if (rc == MSCKF_OK) std::memcpy(dx, hres + c->res_dx_off, d * 8);

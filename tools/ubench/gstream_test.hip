@@ -1,0 +1,177 @@
+// Standalone check of k_gain_stream (csrc/k_gstream.h): the sequential block update against a dense CPU evaluation of
+// the reference's formulas (MSCKF.py:604-614), alone and beside a producer kernel that hands out the rows of T the way
+// the root sweep's flusher does (write-through stores, progress word), at a given pace.
+//   hipcc -O3 --offload-arch=gfx950 -I monocular-visual-inertial-msckf_amd/csrc -o build/gstream_test tools/ubench/gstream_test.hip
+//   build/gstream_test [N=30] [band=60] [us_per_row=0.6] [reps=20]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "k_gstream.h"
+
+using namespace msckf;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// one wavefront: rows of src -> dst (write-through), `gap` wall-clock ticks (10 ns) apart, progress after each drained row
+__global__ void k_producer(const double* src, double* dst, int dc, int ldt, int band, unsigned long long* progress, unsigned epoch, int gap) {
+    const int lane = threadIdx.x;
+    long long t_next = wall_clock64() + 2000;          // 20 us head start of the consumer
+    for (int c = 0; c < dc; ++c) {
+        while (wall_clock64() < t_next) __builtin_amdgcn_s_sleep(1);
+        t_next += gap;
+        for (int col = c + lane; col < dc && col < c + band; col += 64) gs_std(dst + (size_t)c * ldt + col, src[(size_t)c * ldt + col]);
+        if (lane == 0) gs_std(dst + (size_t)c * ldt + dc, src[(size_t)c * ldt + dc]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) gs_st(progress, ((unsigned long long)epoch << 32) | (unsigned)(c + 1));
+    }
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 30;
+    const int band = argc > 2 ? atoi(argv[2]) : 60;
+    const double us_row = argc > 3 ? atof(argv[3]) : 0.6;
+    const int reps = argc > 4 ? atoi(argv[4]) : 20;
+    const int dc = 6 * N, d = 15 + dc, ldt = dc + 1;
+    const int nb = (dc + 15) / 16, ns = nb + 1;
+    const int ncb = std::min(nb, (16 + band - 1 + 15) / 16);
+    const double sigma2 = 0.04;
+    std::mt19937_64 rng(1234);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    std::vector<double> T((size_t)dc * ldt, 0.0), P((size_t)d * d), A((size_t)d * d);
+    for (int c = 0; c < dc; ++c) {
+        for (int col = c; col < dc && col < c + band; ++col) T[(size_t)c * ldt + col] = 3.0 * nd(rng);
+        T[(size_t)c * ldt + dc] = nd(rng);
+    }
+    for (auto& x : A) x = nd(rng);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += A[(size_t)i * d + k] * A[(size_t)j * d + k];
+            P[(size_t)i * d + j] = 1e-4 * s / d + (i == j ? 1e-3 : 0.0);
+        }
+    // ---- CPU: S = T Pcc T^T + s2 I, K = P[:,15:] T^T S^-1, dx = K r, P+ = P - K (P[:,15:] T^T)^T (exact-arithmetic Joseph) ----
+    std::vector<double> Y((size_t)d * dc), S((size_t)dc * dc), L((size_t)dc * dc, 0.0), X((size_t)d * dc), dx(d), Pn((size_t)d * d);
+    for (int i = 0; i < d; ++i)
+        for (int c = 0; c < dc; ++c) {
+            double s = 0.0;
+            for (int k = c; k < dc && k < c + band; ++k) s += P[(size_t)i * d + 15 + k] * T[(size_t)c * ldt + k];
+            Y[(size_t)i * dc + c] = s;
+        }
+    for (int a = 0; a < dc; ++a)
+        for (int b = 0; b < dc; ++b) {
+            double s = (a == b) ? sigma2 : 0.0;
+            for (int k = a; k < dc && k < a + band; ++k) s += T[(size_t)a * ldt + k] * Y[(size_t)(15 + k) * dc + b];
+            S[(size_t)a * dc + b] = s;
+        }
+    for (int j = 0; j < dc; ++j) {
+        double s = S[(size_t)j * dc + j];
+        for (int k = 0; k < j; ++k) s -= L[(size_t)j * dc + k] * L[(size_t)j * dc + k];
+        L[(size_t)j * dc + j] = std::sqrt(s);
+        for (int i = j + 1; i < dc; ++i) {
+            double v = S[(size_t)i * dc + j];
+            for (int k = 0; k < j; ++k) v -= L[(size_t)i * dc + k] * L[(size_t)j * dc + k];
+            L[(size_t)i * dc + j] = v / L[(size_t)j * dc + j];
+        }
+    }
+    std::vector<double> w(dc);
+    for (int j = 0; j < dc; ++j) {
+        double v = T[(size_t)j * ldt + dc];
+        for (int k = 0; k < j; ++k) v -= L[(size_t)j * dc + k] * w[k];
+        w[j] = v / L[(size_t)j * dc + j];
+    }
+    for (int i = 0; i < d; ++i) {
+        for (int j = 0; j < dc; ++j) {
+            double v = Y[(size_t)i * dc + j];
+            for (int k = 0; k < j; ++k) v -= X[(size_t)i * dc + k] * L[(size_t)j * dc + k];
+            X[(size_t)i * dc + j] = v / L[(size_t)j * dc + j];
+        }
+        double s = 0.0;
+        for (int j = 0; j < dc; ++j) s += X[(size_t)i * dc + j] * w[j];
+        dx[i] = s;
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double s = P[(size_t)i * d + j];
+            for (int k = 0; k < dc; ++k) s -= X[(size_t)i * dc + k] * X[(size_t)j * dc + k];
+            Pn[(size_t)i * d + j] = s;
+        }
+    // ---- device ----
+    double *dP, *dT, *dTsrc, *dEx, *dDx, *dPout;
+    unsigned long long *dFlag, *dProg;
+    int* dStatus;
+    CK(hipMalloc(&dP, P.size() * 8)); CK(hipMalloc(&dT, T.size() * 8)); CK(hipMalloc(&dTsrc, T.size() * 8));
+    CK(hipMalloc(&dEx, (size_t)nb * ns * 256 * 8)); CK(hipMalloc(&dFlag, (size_t)nb * ns * 8 + 64)); CK(hipMalloc(&dProg, 64));
+    CK(hipMalloc(&dDx, d * 8)); CK(hipMalloc(&dPout, P.size() * 8)); CK(hipMalloc(&dStatus, 64));
+    CK(hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dTsrc, T.data(), T.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dFlag, 0, (size_t)nb * ns * 8 + 64)); CK(hipMemset(dProg, 0, 64));
+    hipStream_t sa, sb;
+    CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipEvent_t e0, e1, e2;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    const size_t lds = std::max<size_t>(gstream_lds_doubles(ns, ncb) * 8, 100 * 1024);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_stream<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    GStreamArgs a{};
+    a.P = dP; a.ldp = d; a.T = dT; a.ldt = ldt; a.ex = dEx; a.exflag = dFlag; a.dx = dDx; a.Pout = dPout; a.ldo = d;
+    a.status = dStatus; a.sigma2 = sigma2; a.d = d; a.dc = dc; a.nb = nb; a.ns = ns; a.ncb = ncb;
+    unsigned epoch = 0;
+    auto launch = [&](hipStream_t st) {
+        if (ns <= 16) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
+        else hipLaunchKernelGGL(k_gain_stream<2>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
+    };
+    auto check = [&](const char* what) -> int {
+        std::vector<double> hdx(d), hP((size_t)d * d);
+        int st = -1;
+        if (hipMemcpy(hdx.data(), dDx, d * 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        if (hipMemcpy(hP.data(), dPout, hP.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        if (hipMemcpy(&st, dStatus, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        double n1 = 0, e1 = 0, n2 = 0, e2 = 0, asym = 0;
+        for (int i = 0; i < d; ++i) { n1 += dx[i] * dx[i]; e1 += (hdx[i] - dx[i]) * (hdx[i] - dx[i]); }
+        for (size_t i = 0; i < hP.size(); ++i) { n2 += Pn[i] * Pn[i]; e2 += (hP[i] - Pn[i]) * (hP[i] - Pn[i]); }
+        for (int i = 0; i < d; ++i) for (int j = 0; j < i; ++j) asym = std::max(asym, std::fabs(hP[(size_t)i * d + j] - hP[(size_t)j * d + i]));
+        std::printf("%s: status %d  rel err dx %.3e  P+ %.3e  max |P+ - P+^T| %.3e\n", what, st, std::sqrt(e1 / n1), std::sqrt(e2 / n2), asym);
+        return (st == 0 && std::sqrt(e1 / n1) < 1e-9 && std::sqrt(e2 / n2) < 1e-9) ? 0 : 2;
+    };
+    int rc = 0;
+    // (1) alone: T complete, no progress word
+    CK(hipMemcpy(dT, T.data(), T.size() * 8, hipMemcpyHostToDevice));
+    a.progress = nullptr; a.epoch = ++epoch;
+    launch(sb);
+    CK(hipStreamSynchronize(sb));
+    rc |= check("standalone");
+    {
+        float best = 1e9f, sum = 0.f;
+        for (int it = 0; it < reps; ++it) {
+            a.epoch = ++epoch;
+            CK(hipEventRecord(e0, sb)); launch(sb); CK(hipEventRecord(e1, sb)); CK(hipEventSynchronize(e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms); sum += ms;
+        }
+        std::printf("standalone kernel: best %.1f us, mean %.1f us (N = %d, %d row blocks, %d strips, %d column blocks per row block)\n",
+                    best * 1e3, sum / reps * 1e3, N, nb, ns, ncb);
+        rc |= check("standalone (last rep)");
+    }
+    // (2) beside the producer
+    const int gap = (int)std::lround(us_row * 100.0);
+    float tail_best = 1e9f, tail_sum = 0.f;
+    for (int it = 0; it < reps; ++it) {
+        CK(hipMemsetAsync(dT, 0, T.size() * 8, sa));
+        CK(hipStreamSynchronize(sa));
+        a.progress = dProg; a.epoch = ++epoch;
+        hipLaunchKernelGGL(k_producer, dim3(1), dim3(64), 0, sa, dTsrc, dT, dc, ldt, band, dProg, epoch, gap);
+        CK(hipEventRecord(e1, sa));
+        launch(sb);
+        CK(hipEventRecord(e2, sb));
+        CK(hipStreamSynchronize(sa)); CK(hipStreamSynchronize(sb));
+        float ms = 0; CK(hipEventElapsedTime(&ms, e1, e2));
+        tail_best = std::min(tail_best, ms); tail_sum += ms;
+        if (it == 0 || it == reps - 1) rc |= check("beside the producer");
+    }
+    std::printf("producer at %.2f us per row (%.0f us): consumer ends %.1f us (best), %.1f us (mean) after the producer\n",
+                us_row, us_row * dc, tail_best * 1e3, tail_sum / reps * 1e3);
+    std::printf(rc == 0 ? "OK\n" : "FAILED\n");
+    return rc;
+}
