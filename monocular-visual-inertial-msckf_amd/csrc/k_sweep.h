@@ -85,6 +85,10 @@ namespace msckf {
 __host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nf, int wpf) {
     return ((size_t)wtot * SWEEP_RS + (size_t)nf * wpf * 64 + 2) * 8;   // R | dump words | zero words
 }
+// ... with the flusher's table (nsteps + 1 ints) behind them
+__host__ __device__ inline size_t sweep_lds_bytes_fl(int wtot, int nf, int nsteps) {
+    return sweep_lds_bytes(wtot, nf, 1) + (((size_t)nsteps + 2) * 4 + 15) / 16 * 16;
+}
 
 // Sum over the 4 lanes of a DPP quad; every lane of the quad gets the sum.
 template <int CTRL>
@@ -178,6 +182,11 @@ __global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepA
 
     for (int e = t; e < nd.wtot * SWEEP_RS; e += NT) Rb[e] = 0.0;
     if (t < 2) smem[nd.wtot * SWEEP_RS + NW * 64 + t] = 0.0;
+    int* ftab = reinterpret_cast<int*>(smem + (size_t)nd.wtot * SWEEP_RS + NW * 64 + 2);
+    if constexpr (FL) {
+        // (the flusher reads its table from LDS: a vector-memory load per step would make it wait for its own stores)
+        for (int e = t; e <= nsteps; e += NT) ftab[e] = p.flush_tab[e];
+    }
     // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
     const SweepFold f0 = p.folds[nd.fold_begin];
     const int adopt = (nd.fold_end > nd.fold_begin && f0.t0 == 0) ? 1 : 0;
@@ -207,13 +216,11 @@ __global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepA
             int c1 = 0, c2 = 0;                     // vector-memory instructions issued one / two steps ago
             int l1 = 0, l2 = 0, l3 = 0;             // rows final one / two / three steps ago
             int published = 0;
-            int e_next = p.flush_tab[0];
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();           // R zeroed / adopted
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // R zeroed / adopted, table in place
             asm volatile("" ::: "memory");
             for (int ts = 0; ts <= nsteps; ++ts) {
-                const int e = __builtin_amdgcn_readfirstlane(e_next);
-                if (ts < nsteps) e_next = p.flush_tab[ts + 1];
+                const int e = __builtin_amdgcn_readfirstlane(ftab[ts]);
                 const int lo = e & 0xFFFF, n = e >> 16;
                 for (int c = lo; c < lo + n; ++c) {
                     const double x = Rb[(size_t)c * SWEEP_RS + lane];

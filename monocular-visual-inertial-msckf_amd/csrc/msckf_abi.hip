@@ -1219,14 +1219,14 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band, bool beside, 
 }
 // The root sweep (k_sweep form) with its flusher on c->stream and K6-K7 beside it on c->stream2; c->stream continues
 // behind both.  `a` carries the tables and the node index; mid_ev (optional) is recorded behind the sweep.
-int launch_root_and_gain(msckf_ctx* c, SweepArgs a, int wtot, const int* flush_tab, const double* Tblk, int band, hipEvent_t mid_ev) {
+int launch_root_and_gain(msckf_ctx* c, SweepArgs a, int wtot, int nsteps, const int* flush_tab, const double* Tblk, int band, hipEvent_t mid_ev) {
     ++c->gs_epoch;
     a.flush_tab = flush_tab;
     a.progress = ptr<unsigned long long>(c->dGsProg);
     a.epoch = c->gs_epoch;
     a.stamps = nullptr;
     HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
-    hipLaunchKernelGGL((k_sweep<SWEEP_NW, 1, false, true>), dim3(1), dim3(64 * (SWEEP_NW + 1)), sweep_lds_bytes(wtot, SWEEP_NW, 1), c->stream, a);
+    hipLaunchKernelGGL((k_sweep<SWEEP_NW, 1, false, true>), dim3(1), dim3(64 * (SWEEP_NW + 1)), sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps), c->stream, a);
     HIPCHK(c, hipGetLastError());
     if (mid_ev) HIPCHK(c, hipEventRecord(mid_ev, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pre, 0));
@@ -1287,7 +1287,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         a.rbuf = ptr<double>(c->dRbuf);
         a.zero = ptr<double>(c->dRbuf) + c->zero_off;
         a.node_base = c->n_group_merges;
-        if ((rc = launch_root_and_gain(c, a, c->snodes.back().wtot, ptr<int>(c->dRootFlush), root_block(c), c->root_band,
+        if ((rc = launch_root_and_gain(c, a, c->snodes.back().wtot, c->snodes.back().nsteps, ptr<int>(c->dRootFlush), root_block(c), c->root_band,
                                        stage_ev ? stage_ev[2] : nullptr)) != MSCKF_OK) return rc;
     } else {
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
@@ -2590,7 +2590,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     a.node_base = nb + c->x_n_merges;
     int rc;
     if (gstream_ok(c, XW) && c->gs_overlap && !c->x_root_flush.empty()) {
-        rc = launch_root_and_gain(c, a, dc, ptr<int>(c->dXRootFlush), rb + c->x_root_off, XW, nullptr);
+        rc = launch_root_and_gain(c, a, dc, c->x_snodes.back().nsteps, ptr<int>(c->dXRootFlush), rb + c->x_root_off, XW, nullptr);
     } else {
         hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF, SWEEP_P2P>), dim3(1), block, sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF), c->stream, a);
         HIPCHK(c, hipGetLastError());
