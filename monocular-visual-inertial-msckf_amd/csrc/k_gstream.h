@@ -38,22 +38,28 @@
 #include <hip/hip_runtime.h>
 #include "wave_ops.h"
 #include "k_gain.h"
+#include "k_sweep.h"
 
 namespace msckf {
 
 typedef __attribute__((address_space(1))) unsigned long long gs_gu64;
+#ifndef GS_SCOPE
+#define GS_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
 __device__ __forceinline__ unsigned long long gs_ld(const void* p) {
-    return __hip_atomic_load((const gs_gu64*)(const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load((const gs_gu64*)(const unsigned long long*)p, __ATOMIC_RELAXED, GS_SCOPE);
 }
 __device__ __forceinline__ double gs_ldd(const double* p) { return __longlong_as_double((long long)gs_ld(p)); }
 __device__ __forceinline__ void gs_st(void* p, unsigned long long v) {
-    __hip_atomic_store((gs_gu64*)(unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gs_gu64*)(unsigned long long*)p, v, __ATOMIC_RELAXED, GS_SCOPE);
 }
 __device__ __forceinline__ void gs_std(double* p, double v) { gs_st(p, (unsigned long long)__double_as_longlong(v)); }
 
 constexpr int GS_WAVES = 16;                 // wavefronts per workgroup: tile wavefronts 0 .., wavefront 15 also eliminates
 constexpr int GS_PUB_WAVE = 14;              // publishes the strip's Y tile
 constexpr int GS_MAX_NS = 32;                // strips (two tiles per wavefront)
+constexpr int GS_XS = 17;                    // X tiles in LDS: [column][row] with columns 17 doubles apart (a stride of 16 put a
+constexpr int GS_XT = 16 * GS_XS;            //  wavefront's store on four bank pairs: 1.2 us per row block for thirteen tiles)
 constexpr long long GS_TIMEOUT_TICKS = 50000000LL;   // 0.5 s of the 100 MHz wall clock
 
 struct GStreamArgs {
@@ -62,21 +68,39 @@ struct GStreamArgs {
     const unsigned long long* progress;      // (epoch << 32) | rows of T that are final; null: all rows are (standalone)
     unsigned epoch;
     double* ex;                              // exchange tiles [nb][ns][256]
-    unsigned long long* exflag;              // [nb][ns]: (epoch << 32) | (I + 1)
+    unsigned long long* exflag;              // [nb][ns]: (epoch, row block + 1) in the upper 32 bits
     double* dx; double* Pout; int ldo;
     int* status;                             // [0]: 0 ok, 1 a pivot was not a positive normal number, 2 timeout
     double sigma2;
     int d, dc, nb, ns, ncb;                  // nb row blocks of T, ns = nb + 1 strips, ncb column blocks per row block
+    long long* stamps;                       // -DGS_STAMPS builds: wall-clock stamps of workgroup 0, 8 per row block
 };
+#ifdef GS_STAMPS
+#define GS_STAMP(w, i) do { if (p.stamps && r == 0 && wv == (w) && lane == 0) p.stamps[I * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define GS_STAMP(w, i) do { } while (0)
+#endif
 
+// Row blocks of T: when 6 N is no multiple of 16 the SHORT block is the first one (rows [0, rem)), every other block has
+// 16 rows -- so the last block, the one that trails the sweep, is not preceded by a block that became final moments
+// before it (with the short block last, two blocks' worth of work trailed the sweep).
+// 16-column strips a row block meets when its rows are `band` columns wide (any alignment of the block against the strips)
+__host__ __device__ inline int gstream_ncb(int dc, int band) {
+    const int nb = (dc + 15) / 16, rem = dc - 16 * (nb - 1);
+    const int bw = band < dc ? band : dc;
+    const int n = ((rem & 15) + 15 + bw - 1) / 16 + 1;
+    return n < nb ? (n < 1 ? 1 : n) : nb;
+}
 __host__ __device__ inline size_t gstream_lds_doubles(int ns, int ncb) {
-    // multipliers [2][16][17] | 1 / l_cc [2][16] | control words | Y partials [ncb][256] | A partials [ncb][256] | X [ns][256]
-    return 544 + 32 + 16 + (size_t)2 * ncb * 256 + (size_t)ns * 256;
+    // multipliers [2][16][17] | 1 / l_cc [2][16] | control words | Y partials [ncb][256] | A partials [ncb][256] | X [ns][GS_XT]
+    return 544 + 32 + 16 + (size_t)2 * ncb * 256 + (size_t)ns * GS_XT;
 }
 
 // In-wave elimination of a 16 x 16 SPD block in the accumulator layout (k_chol16's D phase, see k_gain.h): per pivot
 // the row of multipliers m_c = -a_cp / a_pp and the progress word go to sw_half ([16][17] doubles), 1 / l_cc to sri.
 // Returns true when a pivot is not a positive normal number.
+// NPIV: pivots to run (the last row block of T may hold fewer than 16 rows: the rest of its A_I is sigma^2 on the diagonal).
+template <int NPIV>
 __device__ __forceinline__ bool gs_eliminate(double (&d)[4], unsigned sw_half, double* sri, int lane) {
     const int g = lane >> 4, cc = lane & 15, cc4 = cc * 4;
     const unsigned w_out = sw_half + lane * 8;
@@ -97,7 +121,7 @@ __device__ __forceinline__ bool gs_eliminate(double (&d)[4], unsigned sw_half, d
         const double e = fma(-piv, r, 1.0);
         const double w = lcm * r;
         const double w2 = fma(w, e, w);
-        if constexpr (P < 15) {
+        if constexpr (P < NPIV - 1) {
             asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d[IN]) : "v"(w2), "i"(P));
             asm volatile("s_mov_b64 exec, 0x1ffff\n\tds_write_b64 %2, %3 offset:%4\n\ts_mov_b64 exec, -1\n\t"
                          "ds_bpermute_b32 %0, %5, %6 offset:%8\n\tds_bpermute_b32 %1, %5, %7 offset:%8"
@@ -112,11 +136,14 @@ __device__ __forceinline__ bool gs_eliminate(double (&d)[4], unsigned sw_half, d
                          : "+v"(d[(IN + 1) & 3]), "+v"(d[(IN + 2) & 3]), "+v"(d[(IN + 3) & 3]) : "v"(w2), "i"(P));
         }
     };
-    __builtin_amdgcn_s_setprio(3);
+#ifndef GS_ELIM_PRIO
+#define GS_ELIM_PRIO 3                       // (the elimination is the block's dependent chain: 1.6 us at priority 3, 2.0 at 0)
+#endif
+    if (GS_ELIM_PRIO) __builtin_amdgcn_s_setprio(GS_ELIM_PRIO);
     pivot(CTag<0>{}); pivot(CTag<1>{}); pivot(CTag<2>{}); pivot(CTag<3>{});
-    pivot(CTag<4>{}); pivot(CTag<5>{}); pivot(CTag<6>{}); pivot(CTag<7>{});
-    pivot(CTag<8>{}); pivot(CTag<9>{}); pivot(CTag<10>{}); pivot(CTag<11>{});
-    pivot(CTag<12>{}); pivot(CTag<13>{}); pivot(CTag<14>{}); pivot(CTag<15>{});
+    if constexpr (NPIV > 4) { pivot(CTag<4>{}); pivot(CTag<5>{}); pivot(CTag<6>{}); pivot(CTag<7>{}); }
+    if constexpr (NPIV > 8) { pivot(CTag<8>{}); pivot(CTag<9>{}); pivot(CTag<10>{}); pivot(CTag<11>{}); }
+    if constexpr (NPIV > 12) { pivot(CTag<12>{}); pivot(CTag<13>{}); pivot(CTag<14>{}); pivot(CTag<15>{}); }
     // the pivots are the diagonal as it stands now: lane (g, c) picks register c >> 2 and takes it from row group c & 3
     double pivs;
     {
@@ -129,18 +156,20 @@ __device__ __forceinline__ bool gs_eliminate(double (&d)[4], unsigned sw_half, d
     const double ri = bad ? 1.0 : fast_rsqrt(pivs);
     asm volatile("" ::: "memory");
     if (g == 0) sri[cc] = ri;
-    __builtin_amdgcn_s_setprio(0);
+    if (GS_ELIM_PRIO) __builtin_amdgcn_s_setprio(0);
     return bad;
 }
 
 // A tile (any 16 rows x the block's 16 columns, accumulator layout) follows the pivots of gs_eliminate:
 // a <- a L^-T (k_chol16's panel owners), four pivots per poll of the progress words.
+template <int NPIV>
 __device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const double* sri, int lane) {
+    constexpr int LASTM = NPIV - 2;                                  // the last pivot with multipliers
     const int cc = lane & 15;
     const unsigned w_cc = w_in + cc * 8;
     auto follow4 = [&](auto tagp) {
         constexpr int P0 = decltype(tagp)::value;
-        constexpr int PL = (P0 + 3 < 14) ? P0 + 3 : 14;              // the last pivot with multipliers
+        constexpr int PL = (P0 + 3 < LASTM) ? P0 + 3 : LASTM;
         double* ap = a0;
         const unsigned win_l = w_in, wcc_l = w_cc;
         int spins = 0;
@@ -156,7 +185,7 @@ __device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const 
         double m0, m1, m2, m3 = 0.0;
         asm volatile("ds_read_b64 %0, %3 offset:%4\n\tds_read_b64 %1, %3 offset:%5\n\tds_read_b64 %2, %3 offset:%6"
                      : "=&v"(m0), "=&v"(m1), "=&v"(m2) : "v"(wcc_l), "i"(P0 * 17 * 8), "i"((P0 + 1) * 17 * 8), "i"((P0 + 2) * 17 * 8) : "memory");
-        if constexpr (P0 + 3 < 15) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m3) : "v"(wcc_l), "i"((P0 + 3) * 17 * 8) : "memory");
+        if constexpr (P0 + 3 <= LASTM) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m3) : "v"(wcc_l), "i"((P0 + 3) * 17 * 8) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)::"memory");
 #define GS_FOLLOW1(PP, M)                                                                                                \
     asm volatile("s_nop 1\n\t"                                                                                          \
@@ -168,10 +197,13 @@ __device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const 
         GS_FOLLOW1(P0, m0);
         GS_FOLLOW1(P0 + 1, m1);
         GS_FOLLOW1(P0 + 2, m2);
-        if constexpr (P0 + 3 < 15) GS_FOLLOW1(P0 + 3, m3);
+        if constexpr (P0 + 3 <= LASTM) GS_FOLLOW1(P0 + 3, m3);
 #undef GS_FOLLOW1
     };
-    follow4(CTag<0>{}); follow4(CTag<4>{}); follow4(CTag<8>{}); follow4(CTag<12>{});
+    follow4(CTag<0>{});
+    if constexpr (NPIV > 4) follow4(CTag<4>{});
+    if constexpr (NPIV > 8) follow4(CTag<8>{});
+    if constexpr (NPIV > 12) follow4(CTag<12>{});
     double ri = 0.0;
     {
         const unsigned ri_addr = lds_addr(sri + cc);
@@ -186,30 +218,34 @@ __device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const 
     for (int i = 0; i < 4; ++i) a0[i] *= ri;
 }
 
-template <int TPW>
-__global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
+// WV wavefronts; wavefront wv holds the tiles s = wv + WV q, q < TPW; wavefront WV - 1 also eliminates, WV - 2 also publishes.
+template <int WV, int TPW>
+__device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int r) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int g = lane >> 4, cc = lane & 15;
-    const int r = blockIdx.x;
     const int d = p.d, dc = p.dc, nb = p.nb, ns = p.ns, ncb = p.ncb;
     double* sW = smem;                                   // [2][16][17]
     double* sRi = smem + 544;                            // [2][16]
-    volatile int* sCtl = reinterpret_cast<volatile int*>(smem + 576);   // [0] bad pivot, [1] timeout
+    // ([0] bad pivot, [1] timeout; an LDS pointer by type: a volatile generic one compiles to flat accesses that wait for vmcnt)
+    typedef __attribute__((address_space(3))) int gs_lds_int;
+    volatile gs_lds_int* sCtl = (volatile gs_lds_int*)(gs_lds_int*)(int*)(smem + 576);
     double* sPartY = smem + 592;                         // [ncb][256]
     double* sPartA = sPartY + (size_t)ncb * 256;         // [ncb][256]
-    double* sX = sPartA + (size_t)ncb * 256;             // [ns][256], operand order [column][row]
+    double* sX = sPartA + (size_t)ncb * 256;             // [ns][GS_XT], operand order [column][row], column stride GS_XS
     const unsigned sw_addr = lds_addr(sW);
     auto g0 = [&](int s) { return s == 0 ? 0 : 15 + 16 * (s - 1); };
     auto nrows = [&](int s) { return s == 0 ? 15 : min(16, d - (15 + 16 * (s - 1))); };
     const int gr = g0(r), nr = nrows(r);
-    const unsigned long long ep = (unsigned long long)p.epoch << 32;
+    const int rem0 = dc - 16 * (nb - 1);                 // rows of the first block of T (1 .. 16)
+    // flag values: (epoch, row block + 1) in the upper 32 bits; never 0 (the flags are zeroed once), never the value a
+    // previous launch left in the same place (the epoch differs)
 
     // tiles P(s, r), s = wv + 16 q, symmetrised as they are loaded (the reference symmetrises its result, MSCKF.py:614)
     double Pt[TPW][4];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int s = wv + 16 * q;
+        const int s = wv + WV * q;
         const int gsr = g0(min(s, ns - 1)), ms = (s < ns) ? nrows(s) : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -227,9 +263,11 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
     const long long t_start = wall_clock64();
     bool failed = false;
     for (int I = 0; I < nb; ++I) {
-        const int need = min(16 * (I + 1), dc);
+        const int row0 = (I == 0) ? 0 : rem0 + 16 * (I - 1), nrw = (I == 0) ? rem0 : 16;   // rows [row0, row0 + nrw) of T
+        const int need = row0 + nrw;
+        const unsigned long long tag = (unsigned long long)((p.epoch << 6) | (unsigned)(I + 1)) << 32;
         // ---- A: row block I of T is final -------------------------------------------------------------------
-        if (p.progress && wv == GS_WAVES - 1) {
+        if (p.progress && wv == WV - 1) {
             for (;;) {
                 const unsigned long long v = gs_ld(p.progress);
                 if ((v >> 32) == p.epoch && (int)(v & 0xffffffffu) >= need) break;
@@ -237,20 +275,21 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
                 __builtin_amdgcn_s_sleep(8);
             }
         }
+        GS_STAMP(WV - 1, 0);                                      // rows of T seen
         __syncthreads();
         if (sCtl[1]) { failed = true; break; }
-        const int s_lo = I + 1, s_hi = min(I + ncb, ns - 1);          // strips that hold T_I's columns
+        const int s_lo = 1 + (row0 >> 4), s_hi = min(s_lo + ncb - 1, ns - 1);   // strips that hold T_I's columns
         // ---- B: partials of Y_I[r] = sum_s P(r, s) T_{I,s}^T ------------------------------------------------
         double Tt[TPW][4];
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int s = wv + 16 * q;
+            const int s = wv + WV * q;
             if (s >= s_lo && s <= s_hi) {
-                const int trow = 16 * I + cc;
+                const int trow = row0 + cc;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int col = 16 * (s - 1) + 4 * u + g;
-                    const bool ok = trow < dc && col < dc;
+                    const bool ok = cc < nrw && col < dc;
                     const double x = gs_ldd(p.T + (ok ? (size_t)trow * p.ldt + col : 0));
                     Tt[q][u] = ok ? x : 0.0;
                 }
@@ -263,41 +302,47 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
             }
         }
         double rhs = 0.0;
-        if (wv == GS_PUB_WAVE && r == 0 && g == 3) {                   // r_n of this block: the dx row's share of Y
-            const int trow = 16 * I + cc;
-            const double x = gs_ldd(p.T + (trow < dc ? (size_t)trow * p.ldt + dc : 0));
-            rhs = trow < dc ? x : 0.0;
+        if (wv == WV - 2 && r == 0 && g == 3) {                   // r_n of this block: the dx row's share of Y
+            const int trow = row0 + cc;
+            const double x = gs_ldd(p.T + (cc < nrw ? (size_t)trow * p.ldt + dc : 0));
+            rhs = cc < nrw ? x : 0.0;
         }
+        GS_STAMP(WV - 1, 1);                                      // partials of Y written
         __syncthreads();
         // ---- C: publish Y_I[r] ---------------------------------------------------------------------------------
-        if (wv == GS_PUB_WAVE) {
+        if (wv == WV - 2) {
             double y[4] = {0.0, 0.0, 0.0, 0.0};
             for (int sl = 0; sl <= s_hi - s_lo; ++sl) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[i] += sPartY[(size_t)sl * 256 + 64 * i + lane];
             }
             y[3] += rhs;                                               // (row 15 of strip 0; zero elsewhere)
+            // payload write-through, drained, then the flag (MI355X_MICROARCH.md, inter-workgroup visibility, first table row).
+            // Tried and dropped: tagged 8-byte granules polled by their readers instead of a flag (no drain, no flag store:
+            // one round trip less on paper).  Readers that re-poll a line back to back keep being served the copy of their
+            // first miss (every launch but the first timed out; a sleep between polls or a buffer_inv sc1 cured it), and
+            // with the sleep the 4 KB sweeps of 13 x 13 wavefronts were slower than this: 108 against 90 us at N = 30.
             double* dst = p.ex + ((size_t)I * ns + r) * 256 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gs_std(dst + 64 * i, y[i]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) gs_st(p.exflag + (size_t)I * ns + r, ep | (unsigned)(I + 1));
+            if (lane == 0) gs_st(p.exflag + (size_t)I * ns + r, tag);
+            GS_STAMP(WV - 2, 2);                                   // published
         }
         // ---- D: fetch Y_I[s]; partials of A_I = sum_s T_{I,s} Y_I[s] -------------------------------------------
         double Yt[TPW][4];
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int s = wv + 16 * q;
+            const int s = wv + WV * q;
 #pragma unroll
             for (int i = 0; i < 4; ++i) Yt[q][i] = 0.0;
             if (s < ns) {
-                const unsigned long long want = ep | (unsigned)(I + 1);
                 const unsigned long long* fl = p.exflag + (size_t)I * ns + s;
                 bool ok = true;
                 for (;;) {
-                    if (gs_ld(fl) == want) break;
+                    if (gs_ld(fl) == tag) break;
                     if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) sCtl[1] = 1; ok = false; break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(2);                            // (never poll a line back to back: see above)
                 }
                 if (ok) {
                     const double* src = p.ex + ((size_t)I * ns + s) * 256 + lane;
@@ -314,12 +359,15 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
                 }
             }
         }
+        GS_STAMP(WV - 1, 3);                                      // all Y tiles of this wavefront fetched
         __syncthreads();
+        GS_STAMP(WV - 1, 4);
         // ---- E: eliminate A_I (one wavefront), every tile follows: X_I[s] = Y_I[s] L_II^-T ----------------------
+        const int npiv = (nrw + 3) & ~3;                                   // pivots of this block (16 but for a short first one)
         const int half = I & 1;
         const unsigned sw_half = sw_addr + half * (16 * 17 * 8);
         double* sri = sRi + half * 16;
-        if (wv == GS_WAVES - 1) {
+        if (wv == WV - 1) {
             double a[4] = {0.0, 0.0, 0.0, 0.0};
             for (int sl = 0; sl <= s_hi - s_lo; ++sl) {
 #pragma unroll
@@ -329,35 +377,48 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
             for (int i = 0; i < 4; ++i) if (g + 4 * i == cc) a[i] += p.sigma2;
             // the other half's words are reset for the next block (its followers have passed this block's first barrier)
             if (lane < 16) { sW[(half ^ 1) * 272 + lane * 17 + 16] = __longlong_as_double(CHOL16_UNSET); sRi[(half ^ 1) * 16 + lane] = 0.0; }
-            const bool bad = gs_eliminate(a, sw_half, sri, lane);
+            bool bad;
+            if (npiv == 16) bad = gs_eliminate<16>(a, sw_half, sri, lane);
+            else if (npiv == 12) bad = gs_eliminate<12>(a, sw_half, sri, lane);
+            else if (npiv == 8) bad = gs_eliminate<8>(a, sw_half, sri, lane);
+            else bad = gs_eliminate<4>(a, sw_half, sri, lane);
             if (bad && lane == 0) sCtl[0] = 1;
+            GS_STAMP(WV - 1, 5);                                  // eliminated
         }
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int s = wv + 16 * q;
+            const int s = wv + WV * q;
             if (s < ns) {
-                gs_follow(Yt[q], sw_half, sri, lane);
-                double* dst = sX + (size_t)s * 256 + cc * 16 + g;
+                if (npiv == 16) gs_follow<16>(Yt[q], sw_half, sri, lane);
+                else if (npiv == 12) gs_follow<12>(Yt[q], sw_half, sri, lane);
+                else if (npiv == 8) gs_follow<8>(Yt[q], sw_half, sri, lane);
+                else gs_follow<4>(Yt[q], sw_half, sri, lane);
+                GS_STAMP(0, 7);                                         // wavefront 0 has followed
+                double* dst = sX + (size_t)s * GS_XT + cc * GS_XS + g;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dst[4 * i] = Yt[q][i];      // [column][row]
             }
         }
+#ifdef GS_STAMPS
+        if (p.stamps && r == 0 && I == 5 && lane == 0) p.stamps[64 * 8 + wv] = wall_clock64();
+#endif
         __syncthreads();
+        GS_STAMP(WV - 1, 6);                                      // everybody has followed
         if (sCtl[0] | sCtl[1]) { failed = true; break; }
         // ---- F: P(s, r) -= X_I[s] X_I[r]^T ----------------------------------------------------------------------
         {
-            const double* xr = sX + (size_t)r * 256 + g * 16 + cc;
+            const double* xr = sX + (size_t)r * GS_XT + g * GS_XS + cc;
             double bv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bv[u] = xr[64 * u];
+            for (int u = 0; u < 4; ++u) bv[u] = xr[4 * GS_XS * u];
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
-                const int s = wv + 16 * q;
+                const int s = wv + WV * q;
                 if (s < ns) {
-                    const double* xs = sX + (size_t)s * 256 + g * 16 + cc;
+                    const double* xs = sX + (size_t)s * GS_XT + g * GS_XS + cc;
                     double av[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) av[u] = -xs[64 * u];
+                    for (int u = 0; u < 4; ++u) av[u] = -xs[4 * GS_XS * u];
                     v4d acc = {Pt[q][0], Pt[q][1], Pt[q][2], Pt[q][3]};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
@@ -375,7 +436,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
     // ---- P+ tiles and dx (= minus the augmented row) -----------------------------------------------------------
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int s = wv + 16 * q;
+        const int s = wv + WV * q;
         if (s < ns) {
             const int gsr = g0(s), ms = nrows(s);
 #pragma unroll
@@ -386,6 +447,24 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
             if (s == 0 && g == 3 && cc < nr) p.dx[gr + cc] = -Pt[q][3];
         }
     }
+}
+
+// alone (T complete, or a sweep kernel of another launch publishing it): one workgroup of 16 wavefronts per strip
+template <int TPW>
+__global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
+    gain_stream_body<GS_WAVES, TPW>(p, blockIdx.x);
+}
+
+// ONE launch for the root sweep and the update that follows it: workgroup 0 is the sweep (NF fold wavefronts + the
+// flusher), workgroups 1 .. ns the strips of the update (NF + 1 wavefronts each, TPW tiles per wavefront).  The strips
+// wait for rows workgroup 0 publishes: workgroup 0 is dispatched first, and every workgroup has the chip to itself (a
+// grid of at most 33 workgroups that ask for more than half of a CU's LDS), so all of them are resident at once.
+// (As two launches on two streams the pair cost an event record in front of the sweep and a cross-stream wait behind
+//  the update: ~17 us per update around ~225 us of kernels.)
+template <int NF, int TPW>
+__global__ __launch_bounds__(64 * (NF + 1)) void k_root_gain(SweepArgs sp, GStreamArgs gp) {
+    if (blockIdx.x == 0) sweep_body<NF, 1, false, true>(sp);
+    else gain_stream_body<NF + 1, TPW>(gp, (int)blockIdx.x - 1);
 }
 
 }  // namespace msckf

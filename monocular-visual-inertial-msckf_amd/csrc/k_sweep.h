@@ -159,8 +159,8 @@ template <int KK> struct STag { static constexpr int value = KK; };
 // hence one instantiation of the step per column of a 16-column period (KK, J).  The four row lanes' partial dots
 // are reduce-scattered with the lane swaps (row r ends up with the dot of column slot r: 6 swaps and 3 additions)
 // and tau goes back the same way.
-template <int NF, int WPF, bool P2P = false, bool FL = false>
-__global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepArgs p) {
+template <int NF, int WPF, bool P2P, bool FL>
+__device__ __forceinline__ void sweep_body(const SweepArgs& p) {
     static_assert(WPF == 1 && !P2P, "one wavefront per fold, one barrier per macro step");
     constexpr int NW = NF;              // fold wavefronts
     constexpr int NT = 64 * (NF + (FL ? 1 : 0));   // threads: with FL one more wavefront, the flusher
@@ -216,6 +216,7 @@ __global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepA
             int c1 = 0, c2 = 0;                     // vector-memory instructions issued one / two steps ago
             int l1 = 0, l2 = 0, l3 = 0;             // rows final one / two / three steps ago
             int published = 0;
+            const int boff = (16 - (wtot & 15)) & 15;   // k_gstream.h's row blocks end at rows = wtot (mod 16)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // R zeroed / adopted, table in place
             asm volatile("" ::: "memory");
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepA
                     }
                 }
                 int issued = n;
-                if (l3 > published) {
+                if (((l3 + boff) >> 4) > ((published + boff) >> 4)) {   // (the reader takes rows in blocks of 16, the short block first)
                     // the stores of rows < l3 were issued three steps ago or earlier: c2 + c1 + n instructions since
                     const int m = c2 + c1 + n;
                     switch (m < 7 ? m : 7) {
@@ -429,6 +430,11 @@ __global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepA
         for (int q = 0; q < 8; ++q) o[q] = prof[q];
     }
 #endif
+}
+
+template <int NF, int WPF, bool P2P = false, bool FL = false>
+__global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepArgs p) {
+    sweep_body<NF, WPF, P2P, FL>(p);
 }
 
 }  // namespace msckf

@@ -329,16 +329,14 @@ struct msckf_ctx {
     bool oneshot = false;                 // msckf_update: set_features uploads, launches K1-K4 and plans K5 meanwhile, no sync
     bool feature_launched = false;        // K1-K4 of the current batch is already in the stream (oneshot)
     HostPool* pool = nullptr;             // host worker threads for the pack loops (CPU work only)
-    // K6-K7 beside the root sweep (k_gstream.h): the sequential block update polls the rows the sweep's flusher publishes
-    hipStream_t stream2 = nullptr;        // k_gain_stream runs here while the root sweep runs on `stream`
-    hipEvent_t ev_pre = nullptr, ev_gain = nullptr;
+    // K6-K7 beside the root sweep (k_gstream.h, k_root_gain): the sequential block update polls the rows the sweep's flusher publishes
     Buf dGsEx, dGsFlag, dGsProg;          // exchange tiles [nb][ns][256], their flags, the sweep's progress word
     Buf dRootFlush, dXRootFlush;          // flush tables of the root sweeps (rows final at the head of every macro step): local plan, merge plan
     std::vector<int> h_root_flush;        // ... of the local plan's root (band plan, k_sweep form)
     std::vector<int> x_root_flush;        // ... of the merge plan's root (msckf_run_merge_groups)
     unsigned gs_epoch = 0;                // tag of the current launch pair in the progress word and the exchange flags
     bool gs_enabled = true;               // MSCKF_GAIN_STREAM=0: the round-3 K6-K7 (separate launches behind the root sweep)
-    bool gs_overlap = true;               // MSCKF_GAIN_OVERLAP=0: k_gain_stream alone, behind the root sweep
+    bool gs_overlap = true;               // MSCKF_GAIN_OVERLAP=0: k_gain_stream as a launch of its own behind the root sweep
     int root_band = 0;                    // widest row of the root block in columns (the local plan's / the merge plan's)
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
@@ -1184,22 +1182,16 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
 }
 
 // ---- K6-K7 as the sequential block update of k_gstream.h ---------------------------------------------------------
-// 16-column blocks a 16-row block of the root spans when its rows are `band` columns wide
-inline int gstream_ncb(int dc, int band) {
-    const int nb = (dc + 15) / 16;
-    return std::max(1, std::min(nb, (std::min(band, dc) + 15 + 15) / 16));
-}
 bool gstream_ok(const msckf_ctx* c, int band) {
     if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || c->dc < 1) return false;
     const int nb = (c->dc + 15) / 16, ns = nb + 1;
     if (ns > GS_MAX_NS) return false;
     return gstream_lds_doubles(ns, gstream_ncb(c->dc, band)) * 8 <= (size_t)(LDS_MAX_BYTES - 1024);
 }
-// Tblk: the root block [T | r_n]; band: its widest row in columns; beside: the root sweep is running (or about to) on
-// c->stream with its flusher publishing rows under c->gs_epoch -- else T is complete and nothing is polled
-int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band, bool beside, hipStream_t st) {
-    const int d = c->d, dc = c->dc, nb = (dc + 15) / 16, ns = nb + 1, ncb = gstream_ncb(dc, band);
-    GStreamArgs a{};
+// Tblk: the root block [T | r_n]; band: its widest row in columns
+void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int band, bool beside) {
+    const int d = c->d, dc = c->dc, nb = (dc + 15) / 16;
+    a = GStreamArgs{};
     a.P = ptr<double>(c->dP); a.ldp = d;
     a.T = Tblk; a.ldt = dc + 1;
     a.progress = beside ? ptr<unsigned long long>(c->dGsProg) : nullptr;
@@ -1208,31 +1200,39 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band, bool beside, 
     a.dx = ptr<double>(c->dDx); a.Pout = ptr<double>(c->dPout); a.ldo = d;
     a.status = ptr<int>(c->dStatus);
     a.sigma2 = c->sigma * c->sigma;
-    a.d = d; a.dc = dc; a.nb = nb; a.ns = ns; a.ncb = ncb;
-    // (at least 100 KB of LDS: the workgroups of this kernel never share a CU with the root sweep's)
-    const size_t lds = std::max<size_t>(gstream_lds_doubles(ns, ncb) * 8, (size_t)100 * 1024);
-    if (ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
-    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
+    a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
+    a.stamps = nullptr;
+}
+// K6-K7 behind a complete root block: nothing is polled
+int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
+    ++c->gs_epoch;
+    GStreamArgs a;
+    fill_gstream_args(c, a, Tblk, band, false);
+    const size_t lds = gstream_lds_doubles(a.ns, a.ncb) * 8;
+    if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
+    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     c->gain_blocked = false;
     return MSCKF_OK;
 }
-// The root sweep (k_sweep form) with its flusher on c->stream and K6-K7 beside it on c->stream2; c->stream continues
-// behind both.  `a` carries the tables and the node index; mid_ev (optional) is recorded behind the sweep.
-int launch_root_and_gain(msckf_ctx* c, SweepArgs a, int wtot, int nsteps, const int* flush_tab, const double* Tblk, int band, hipEvent_t mid_ev) {
+// The root sweep (k_sweep form) and K6-K7 in ONE launch (k_root_gain): workgroup 0 sweeps and publishes the rows of the
+// root block as they become final, workgroups 1.. are the strips of the update.  `sa` carries the tables and the node index.
+bool root_gain_ok(const msckf_ctx* c, int band) {
+    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 2 * (SWEEP_NW + 1);
+}
+int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const int* flush_tab, const double* Tblk, int band) {
     ++c->gs_epoch;
-    a.flush_tab = flush_tab;
-    a.progress = ptr<unsigned long long>(c->dGsProg);
-    a.epoch = c->gs_epoch;
-    a.stamps = nullptr;
-    HIPCHK(c, hipEventRecord(c->ev_pre, c->stream));
-    hipLaunchKernelGGL((k_sweep<SWEEP_NW, 1, false, true>), dim3(1), dim3(64 * (SWEEP_NW + 1)), sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps), c->stream, a);
+    sa.flush_tab = flush_tab;
+    sa.progress = ptr<unsigned long long>(c->dGsProg);
+    sa.epoch = c->gs_epoch;
+    sa.stamps = nullptr;
+    GStreamArgs ga;
+    fill_gstream_args(c, ga, Tblk, band, true);
+    // (every workgroup asks for more than half of a CU's LDS: one per CU, the sweep has its CU to itself)
+    const size_t lds = std::max<size_t>(std::max(sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps), gstream_lds_doubles(ga.ns, ga.ncb) * 8), (size_t)84 * 1024);
+    hipLaunchKernelGGL((k_root_gain<SWEEP_NW, 2>), dim3(1 + ga.ns), dim3(64 * (SWEEP_NW + 1)), lds, c->stream, sa, ga);
     HIPCHK(c, hipGetLastError());
-    if (mid_ev) HIPCHK(c, hipEventRecord(mid_ev, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_pre, 0));
-    if (int rc = launch_gain_stream(c, Tblk, band, true, c->stream2)) return rc;
-    HIPCHK(c, hipEventRecord(c->ev_gain, c->stream2));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gain, 0));
+    c->gain_blocked = false;
     return MSCKF_OK;
 }
 
@@ -1269,9 +1269,9 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c)) != MSCKF_OK) return rc;
     if (c->F > 0 && !c->band_plan && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
-    // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront, k_gain_stream on the second stream
+    // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront and the update's strips in ONE launch
     const bool gs = with_gain && c->F > 0 && c->root >= 0 && gstream_ok(c, c->root_band);
-    const bool beside = gs && c->band_plan && c->sweep_mode == 0 && c->gs_overlap && !c->h_root_flush.empty();
+    const bool beside = gs && c->band_plan && c->sweep_mode == 0 && !c->h_root_flush.empty() && root_gain_ok(c, c->root_band);
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, (with_gain || !c->xchg_planned) && !beside)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
         // (with msckf_set_exchange_mask the shard's gate bytes ride behind it, in input order)
@@ -1287,12 +1287,15 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         a.rbuf = ptr<double>(c->dRbuf);
         a.zero = ptr<double>(c->dRbuf) + c->zero_off;
         a.node_base = c->n_group_merges;
-        if ((rc = launch_root_and_gain(c, a, c->snodes.back().wtot, c->snodes.back().nsteps, ptr<int>(c->dRootFlush), root_block(c), c->root_band,
-                                       stage_ev ? stage_ev[2] : nullptr)) != MSCKF_OK) return rc;
+        // (one launch: the stage boundary K5 | K6-K7 is not observable; the events report the pair under K5 and only what
+        //  trails the launch -- nothing -- under K6-K7)
+        if ((rc = launch_root_and_gain(c, a, c->snodes.back().wtot, c->snodes.back().nsteps, ptr<int>(c->dRootFlush), root_block(c),
+                                       c->root_band)) != MSCKF_OK) return rc;
+        if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     } else {
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
         if (with_gain && c->F > 0 && c->root >= 0) {
-            if (gs) { ++c->gs_epoch; rc = launch_gain_stream(c, root_block(c), c->root_band, false, c->stream); }
+            if (gs) rc = launch_gain_stream(c, root_block(c), c->root_band);
             else rc = launch_gain(c, root_block(c));
             if (rc != MSCKF_OK) return rc;
         }
@@ -1349,7 +1352,6 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { msckf_destroy(c); return MSCKF_ERR_HIP; }
     {
         const char* e1 = std::getenv("MSCKF_GAIN_STREAM");
         const char* e2 = std::getenv("MSCKF_GAIN_OVERLAP");
@@ -1362,8 +1364,6 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     const char* cwhat = "";
     auto CK = [&](hipError_t e, const char* what) { if (cerr == hipSuccess && e != hipSuccess) { cerr = e; cwhat = what; } };
     for (auto& e : c->ev) CK(hipEventCreate(&e), "hipEventCreate");
-    CK(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming), "hipEventCreate");
-    CK(hipEventCreateWithFlags(&c->ev_gain, hipEventDisableTiming), "hipEventCreate");
     auto lds_attr = [&](const void* f, int bytes, const char* what) {
         CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
     };
@@ -1389,7 +1389,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     }
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
-    lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, 1, false, true>), FOLD_LDS_BYTES, "k_sweep (flusher) LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_root_gain<SWEEP_NW, 2>), LDS_MAX_BYTES - 1024, "k_root_gain LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<1>), LDS_MAX_BYTES - 1024, "k_gain_stream<1> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<2>), LDS_MAX_BYTES - 1024, "k_gain_stream<2> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
@@ -1472,7 +1472,6 @@ void msckf_destroy(msckf_ctx* c) {
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
@@ -1485,9 +1484,6 @@ void msckf_destroy(msckf_ctx* c) {
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
-    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
-    if (c->ev_gain) (void)hipEventDestroy(c->ev_gain);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2310,7 +2306,7 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     // counters[0] decides OK / NOOP in get_result: mark "accepted" when any block is non-empty
     (void)N;
     int rc;
-    if (gstream_ok(c, dc)) { ++c->gs_epoch; rc = launch_gain_stream(c, root, dc, false, c->stream); }
+    if (gstream_ok(c, dc)) rc = launch_gain_stream(c, root, dc);
     else rc = launch_gain(c, root);
     if (rc != MSCKF_OK) return rc;
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, c->stream, ptr<int>(c->dStatus) + 2, (int)total_accepted);   // (shared result)
@@ -2565,7 +2561,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         }
         HIPCHK(c, hipGetLastError());
         int rcg;
-        if (gstream_ok(c, XW)) { ++c->gs_epoch; rcg = launch_gain_stream(c, rb + c->x_root_off, XW, false, c->stream); }
+        if (gstream_ok(c, XW)) rcg = launch_gain_stream(c, rb + c->x_root_off, XW);
         else rcg = launch_gain(c, rb + c->x_root_off);
         if (rcg != MSCKF_OK) return rcg;
         if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
@@ -2589,12 +2585,12 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     }
     a.node_base = nb + c->x_n_merges;
     int rc;
-    if (gstream_ok(c, XW) && c->gs_overlap && !c->x_root_flush.empty()) {
-        rc = launch_root_and_gain(c, a, dc, c->x_snodes.back().nsteps, ptr<int>(c->dXRootFlush), rb + c->x_root_off, XW, nullptr);
+    if (root_gain_ok(c, XW) && !c->x_root_flush.empty()) {
+        rc = launch_root_and_gain(c, a, dc, c->x_snodes.back().nsteps, ptr<int>(c->dXRootFlush), rb + c->x_root_off, XW);
     } else {
         hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF, SWEEP_P2P>), dim3(1), block, sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF), c->stream, a);
         HIPCHK(c, hipGetLastError());
-        if (gstream_ok(c, XW)) { ++c->gs_epoch; rc = launch_gain_stream(c, rb + c->x_root_off, XW, false, c->stream); }
+        if (gstream_ok(c, XW)) rc = launch_gain_stream(c, rb + c->x_root_off, XW);
         else rc = launch_gain(c, rb + c->x_root_off);
     }
     if (rc != MSCKF_OK) return rc;

@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 4 ? atoi(argv[4]) : 20;
     const int dc = 6 * N, d = 15 + dc, ldt = dc + 1;
     const int nb = (dc + 15) / 16, ns = nb + 1;
-    const int ncb = std::min(nb, (16 + band - 1 + 15) / 16);
+    const int ncb = gstream_ncb(dc, band);
     const double sigma2 = 0.04;
     std::mt19937_64 rng(1234);
     std::normal_distribution<double> nd(0.0, 1.0);
@@ -118,8 +118,12 @@ int main(int argc, char** argv) {
     GStreamArgs a{};
     a.P = dP; a.ldp = d; a.T = dT; a.ldt = ldt; a.ex = dEx; a.exflag = dFlag; a.dx = dDx; a.Pout = dPout; a.ldo = d;
     a.status = dStatus; a.sigma2 = sigma2; a.d = d; a.dc = dc; a.nb = nb; a.ns = ns; a.ncb = ncb;
+    long long* dStamps = nullptr;
+    CK(hipMalloc(&dStamps, 80 * 8 * 8)); CK(hipMemset(dStamps, 0, 80 * 8 * 8));
+    a.stamps = dStamps;
     unsigned epoch = 0;
     auto launch = [&](hipStream_t st) {
+
         if (ns <= 16) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
         else hipLaunchKernelGGL(k_gain_stream<2>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
     };
@@ -153,6 +157,20 @@ int main(int argc, char** argv) {
         std::printf("standalone kernel: best %.1f us, mean %.1f us (N = %d, %d row blocks, %d strips, %d column blocks per row block)\n",
                     best * 1e3, sum / reps * 1e3, N, nb, ns, ncb);
         rc |= check("standalone (last rep)");
+#ifdef GS_STAMPS
+        std::vector<long long> st(80 * 8);
+        CK(hipMemcpy(st.data(), dStamps, st.size() * 8, hipMemcpyDeviceToHost));
+        std::printf("workgroup 0, 10 ns ticks per row block: T seen -> partials | -> published | -> tiles fetched | barrier | eliminated | wave 0 followed | LDS write + barrier | to next block's T seen\n");
+        for (int I = 0; I < nb; ++I) {
+            const long long* q = &st[I * 8];
+            std::printf("  block %2d: %5lld | %5lld | %5lld | %4lld | %5lld | %5lld | %5lld | %5lld\n", I, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4],
+                        q[7] - q[5], q[6] - q[7], I + 1 < nb ? st[(I + 1) * 8] - q[6] : 0LL);
+        }
+        for (int k = 0; k < 2; ++k) { std::printf("timeout record %d:", k); for (int q = 0; q < 8; ++q) std::printf(" %llx", (unsigned long long)st[70 * 8 + 8 * k + q]); std::printf("\n"); }
+        std::printf("block 5, arrival at the last barrier by wavefront, ticks after the elimination: ");
+        for (int w = 0; w < 16; ++w) std::printf("%lld ", st[64 * 8 + w] - st[5 * 8 + 5]);
+        std::printf("\n");
+#endif
     }
     // (2) beside the producer
     const int gap = (int)std::lround(us_row * 100.0);
