@@ -74,6 +74,7 @@ struct GStreamArgs {
     double sigma2;
     int d, dc, nb, ns, ncb;                  // nb row blocks of T, ns = nb + 1 strips, ncb column blocks per row block
     long long* stamps;                       // -DGS_STAMPS builds: wall-clock stamps of workgroup 0, 8 per row block
+    long long* tstamp;                       // optional: [2] wall clock (10 ns ticks) when strip 0 has stored its results
 };
 #ifdef GS_STAMPS
 #define GS_STAMP(w, i) do { if (p.stamps && r == 0 && wv == (w) && lane == 0) p.stamps[I * 8 + (i)] = wall_clock64(); } while (0)
@@ -162,15 +163,16 @@ __device__ __forceinline__ bool gs_eliminate(double (&d)[4], unsigned sw_half, d
 
 // A tile (any 16 rows x the block's 16 columns, accumulator layout) follows the pivots of gs_eliminate:
 // a <- a L^-T (k_chol16's panel owners), four pivots per poll of the progress words.
-template <int NPIV>
-__device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const double* sri, int lane) {
+// NT tiles of one wavefront take the same multipliers side by side (independent chains).
+template <int NPIV, int NT>
+__device__ __forceinline__ void gs_follow(double (&a0)[NT][4], unsigned w_in, const double* sri, int lane) {
     constexpr int LASTM = NPIV - 2;                                  // the last pivot with multipliers
     const int cc = lane & 15;
     const unsigned w_cc = w_in + cc * 8;
     auto follow4 = [&](auto tagp) {
         constexpr int P0 = decltype(tagp)::value;
         constexpr int PL = (P0 + 3 < LASTM) ? P0 + 3 : LASTM;
-        double* ap = a0;
+        double (*ap)[4] = a0;
         const unsigned win_l = w_in, wcc_l = w_cc;
         int spins = 0;
         do {
@@ -188,12 +190,13 @@ __device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const 
         if constexpr (P0 + 3 <= LASTM) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(m3) : "v"(wcc_l), "i"((P0 + 3) * 17 * 8) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)::"memory");
 #define GS_FOLLOW1(PP, M)                                                                                                \
+    _Pragma("unroll") for (int tq = 0; tq < NT; ++tq)                                                                   \
     asm volatile("s_nop 1\n\t"                                                                                          \
                  "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
                  "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
                  "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"                             \
                  "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"                                 \
-                 : "+v"(ap[0]), "+v"(ap[1]), "+v"(ap[2]), "+v"(ap[3]) : "v"(M), "i"(PP))
+                 : "+v"(ap[tq][0]), "+v"(ap[tq][1]), "+v"(ap[tq][2]), "+v"(ap[tq][3]) : "v"(M), "i"(PP))
         GS_FOLLOW1(P0, m0);
         GS_FOLLOW1(P0 + 1, m1);
         GS_FOLLOW1(P0 + 2, m2);
@@ -215,11 +218,14 @@ __device__ __forceinline__ void gs_follow(double (&a0)[4], unsigned w_in, const 
         } while (++spins < (1 << 22));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a0[i] *= ri;
+    for (int tq = 0; tq < NT; ++tq)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a0[tq][i] *= ri;
 }
 
-// WV wavefronts; wavefront wv holds the tiles s = wv + WV q, q < TPW; wavefront WV - 1 also eliminates, WV - 2 also publishes.
-template <int WV, int TPW>
+// WV wavefronts; wavefront wv < TW holds the tiles s = wv + TW q, q < TPW; wavefront WV - 1 eliminates (with TW < WV it has
+// no tile of its own to follow afterwards), wavefront WV - 2 also publishes.
+template <int WV, int TW, int TPW>
 __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int r) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -245,7 +251,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
     double Pt[TPW][4];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int s = wv + WV * q;
+        const int s = (wv < TW) ? wv + TW * q : GS_MAX_NS + 1;
         const int gsr = g0(min(s, ns - 1)), ms = (s < ns) ? nrows(s) : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -276,6 +282,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             }
         }
         GS_STAMP(WV - 1, 0);                                      // rows of T seen
+        if (p.tstamp && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();
         __syncthreads();
         if (sCtl[1]) { failed = true; break; }
         const int s_lo = 1 + (row0 >> 4), s_hi = min(s_lo + ncb - 1, ns - 1);   // strips that hold T_I's columns
@@ -283,7 +290,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         double Tt[TPW][4];
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int s = wv + WV * q;
+            const int s = (wv < TW) ? wv + TW * q : GS_MAX_NS + 1;
             if (s >= s_lo && s <= s_hi) {
                 const int trow = row0 + cc;
 #pragma unroll
@@ -333,7 +340,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         double Yt[TPW][4];
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            const int s = wv + WV * q;
+            const int s = (wv < TW) ? wv + TW * q : GS_MAX_NS + 1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) Yt[q][i] = 0.0;
             if (s < ns) {
@@ -385,18 +392,20 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             if (bad && lane == 0) sCtl[0] = 1;
             GS_STAMP(WV - 1, 5);                                  // eliminated
         }
+        if (wv < TW && wv < ns) {                                           // (tiles past the last strip are zeros: they ride along)
+            if (npiv == 16) gs_follow<16, TPW>(Yt, sw_half, sri, lane);
+            else if (npiv == 12) gs_follow<12, TPW>(Yt, sw_half, sri, lane);
+            else if (npiv == 8) gs_follow<8, TPW>(Yt, sw_half, sri, lane);
+            else gs_follow<4, TPW>(Yt, sw_half, sri, lane);
+            GS_STAMP(0, 7);                                             // wavefront 0 has followed
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int s = wv + WV * q;
-            if (s < ns) {
-                if (npiv == 16) gs_follow<16>(Yt[q], sw_half, sri, lane);
-                else if (npiv == 12) gs_follow<12>(Yt[q], sw_half, sri, lane);
-                else if (npiv == 8) gs_follow<8>(Yt[q], sw_half, sri, lane);
-                else gs_follow<4>(Yt[q], sw_half, sri, lane);
-                GS_STAMP(0, 7);                                         // wavefront 0 has followed
-                double* dst = sX + (size_t)s * GS_XT + cc * GS_XS + g;
+            for (int q = 0; q < TPW; ++q) {
+                const int s = (wv < TW) ? wv + TW * q : GS_MAX_NS + 1;
+                if (s < ns) {
+                    double* dst = sX + (size_t)s * GS_XT + cc * GS_XS + g;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dst[4 * i] = Yt[q][i];      // [column][row]
+                    for (int i = 0; i < 4; ++i) dst[4 * i] = Yt[q][i];  // [column][row]
+                }
             }
         }
 #ifdef GS_STAMPS
@@ -413,7 +422,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             for (int u = 0; u < 4; ++u) bv[u] = xr[4 * GS_XS * u];
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
-                const int s = wv + WV * q;
+                const int s = (wv < TW) ? wv + TW * q : GS_MAX_NS + 1;
                 if (s < ns) {
                     const double* xs = sX + (size_t)s * GS_XT + g * GS_XS + cc;
                     double av[4];
@@ -436,7 +445,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
     // ---- P+ tiles and dx (= minus the augmented row) -----------------------------------------------------------
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int s = wv + WV * q;
+        const int s = (wv < TW) ? wv + TW * q : GS_MAX_NS + 1;
         if (s < ns) {
             const int gsr = g0(s), ms = nrows(s);
 #pragma unroll
@@ -447,12 +456,17 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             if (s == 0 && g == 3 && cc < nr) p.dx[gr + cc] = -Pt[q][3];
         }
     }
+    if (p.tstamp && r == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) p.tstamp[2] = wall_clock64();
+    }
 }
 
 // alone (T complete, or a sweep kernel of another launch publishing it): one workgroup of 16 wavefronts per strip
 template <int TPW>
 __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
-    gain_stream_body<GS_WAVES, TPW>(p, blockIdx.x);
+    gain_stream_body<GS_WAVES, GS_WAVES, TPW>(p, blockIdx.x);
 }
 
 // ONE launch for the root sweep and the update that follows it: workgroup 0 is the sweep (NF fold wavefronts + the
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
 template <int NF, int TPW>
 __global__ __launch_bounds__(64 * (NF + 1)) void k_root_gain(SweepArgs sp, GStreamArgs gp) {
     if (blockIdx.x == 0) sweep_body<NF, 1, false, true>(sp);
-    else gain_stream_body<NF + 1, TPW>(gp, (int)blockIdx.x - 1);
+    else gain_stream_body<NF + 1, NF, TPW>(gp, (int)blockIdx.x - 1);
 }
 
 }  // namespace msckf

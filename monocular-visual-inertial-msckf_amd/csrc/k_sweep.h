@@ -73,6 +73,7 @@ struct SweepArgs {
     const int* flush_tab;       // nsteps + 1 entries lo | n << 16: rows [lo, lo + n) of R are final at the head of macro step t
     unsigned long long* progress;   // (epoch << 32) | rows of the output block that are final AND visible device-wide
     unsigned epoch;
+    long long* tstamp;          // optional: [0] wall clock (10 ns ticks) when the sweep starts, [1] when its last row is published
 };
 
 constexpr int SWEEP_MAX_W = 60;        // widest source / envelope (local column 63 holds the rhs)
@@ -217,6 +218,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
             int l1 = 0, l2 = 0, l3 = 0;             // rows final one / two / three steps ago
             int published = 0;
             const int boff = (16 - (wtot & 15)) & 15;   // k_gstream.h's row blocks end at rows = wtot (mod 16)
+            if (p.tstamp && lane == 0) p.tstamp[0] = wall_clock64();
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // R zeroed / adopted, table in place
             asm volatile("" ::: "memory");
@@ -250,6 +252,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     published = l3;
                     ++issued;
+                    if (p.tstamp && lane == 0) { const int kb = (l3 + boff) >> 4; if (kb < 14) p.tstamp[18 + kb] = wall_clock64(); }
                 }
                 l3 = l2; l2 = l1; l1 = lo + n;
                 c2 = c1; c1 = issued;
@@ -263,6 +266,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
             if (lane == 0)
                 __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress, ep | (unsigned)wtot,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.tstamp && lane == 0) p.tstamp[1] = wall_clock64();
             return;
         }
     }

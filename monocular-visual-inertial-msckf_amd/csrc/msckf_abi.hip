@@ -338,6 +338,8 @@ struct msckf_ctx {
     bool gs_enabled = true;               // MSCKF_GAIN_STREAM=0: the round-3 K6-K7 (separate launches behind the root sweep)
     bool gs_overlap = true;               // MSCKF_GAIN_OVERLAP=0: k_gain_stream as a launch of its own behind the root sweep
     int root_band = 0;                    // widest row of the root block in columns (the local plan's / the merge plan's)
+    bool gs_stamp = false;                // msckf_run_timed: k_root_gain notes when its sweep ends and when its update ends
+    bool gs_fused_last = false;           // the last pipeline ran k_root_gain (stage events cannot split it)
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
     int fetched_rc = 0;                   // ... and that code: msckf_commit_covariance need not read the gate results again
@@ -1202,6 +1204,7 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.sigma2 = c->sigma * c->sigma;
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.stamps = nullptr;
+    a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
 }
 // K6-K7 behind a complete root block: nothing is polled
 int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
@@ -1218,7 +1221,7 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
 // The root sweep (k_sweep form) and K6-K7 in ONE launch (k_root_gain): workgroup 0 sweeps and publishes the rows of the
 // root block as they become final, workgroups 1.. are the strips of the update.  `sa` carries the tables and the node index.
 bool root_gain_ok(const msckf_ctx* c, int band) {
-    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 2 * (SWEEP_NW + 1);
+    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 2 * SWEEP_NW;      // two tiles on each fold-slot wavefront
 }
 int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const int* flush_tab, const double* Tblk, int band) {
     ++c->gs_epoch;
@@ -1226,6 +1229,7 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
     sa.progress = ptr<unsigned long long>(c->dGsProg);
     sa.epoch = c->gs_epoch;
     sa.stamps = nullptr;
+    sa.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;      // (behind the progress word, same allocation)
     GStreamArgs ga;
     fill_gstream_args(c, ga, Tblk, band, true);
     // (every workgroup asks for more than half of a CU's LDS: one per CU, the sweep has its CU to itself)
@@ -1280,6 +1284,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
                            c->xmask_doubles > 0 ? reinterpret_cast<unsigned char*>(ptr<double>(c->dRbuf) + c->N + 1) : nullptr);
         HIPCHK(c, hipGetLastError());
     }
+    c->gs_fused_last = beside;
     if (beside) {
         SweepArgs a{};
         a.nodes = ptr<SweepNode>(c->dSweepNodes);
@@ -1443,7 +1448,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         const size_t nbm = (size_t)(dc + 15) / 16, nsm = nbm + 1;
         E(c->dGsEx, nbm * nsm * 256 * 8);
         E(c->dGsFlag, (nbm * nsm + 8) * 8, true);
-        E(c->dGsProg, 64, true);
+        E(c->dGsProg, 512, true);                      // (progress word at 0, k_root_gain's time stamps on a line of their own at byte 256)
     }
     if (rc != MSCKF_OK) { msckf_destroy(c); return rc; }
     {
@@ -1795,12 +1800,32 @@ int msckf_run_timed(msckf_ctx* c, int32_t iters, float* ms_total, float* stage_u
         double acc[3] = {0, 0, 0};
         const int reps = std::min(iters, 20);
         for (int i = 0; i < reps; ++i) {
-            if ((rc = run_pipeline(c, true, c->ev)) != MSCKF_OK) return rc;
+            c->gs_stamp = true;
+            rc = run_pipeline(c, true, c->ev);
+            c->gs_stamp = false;
+            if (rc != MSCKF_OK) return rc;
             HIPCHK(c, hipEventSynchronize(c->ev[3]));
             for (int s = 0; s < 3; ++s) {
                 float t = 0;
                 HIPCHK(c, hipEventElapsedTime(&t, c->ev[s], c->ev[s + 1]));
                 acc[s] += t * 1000.0;
+            }
+            if (c->gs_fused_last) {
+                // one launch holds the root sweep and K6-K7: what trails the sweep's last published row is K6-K7's share
+                long long ts[3] = {0, 0, 0};
+                HIPCHK(c, hipMemcpy(ts, ptr<long long>(c->dGsProg) + 32, 24, hipMemcpyDeviceToHost));
+                if (std::getenv("MSCKF_GS_DEBUG")) {
+                    long long t8[32];
+                    HIPCHK(c, hipMemcpy(t8, ptr<long long>(c->dGsProg) + 32, 256, hipMemcpyDeviceToHost));
+                    std::fprintf(stderr, "k_root_gain (us after the sweep started): last row published %.1f, update done %.1f | strip 0 saw the row blocks at",
+                                 (t8[1] - t8[0]) * 0.01, (t8[2] - t8[0]) * 0.01);
+                    for (int b = 0; b < (c->dc + 15) / 16 && b < 15; ++b) std::fprintf(stderr, " %.1f", (t8[3 + b] - t8[0]) * 0.01);
+                    std::fprintf(stderr, " | the flusher published them at");
+                    for (int b = 1; b < (c->dc + 15) / 16 && b < 14; ++b) std::fprintf(stderr, " %.1f", (t8[18 + b] - t8[0]) * 0.01);
+                    std::fprintf(stderr, "\n");
+                }
+                const double tail = (double)(ts[2] - ts[1]) * 0.01;
+                if (tail > 0.0 && tail < 1000.0) { acc[1] -= tail; acc[2] += tail; }
             }
         }
         for (int s = 0; s < 3; ++s) { stage_us[s] = (float)(acc[s] / reps); c->us_stage[s] = stage_us[s]; }

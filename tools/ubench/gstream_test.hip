@@ -29,6 +29,11 @@ __global__ void k_producer(const double* src, double* dst, int dc, int ldt, int 
     }
 }
 
+#ifdef GS_TEST_WV
+// the update's strips as k_root_gain runs them: GS_TEST_WV wavefronts per workgroup, GS_TEST_TPW tiles per wavefront
+__global__ __launch_bounds__(64 * GS_TEST_WV) void k_gain_test(GStreamArgs p) { gain_stream_body<GS_TEST_WV, GS_TEST_WV - 1, GS_TEST_TPW>(p, blockIdx.x); }
+#endif
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 30;
     const int band = argc > 2 ? atoi(argv[2]) : 60;
@@ -115,6 +120,9 @@ int main(int argc, char** argv) {
     const size_t lds = std::max<size_t>(gstream_lds_doubles(ns, ncb) * 8, 100 * 1024);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_stream<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+#ifdef GS_TEST_WV
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_test), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+#endif
     GStreamArgs a{};
     a.P = dP; a.ldp = d; a.T = dT; a.ldt = ldt; a.ex = dEx; a.exflag = dFlag; a.dx = dDx; a.Pout = dPout; a.ldo = d;
     a.status = dStatus; a.sigma2 = sigma2; a.d = d; a.dc = dc; a.nb = nb; a.ns = ns; a.ncb = ncb;
@@ -123,6 +131,10 @@ int main(int argc, char** argv) {
     a.stamps = dStamps;
     unsigned epoch = 0;
     auto launch = [&](hipStream_t st) {
+#ifdef GS_TEST_WV
+        hipLaunchKernelGGL(k_gain_test, dim3(ns), dim3(64 * GS_TEST_WV), lds, st, a);
+        return;
+#endif
 
         if (ns <= 16) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
         else hipLaunchKernelGGL(k_gain_stream<2>, dim3(ns), dim3(64 * GS_WAVES), lds, st, a);
