@@ -281,7 +281,9 @@ int msckf_set_exchange_span(msckf_ctx* ctx, int32_t max_span);
  * batch of tracks spanning at most `max_span` clone slots over N clones is planned as the band pipeline on
  * this context (1 k_sweep, 2 k_wsweep<4> with the band in a ring, 3 k_wsweep<6> with 90-column tiles; group
  * records work for all three once msckf_set_exchange_span told the span), 0 when it gets the merge tree
- * (MSCKF_FLAG_TREE_PLAN, tracks wider than 15 slots): then use msckf_export_block. */
+ * (MSCKF_FLAG_TREE_PLAN, tracks wider than 15 slots): then use msckf_export_block.
+ * NB (changed in round 3, same ABI version): the value is the sweep mode + 1, not a boolean -- test `> 0`, never
+ * `== 1` (a caller that did fell back to root blocks for the two ring modes). */
 int msckf_band_rule(const msckf_ctx* ctx, int32_t N, int32_t max_span);
 size_t msckf_group_record_doubles(const msckf_ctx* ctx);   /* N + 1 + gate-byte doubles (msckf_set_exchange_mask) + N * 3660 (8190 with 90-column slots) */
 int msckf_export_groups(msckf_ctx* ctx, void* dst, int device_ptr, int32_t* n_accepted /* nullable */);

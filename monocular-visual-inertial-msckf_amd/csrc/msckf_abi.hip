@@ -133,6 +133,7 @@ public:
                 if (CPU_ISSET(cpu, &allowed)) cpus.push_back(cpu);
             }
         }
+        pinned_ = (int)cpus.size() >= workers;       // else: no busy polling on CPUs the workers share with the caller
         for (int i = 0; i < workers; ++i) {
             const int cpu = i < (int)cpus.size() ? cpus[i] : -1;
             th_.emplace_back([this, cpu] {
@@ -177,7 +178,7 @@ private:
         for (;;) {
             // spin for a while, then sleep
             bool got = false;
-            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us_);
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(pinned_ ? spin_us_ : 0);
             for (int spins = 0;; ++spins) {
                 if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; }
                 cpu_relax();
@@ -206,6 +207,7 @@ private:
     const std::function<void(int)>* fn_ = nullptr;
     int n_ = 0;
     bool stop_ = false;
+    bool pinned_ = false;
     int spin_us_ = 1000;
 
 public:
@@ -1454,7 +1456,12 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     {
         const char* e = std::getenv("MSCKF_HOST_THREADS");
         int nw = e ? std::atoi(e) : 3;
-        const int hw = (int)std::thread::hardware_concurrency();
+        // the CPUs this thread may run on decide (a cpuset / taskset / a launcher that binds ranks to cores), not the machine's
+        // count: every worker gets a CPU of its own beside the caller's, or there are fewer workers (none on one CPU)
+        int hw = (int)std::thread::hardware_concurrency();
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) hw = std::min(hw > 0 ? hw : CPU_SETSIZE, CPU_COUNT(&allowed));
         nw = std::max(0, std::min(nw, std::max(0, hw - 1)));
         nw = std::min(nw, 15);
         const char* es = std::getenv("MSCKF_HOST_SPIN_US");
@@ -1574,6 +1581,12 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     std::vector<int> fmin_in(F), fmax_in(F);
     int Mmax = 0;
     if (view_ptr[0] != 0) return MSCKF_ERR_ARG;
+    // the CSR offsets first, all of them (a few microseconds): the feature ranges below read obs_slot[view_ptr[f] ..] and must
+    // not do so through an offset no earlier range has vouched for (a malformed view_ptr would send them out of bounds)
+    for (int f = 0; f < F; ++f) {
+        const int M = view_ptr[f + 1] - view_ptr[f];
+        if (M < 1 || M > c->maxM) return MSCKF_ERR_ARG;
+    }
     {
         const int nch = (c->pool && F >= host_par_min()) ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
         std::vector<int> ch_err(nch, MSCKF_OK), ch_mmax(nch, 0);

@@ -142,9 +142,12 @@ def _run_tag() -> bytes:
     `torch.distributed.run` / `mpirun`).  Callers with their own side channel pass a tag explicitly."""
     import hashlib
     e = os.environ
-    key = "|".join([e.get("TORCHELASTIC_RUN_ID", ""), e.get("MASTER_ADDR", ""), e.get("MASTER_PORT", ""),
-                    e.get("MSCKF_RUN_TAG", ""), str(os.getppid())])
-    return hashlib.sha256(key.encode()).digest()[:16]
+    ident = [e.get("TORCHELASTIC_RUN_ID", ""), e.get("MASTER_ADDR", ""), e.get("MASTER_PORT", ""), e.get("MSCKF_RUN_TAG", "")]
+    # the parent's pid only when nothing else names the launch: ranks started through per-rank wrappers (`mpirun` / `srun`
+    # with a script or `bash -c` per rank) or on several nodes have DIFFERENT parents and must still agree on the tag
+    if not any(ident):
+        ident.append(str(os.getppid()))
+    return hashlib.sha256("|".join(ident).encode()).digest()[:16]
 
 
 def exchange_unique_id(engine, rank: int, world: int, path: str, timeout_s: float = 120.0, tag: bytes = None) -> bytes:
@@ -170,7 +173,9 @@ def exchange_unique_id(engine, rank: int, world: int, path: str, timeout_s: floa
         except FileNotFoundError:
             pass
         time.sleep(0.01)
-    raise TimeoutError("no RCCL id of this launch at " + path)
+    raise TimeoutError("no RCCL id of this launch at " + path + ": the ranks derive the launch's tag from TORCHELASTIC_RUN_ID / "
+                       "MASTER_ADDR + MASTER_PORT / MSCKF_RUN_TAG (else the parent's pid); set MSCKF_RUN_TAG to the same value on "
+                       "every rank, or pass tag=, if the launcher provides none of them")
 
 
 class RcclShardedUpdate:

@@ -623,6 +623,7 @@ def main():
     cases["edge_full_window_tracks"] = lambda: (synth.make_problem(8, 40, 8, seed=13), None)      # every track spans all clones
     cases["edge_rank2_Hf"] = lambda: (coincident_clone_problem(14), None)                         # tracks with rank(H_f) = 2
     cases["edge_gate_threshold"] = lambda: (gate_threshold_problem(15), None)                     # gamma within 1e-4 of crit, both sides
+    cases["edge_gate_threshold_tight"] = lambda: (gate_threshold_problem(16, rel=1e-7), None)     # ... within 1e-7: the reference decides the mask
     if args.headline:
         cases["cfg3_A"] = lambda: (synth.make_problem(30, 2000, 10, seed=0), None)
 

@@ -140,6 +140,44 @@ def test_covariance_properties_full_size(eng):
     assert np.linalg.eigvalsh(res.P_new).min() > 0
 
 
+@pytest.mark.parametrize("case", ["cfg1_B", "cfg2_B"])
+def test_recipe_b_spectrum_matches_the_reference(eng, case):
+    """Recipe B: covariance and poses produced by the reference's own process_imu / state_augmentation, cond(P) ~ 1e18,
+    smallest eigenvalue a rounding-level negative.  The update here is the sequential block form P+ = P - sum_I X_I X_I^T
+    (csrc/k_gstream.h), the reference's the Joseph form (MSCKF.py:613): the whole SPECTRUM of P+ must agree with the
+    reference fixture's, the smallest eigenvalue included, to 1e-12 of the largest one, and P - P+ must be positive
+    semidefinite to the same level (an update only removes uncertainty)."""
+    prob, ref = load_golden(case)
+    res = eng.update_problem(prob)
+    assert res.status == 0
+    assert np.array_equal(res.P_new, res.P_new.T)
+    ev, ev_ref = np.linalg.eigvalsh(res.P_new), np.linalg.eigvalsh(ref["P_new"])
+    scale = abs(ev_ref).max()
+    assert abs(ev - ev_ref).max() < 1e-12 * scale, (ev[0], ev_ref[0], scale)
+    assert abs(ev[0] - ev_ref[0]) < 1e-12 * scale
+    gain = np.linalg.eigvalsh(prob.P - res.P_new)
+    assert gain.min() > -1e-12 * abs(np.linalg.eigvalsh(prob.P)).max()
+
+
+def test_malformed_view_ptr_in_a_large_batch(eng):
+    """The CSR offsets of a batch large enough for the host worker pool (>= 1024 features) are checked as a whole BEFORE
+    any feature range reads obs_slot through them: a non-monotone or wild view_ptr returns MSCKF_ERR_ARG (round-3 advisor:
+    the parallel validation could read far outside obs_slot)."""
+    from msckf_amd import synth
+    from msckf_amd._ffi import EngineError, ERR_ARG
+    good = synth.make_problem(12, 2048, 5, seed=71)
+    for where, val in ((1500, -(2 ** 30)), (1500, 2 ** 30), (700, 3), (2048, 2 ** 30)):
+        bad = synth.UpdateProblem(**{**good.__dict__})
+        vp = good.view_ptr.copy(); vp[where] = val
+        bad.view_ptr = vp
+        with pytest.raises(EngineError) as ei:
+            eng.load(bad)
+        assert ei.value.code == ERR_ARG, (where, val)
+    eng.load(good)                                           # and the engine recovers
+    eng.run()
+    assert eng.result().status == 0
+
+
 @pytest.mark.parametrize("shards", [2, 3, 4])
 def test_logical_shards_on_one_gpu(eng, shards):
     """Shard-merge invariance: S logical shards compressed

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + separate PMC passes (HBM bytes; matrix-core /
 # VALU activity and wave occupancy).  --pmc passes never carry trace flags (gpurun refuses the combination).
-# usage: tools/profile_round.sh r03   -> gpurun_out/profiles_r02/{stats,fetch,write,mfma,sq}/...
+# usage: tools/profile_round.sh r03   -> gpurun_out/profiles_<tag>/{stats,fetch,write,mfma,sq}/...
 tag=${1:-r03}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
