@@ -39,6 +39,7 @@
 #include "wave_ops.h"
 #include "k_gain.h"
 #include "k_sweep.h"
+#include "k_wsweep.h"
 
 namespace msckf {
 
@@ -479,6 +480,15 @@ template <int NF, int TPW>
 __global__ __launch_bounds__(64 * (NF + 1)) void k_root_gain(SweepArgs sp, GStreamArgs gp) {
     if (blockIdx.x == 0) sweep_body<NF, 1, false, true>(sp);
     else gain_stream_body<NF + 1, NF, TPW>(gp, (int)blockIdx.x - 1);
+}
+
+// The same pairing for the ring-buffered sweeps (N > 37 clones or tracks of 11 - 15 slots): k_wsweep's fold wavefronts store
+// the final rows themselves (write-through) and wavefront 0 publishes the count; NF wavefronts per workgroup, the strips'
+// tiles on NF - 1 of them.
+template <int NF, int CS, int TPW>
+__global__ __launch_bounds__(64 * NF) void k_root_gain_w(WSweepArgs sp, GStreamArgs gp) {
+    if (blockIdx.x == 0) wsweep_body<NF, CS, true>(sp);
+    else gain_stream_body<NF, NF - 1, TPW>(gp, (int)blockIdx.x - 1);
 }
 
 }  // namespace msckf

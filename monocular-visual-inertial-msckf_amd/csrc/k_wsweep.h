@@ -28,6 +28,11 @@ struct WSweepArgs {
     const int* flush;           // per node: nsteps + 1 entries (lo | n << 16), at flush_off[node]
     const int* flush_off;       // [nodes] offset into `flush`
     int rc_log2;                // ring rows = 1 << rc_log2
+    // k_wsweep body with PUB = true (the root sweep inside k_root_gain_w): rows leave with write-through stores and wavefront 0
+    // publishes how many are final AND visible device-wide (k_gstream.h follows them block by block)
+    unsigned long long* progress;
+    unsigned epoch;
+    long long* tstamp;          // optional: [0] start, [1] last row published (10 ns wall-clock ticks)
 };
 
 template <int CS> struct WSweepGeom {
@@ -43,8 +48,8 @@ __host__ __device__ inline size_t wsweep_lds_bytes(int rc, int nf, int nsteps) {
     return ((size_t)(rc + 1) * WSweepGeom<CS>::W + (size_t)nf * 64 + 2) * 8 + ((size_t)nsteps + 2) * 4;
 }
 
-template <int NF, int CS>
-__global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
+template <int NF, int CS, bool PUB>
+__device__ __forceinline__ void wsweep_body(const WSweepArgs& p) {
     using G = WSweepGeom<CS>;
     constexpr int W = G::W, RSL = G::RSL;
     constexpr int CL = 16;
@@ -72,6 +77,7 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
     double* out = p.rbuf + nd.out_off;
     const int ldo = wtot + 1;
 
+    if constexpr (PUB) { if (p.tstamp && t == 0) p.tstamp[0] = wall_clock64(); }
     for (int e = t; e < (RC + 1) * W; e += 64 * NF) smem[e] = 0.0;
     if (t < 2) smem[zero_i + t] = 0.0;
     {
@@ -132,8 +138,36 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
         }
     };
 
+    // PUB: a wavefront that stored rows at step ts waits for its stores PUB_LAG steps later (`pend`, one bit per step: by
+    // then the round trip is over, and so are the prefetches of the fold issued before it), and one step after that --
+    // behind the barrier that orders every wavefront's wait -- wavefront 0 publishes the rows that were final at step ts.
+    constexpr int PUB_LAG = 4;
+    unsigned pend = 0;
+    int published = 0;
+    const int boff = (16 - (wtot & 15)) & 15;              // k_gstream.h's row blocks end at rows = wtot (mod 16)
+    auto store_out = [&](double* q, double x) {
+        if constexpr (PUB) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)q,
+                                              (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *q = x;
+    };
+    auto publish = [&](int rows) {
+        if (((rows + boff) >> 4) > ((published + boff) >> 4) || rows == wtot) {
+            if (wv == 0 && lane == 0)
+                __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress,
+                                   ((unsigned long long)p.epoch << 32) | (unsigned)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            published = rows;
+        }
+    };
     // rows [lo, lo + n) are final at the head of macro step ts: out to HBM, ring slots cleared
     auto flush_rows = [&](int ts) {
+        if constexpr (PUB) {
+            if (pend & 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            pend >>= 1;
+            if (ts > PUB_LAG) {                              // (uniform: every wavefront keeps `published` in step)
+                const int e0 = ftab[ts - PUB_LAG - 1];
+                publish(__builtin_amdgcn_readfirstlane((e0 & 0xFFFF) + (e0 >> 16)));
+            }
+        }
         const int e = ftab[ts];
         const int n = __builtin_amdgcn_readfirstlane(e >> 16);
         if (n == 0) return;
@@ -147,11 +181,12 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
                 const int dlt = lane + 64 * h;
                 if (dlt < W) {
                     const double x = Rrow[dlt];
-                    if (dlt == W - 1) orow[wtot] = x;
-                    else if (c + dlt < wtot) orow[c + dlt] = x;
+                    if (dlt == W - 1) store_out(orow + wtot, x);
+                    else if (c + dlt < wtot) store_out(orow + c + dlt, x);
                     Rrow[dlt] = 0.0;
                 }
             }
+            if constexpr (PUB) pend |= 1u << (PUB_LAG - 1);   // waited for at step ts + PUB_LAG, published one barrier later
         }
     };
     auto barrier_step = [&]() {
@@ -274,6 +309,17 @@ __global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
     }
     while (tcur < nsteps) barrier_step();
     // (the table's last entry, index nsteps, covers every row still in the ring)
+    if constexpr (PUB) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        publish(wtot);
+        if (p.tstamp && t == 0) p.tstamp[1] = wall_clock64();
+    }
+}
+
+template <int NF, int CS>
+__global__ __launch_bounds__(64 * NF) void k_wsweep(WSweepArgs p) {
+    wsweep_body<NF, CS, false>(p);
 }
 
 }  // namespace msckf

@@ -1242,6 +1242,38 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
     return MSCKF_OK;
 }
 
+// ... and for the ring-buffered root sweeps (k_wsweep form, sweep modes 1 and 2): k_root_gain_w
+bool root_gain_w_ok(const msckf_ctx* c, int band) {
+    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 3 * (SWEEP_NW - 1);
+}
+template <int CS>
+int launch_root_and_gain_w(msckf_ctx* c, int node, int nsteps, int rc_log2, const double* zero, const double* Tblk, int band) {
+    ++c->gs_epoch;
+    WSweepArgs a{};
+    a.nodes = ptr<SweepNode>(c->dSweepNodes);
+    a.folds = ptr<SweepFold>(c->dSweepFolds);
+    a.node_base = node;
+    a.rbuf = ptr<double>(c->dRbuf);
+    a.zero = zero;
+    a.flush = ptr<int>(c->dFlush);
+    a.flush_off = ptr<int>(c->dFlushOff);
+    a.rc_log2 = rc_log2;
+    a.progress = ptr<unsigned long long>(c->dGsProg);
+    a.epoch = c->gs_epoch;
+    a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
+    GStreamArgs ga;
+    fill_gstream_args(c, ga, Tblk, band, true);
+    const size_t lds = std::max<size_t>(std::max(wsweep_lds_bytes<CS>(1 << rc_log2, SWEEP_NW, nsteps), gstream_lds_doubles(ga.ns, ga.ncb) * 8),
+                                        (size_t)84 * 1024);
+    if (ga.ns <= 2 * (SWEEP_NW - 1))
+        hipLaunchKernelGGL((k_root_gain_w<SWEEP_NW, CS, 2>), dim3(1 + ga.ns), dim3(64 * SWEEP_NW), lds, c->stream, a, ga);
+    else
+        hipLaunchKernelGGL((k_root_gain_w<SWEEP_NW, CS, 3>), dim3(1 + ga.ns), dim3(64 * SWEEP_NW), lds, c->stream, a, ga);
+    HIPCHK(c, hipGetLastError());
+    c->gain_blocked = false;
+    return MSCKF_OK;
+}
+
 // Gate results of the last run, summed on the host:
 // {accepted, stacked rows, not-SPD gate matrices, not selected by k_select}.
 int gate_counts(msckf_ctx* c, int out[4], std::vector<unsigned char>* acc_sorted, bool copied = false) {
@@ -1277,7 +1309,8 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
     // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront and the update's strips in ONE launch
     const bool gs = with_gain && c->F > 0 && c->root >= 0 && gstream_ok(c, c->root_band);
-    const bool beside = gs && c->band_plan && c->sweep_mode == 0 && !c->h_root_flush.empty() && root_gain_ok(c, c->root_band);
+    const bool beside = gs && c->band_plan &&
+                        (c->sweep_mode == 0 ? (!c->h_root_flush.empty() && root_gain_ok(c, c->root_band)) : root_gain_w_ok(c, c->root_band));
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, (with_gain || !c->xchg_planned) && !beside)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
         // (with msckf_set_exchange_mask the shard's gate bytes ride behind it, in input order)
@@ -1287,7 +1320,14 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         HIPCHK(c, hipGetLastError());
     }
     c->gs_fused_last = beside;
-    if (beside) {
+    if (beside && c->sweep_mode > 0) {
+        const SweepNode& rn = c->snodes.back();
+        const double* zero = ptr<double>(c->dRbuf) + c->zero_off;
+        if (c->sweep_mode == 1) rc = launch_root_and_gain_w<4>(c, c->n_group_merges, rn.nsteps, WS_RC_LOG2_4, zero, root_block(c), c->root_band);
+        else rc = launch_root_and_gain_w<6>(c, c->n_group_merges, rn.nsteps, WS_RC_LOG2_6, zero, root_block(c), c->root_band);
+        if (rc != MSCKF_OK) return rc;
+        if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
+    } else if (beside) {
         SweepArgs a{};
         a.nodes = ptr<SweepNode>(c->dSweepNodes);
         a.folds = ptr<SweepFold>(c->dSweepFolds);
@@ -1397,6 +1437,10 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain<SWEEP_NW, 2>), LDS_MAX_BYTES - 1024, "k_root_gain LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 3>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 6, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 6, 3>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<1>), LDS_MAX_BYTES - 1024, "k_gain_stream<1> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<2>), LDS_MAX_BYTES - 1024, "k_gain_stream<2> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
