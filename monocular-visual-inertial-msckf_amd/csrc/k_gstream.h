@@ -149,7 +149,11 @@ __device__ __forceinline__ bool gs_eliminate(double (&d)[4], unsigned sw_half, d
     // the pivots are the diagonal as it stands now: lane (g, c) picks register c >> 2 and takes it from row group c & 3
     double pivs;
     {
-        const double sel = (cc < 8) ? ((cc < 4) ? d[0] : d[1]) : ((cc < 12) ? d[2] : d[3]);
+        // (scalars behind an empty asm statement: the compiler turned the selects over d[] into an indexed load of a copy of
+        //  the array in scratch memory -- a store / load round trip at the end of every elimination)
+        double d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        const double sel = (cc < 8) ? ((cc < 4) ? d0 : d1) : ((cc < 12) ? d2 : d3);
         const int src4 = (16 * (cc & 3) + cc) * 4;
         const int plo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(sel)), phi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(sel));
         pivs = __hiloint2double(phi, plo);

@@ -35,6 +35,7 @@ struct WSweepArgs {
     long long* tstamp;          // optional: [0] start, [1] last row published (10 ns wall-clock ticks)
 };
 
+constexpr int WS_PUB_LAG = 4;             // steps between a row's store and the wait for it (the count goes out one step later)
 template <int CS> struct WSweepGeom {
     static constexpr int W = 16 * CS;          // tile columns = LDS row stride
     static constexpr int MAX_W = W - 6;        // widest source / envelope
@@ -45,7 +46,7 @@ template <int CS> struct WSweepGeom {
 template <int CS>
 __host__ __device__ inline size_t wsweep_lds_bytes(int rc, int nf, int nsteps) {
     // pad | ring | dump words | zero words | flush table (ints)
-    return ((size_t)(rc + 1) * WSweepGeom<CS>::W + (size_t)nf * 64 + 2) * 8 + ((size_t)nsteps + 2) * 4;
+    return ((size_t)(rc + 1) * WSweepGeom<CS>::W + (size_t)nf * 64 + 2) * 8 + ((size_t)nsteps + 2) * 8;   // (flush + publish tables)
 }
 
 template <int NF, int CS, bool PUB>
@@ -82,7 +83,7 @@ __device__ __forceinline__ void wsweep_body(const WSweepArgs& p) {
     if (t < 2) smem[zero_i + t] = 0.0;
     {
         const int* src = p.flush + p.flush_off[p.node_base + blockIdx.x];
-        for (int e = t; e <= nsteps; e += 64 * NF) ftab[e] = src[e];
+        for (int e = t; e < 2 * (nsteps + 1); e += 64 * NF) ftab[e] = src[e];     // flush entries, then the publish entries
     }
     // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
     const SweepFold f0 = p.folds[nd.fold_begin];
@@ -141,34 +142,47 @@ __device__ __forceinline__ void wsweep_body(const WSweepArgs& p) {
     // PUB: a wavefront that stored rows at step ts waits for its stores PUB_LAG steps later (`pend`, one bit per step: by
     // then the round trip is over, and so are the prefetches of the fold issued before it), and one step after that --
     // behind the barrier that orders every wavefront's wait -- wavefront 0 publishes the rows that were final at step ts.
-    constexpr int PUB_LAG = 4;
+    constexpr int PUB_LAG = WS_PUB_LAG;
     unsigned pend = 0;
-    int published = 0;
-    const int boff = (16 - (wtot & 15)) & 15;              // k_gstream.h's row blocks end at rows = wtot (mod 16)
+    int e_nx = 0, p_nx = 0;                                // table entries of the coming step (read one step ahead)
+    const int* ptab = ftab + nsteps + 1;                   // rows to publish at the head of step ts (0: nothing), made by the host
     auto store_out = [&](double* q, double x) {
+#ifdef WS_PUB_PLAIN
+        if constexpr (false) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)q,
+                                              (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         if constexpr (PUB) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)q,
                                               (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         else *q = x;
     };
     auto publish = [&](int rows) {
-        if (((rows + boff) >> 4) > ((published + boff) >> 4) || rows == wtot) {
-            if (wv == 0 && lane == 0)
-                __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress,
-                                   ((unsigned long long)p.epoch << 32) | (unsigned)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            published = rows;
-        }
+        if (wv == 0 && lane == 0)
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress,
+                               ((unsigned long long)p.epoch << 32) | (unsigned)rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // rows [lo, lo + n) are final at the head of macro step ts: out to HBM, ring slots cleared
     auto flush_rows = [&](int ts) {
         if constexpr (PUB) {
+#ifndef WS_PUB_NOWAIT
             if (pend & 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             pend >>= 1;
-            if (ts > PUB_LAG) {                              // (uniform: every wavefront keeps `published` in step)
-                const int e0 = ftab[ts - PUB_LAG - 1];
-                publish(__builtin_amdgcn_readfirstlane((e0 & 0xFFFF) + (e0 >> 16)));
-            }
         }
-        const int e = ftab[ts];
+        // (the table entries of step ts were requested during step ts - 1: a dependent LDS read at the head of every step
+        //  cost the 96-column root 0.12 us per step once the publish entry sat beside the flush entry)
+        const int e = e_nx;
+        const int pr_now = p_nx;
+        if (ts < nsteps) {
+            e_nx = ftab[ts + 1];
+            if constexpr (PUB) p_nx = ptab[ts + 1];
+        }
+        if constexpr (PUB) {
+            // (the rows that were final PUB_LAG + 1 steps ago, where that count passes a 16-row block boundary of the reader:
+            //  the host's sweep_publish_table says so, one entry per step beside the flush entry)
+            const int pr = __builtin_amdgcn_readfirstlane(pr_now);
+            if (pr) publish(pr);
+        }
         const int n = __builtin_amdgcn_readfirstlane(e >> 16);
         if (n == 0) return;
         const int lo = __builtin_amdgcn_readfirstlane(e & 0xFFFF);
@@ -271,6 +285,8 @@ __device__ __forceinline__ void wsweep_body(const WSweepArgs& p) {
     };
 
     __syncthreads();                                       // R zeroed / adopted, flush table in place
+    e_nx = ftab[0];
+    if constexpr (PUB) p_nx = ptab[0];
     flush_rows(0);
     int fi = nd.fold_begin + adopt + wv;
     bool have = fi < fold_end;

@@ -608,6 +608,23 @@ bool sweep_flush_table(const std::vector<SweepFold>& folds, int begin, int end, 
     return ok;
 }
 
+// k_wsweep with PUB: what wavefront 0 publishes at the head of macro step t -- the rows that were final WS_PUB_LAG + 1 steps
+// earlier, where that count passes a boundary of k_gstream.h's 16-row blocks (they end at rows = wtot mod 16); 0: nothing.
+// Appended behind the node's flush entries (tab[off .. off + nsteps]).
+void sweep_publish_table(std::vector<int>& tab, size_t off, int nsteps, int wtot) {
+    const int boff = (16 - (wtot & 15)) & 15;
+    int published = 0;
+    for (int t = 0; t <= nsteps; ++t) {
+        int pr = 0;
+        if (t > WS_PUB_LAG) {
+            const int e = tab[off + t - WS_PUB_LAG - 1];
+            const int rows = (e & 0xFFFF) + (e >> 16);
+            if (((rows + boff) >> 4) > ((published + boff) >> 4)) { pr = rows; published = rows; }
+        }
+        tab.push_back(pr);
+    }
+}
+
 bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                      const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     const int F = c->F, N = c->N, dc = 6 * N;
@@ -784,8 +801,10 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     if (mode > 0) {
         const int rc = 1 << (mode == 1 ? WS_RC_LOG2_4 : WS_RC_LOG2_6);
         for (const SweepNode& nd : c->snodes) {
-            c->h_flush_off.push_back((int)c->h_flush.size());
+            const size_t o = c->h_flush.size();
+            c->h_flush_off.push_back((int)o);
             if (!sweep_flush_table(c->sfolds, nd.fold_begin, nd.fold_end, nd.nsteps, nd.wtot, rc, c->h_flush)) return false;
+            sweep_publish_table(c->h_flush, o, nd.nsteps, nd.wtot);
         }
     }
     return true;
@@ -2593,11 +2612,13 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
             std::vector<int> fl_tab(c->h_flush), fl_off(c->h_flush_off);
             fl_off.resize(c->snodes.size(), 0);
             for (const SweepNode& nd : c->x_snodes) {
-                fl_off.push_back((int)fl_tab.size());
+                const size_t o = fl_tab.size();
+                fl_off.push_back((int)o);
                 if (!sweep_flush_table(fl, nd.fold_begin - fold_base, nd.fold_end - fold_base, nd.nsteps, nd.wtot, rc, fl_tab)) {
                     c->last_error = "merge plan: the band does not fit the ring of k_wsweep";
                     return MSCKF_ERR_ARG;
                 }
+                sweep_publish_table(fl_tab, o, nd.nsteps, nd.wtot);
             }
             if (int rc2 = ensure(c, c->dFlush, fl_tab.size() * 4)) return rc2;
             if (int rc2 = ensure(c, c->dFlushOff, fl_off.size() * 4)) return rc2;
