@@ -25,6 +25,7 @@ namespace msckf {
 
 struct FeatureArgs {
     int F;                       // features in this launch
+    int f0;                      // ... sorted features [f0, f0 + F): workgroup b takes feature f0 + b
     int ldp;                     // leading dimension of P
     const int* view_ptr;         // [F+1] CSR, in SORTED feature order
     const double* obs_uv;        // [sumM*2]
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
     constexpr bool ONE_CHUNK = RMAX <= 24;        // k_feature<24>: tracks of up to 10 views, all 60 columns in one chunk
     constexpr int MAXVK = ONE_CHUNK ? 10 : (RMAX - 2) / 2;   // longest track of this instance
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int f = blockIdx.x;
+    const int f = blockIdx.x + p.f0;
     const int lane = threadIdx.x;
     const int v0 = p.view_ptr[f];
     const int M = p.view_ptr[f + 1] - v0;

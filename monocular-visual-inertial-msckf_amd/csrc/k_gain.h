@@ -266,6 +266,7 @@ struct CholArgs {
     double* work;                 // n*(n+1)/2 doubles when !use_lds
     int* status;                  // [0] set to 1 when a pivot is not positive
     long long* stamps;            // debug builds (CHOL16_STAMPS) only: s_memtime stamps per step and wavefront
+    double diag_rel;              // k_chol16: factor S + diag_rel * trace(S) / n * I (0: S itself); k_gram.h says why
 };
 
 template <int T>
@@ -813,13 +814,26 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
     const int n = c.n, nb = (n + 15) >> 4, noff = nb * (nb - 1) / 2;
     const unsigned sw_addr = lds_addr(&sW[0][0][0]);
     const int cc4 = cc * 4;
+    double dshift = 0.0;
+    if (c.diag_rel > 0.0) {
+        // trace(S), summed in a fixed order (wavefront sums, then wavefront 0 over the W of them): bit-reproducible
+        double x = 0.0;
+        for (int i = t; i < n; i += 64 * W) x += c.S[(size_t)i * c.lds_ + i];
+        x = wave_sum(x);
+        if (lane == 0) sRi[0][wv] = x;
+        __syncthreads();
+        double tr = 0.0;
+        for (int w = 0; w < W; ++w) tr += sRi[0][w];
+        dshift = fmax(c.diag_rel * tr / (double)n, 1e-150);          // (all-zero S: nothing was accepted, the rows stay negligible)
+        __syncthreads();
+    }
     auto load_block = [&](int bi_, int bj_) {
         v4d a;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 16 * bi_ + g + 4 * i, col = 16 * bj_ + cc;
             double x = (r == col) ? 1.0 : 0.0;                               // identity padding beyond n
-            if (bi_ >= 0 && r < n && col < n) x = c.S[(size_t)r * c.lds_ + col];
+            if (bi_ >= 0 && r < n && col < n) x = c.S[(size_t)r * c.lds_ + col] + ((r == col) ? dshift : 0.0);
             a[i] = x;
         }
         return a;

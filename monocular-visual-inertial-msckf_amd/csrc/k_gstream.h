@@ -74,6 +74,10 @@ struct GStreamArgs {
     int* status;                             // [0]: 0 ok, 1 a pivot was not a positive normal number, 2 timeout
     double sigma2;
     int d, dc, nb, ns, ncb;                  // nb row blocks of T, ns = nb + 1 strips, ncb column blocks per row block
+    // A second, COMPLETE source of rows taken first (while the sweep that publishes T is still on its first rows): the
+    // square root of the wide tracks' Gram matrix (k_gram.h).  nb2 = 0: none.  Its rows are dense right of the diagonal.
+    const double* T2; int ldt2; int nb2;
+    int nb1;                                 // row blocks of T to take (nb, or 0 when there is no band root at all)
     long long* stamps;                       // -DGS_STAMPS builds: wall-clock stamps of workgroup 0, 8 per row block
     long long* tstamp;                       // optional: [2] wall clock (10 ns ticks) when strip 0 has stored its results
 };
@@ -273,12 +277,18 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
 
     const long long t_start = wall_clock64();
     bool failed = false;
-    for (int I = 0; I < nb; ++I) {
+    const int nb2 = p.nb2;
+    for (int J = 0; J < nb2 + p.nb1; ++J) {
+        const bool src2 = J < nb2;                                         // the complete source first
+        const int I = src2 ? J : J - nb2;
+        const double* Tsrc = src2 ? p.T2 : p.T;
+        const int ldts = src2 ? p.ldt2 : p.ldt;
+        const int ncbs = src2 ? nb : ncb;
         const int row0 = (I == 0) ? 0 : rem0 + 16 * (I - 1), nrw = (I == 0) ? rem0 : 16;   // rows [row0, row0 + nrw) of T
         const int need = row0 + nrw;
-        const unsigned long long tag = (unsigned long long)((p.epoch << 6) | (unsigned)(I + 1)) << 32;
+        const unsigned long long tag = (unsigned long long)((p.epoch << 6) | (unsigned)(J + 1)) << 32;
         // ---- A: row block I of T is final -------------------------------------------------------------------
-        if (p.progress && wv == WV - 1) {
+        if (!src2 && p.progress && wv == WV - 1) {
             for (;;) {
                 const unsigned long long v = gs_ld(p.progress);
                 if ((v >> 32) == p.epoch && (int)(v & 0xffffffffu) >= need) break;
@@ -287,10 +297,10 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             }
         }
         GS_STAMP(WV - 1, 0);                                      // rows of T seen
-        if (p.tstamp && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();
+        if (p.tstamp && !src2 && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();
         __syncthreads();
         if (sCtl[1]) { failed = true; break; }
-        const int s_lo = 1 + (row0 >> 4), s_hi = min(s_lo + ncb - 1, ns - 1);   // strips that hold T_I's columns
+        const int s_lo = 1 + (row0 >> 4), s_hi = min(s_lo + ncbs - 1, ns - 1);   // strips that hold T_I's columns
         // ---- B: partials of Y_I[r] = sum_s P(r, s) T_{I,s}^T ------------------------------------------------
         double Tt[TPW][4];
 #pragma unroll
@@ -302,7 +312,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
                 for (int u = 0; u < 4; ++u) {
                     const int col = 16 * (s - 1) + 4 * u + g;
                     const bool ok = cc < nrw && col < dc;
-                    const double x = gs_ldd(p.T + (ok ? (size_t)trow * p.ldt + col : 0));
+                    const double x = gs_ldd(Tsrc + (ok ? (size_t)trow * ldts + col : 0));
                     Tt[q][u] = ok ? x : 0.0;
                 }
                 v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -316,7 +326,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         double rhs = 0.0;
         if (wv == WV - 2 && r == 0 && g == 3) {                   // r_n of this block: the dx row's share of Y
             const int trow = row0 + cc;
-            const double x = gs_ldd(p.T + (cc < nrw ? (size_t)trow * p.ldt + dc : 0));
+            const double x = gs_ldd(Tsrc + (cc < nrw ? (size_t)trow * ldts + dc : 0));
             rhs = cc < nrw ? x : 0.0;
         }
         GS_STAMP(WV - 1, 1);                                      // partials of Y written
@@ -334,11 +344,11 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             // one round trip less on paper).  Readers that re-poll a line back to back keep being served the copy of their
             // first miss (every launch but the first timed out; a sleep between polls or a buffer_inv sc1 cured it), and
             // with the sleep the 4 KB sweeps of 13 x 13 wavefronts were slower than this: 108 against 90 us at N = 30.
-            double* dst = p.ex + ((size_t)I * ns + r) * 256 + lane;
+            double* dst = p.ex + ((size_t)J * ns + r) * 256 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gs_std(dst + 64 * i, y[i]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) gs_st(p.exflag + (size_t)I * ns + r, tag);
+            if (lane == 0) gs_st(p.exflag + (size_t)J * ns + r, tag);
             GS_STAMP(WV - 2, 2);                                   // published
         }
         // ---- D: fetch Y_I[s]; partials of A_I = sum_s T_{I,s} Y_I[s] -------------------------------------------
@@ -349,7 +359,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
 #pragma unroll
             for (int i = 0; i < 4; ++i) Yt[q][i] = 0.0;
             if (s < ns) {
-                const unsigned long long* fl = p.exflag + (size_t)I * ns + s;
+                const unsigned long long* fl = p.exflag + (size_t)J * ns + s;
                 bool ok = true;
                 for (;;) {
                     if (gs_ld(fl) == tag) break;
@@ -357,7 +367,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
                     __builtin_amdgcn_s_sleep(2);                            // (never poll a line back to back: see above)
                 }
                 if (ok) {
-                    const double* src = p.ex + ((size_t)I * ns + s) * 256 + lane;
+                    const double* src = p.ex + ((size_t)J * ns + s) * 256 + lane;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) Yt[q][i] = gs_ldd(src + 64 * i);
                 }
@@ -376,7 +386,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         GS_STAMP(WV - 1, 4);
         // ---- E: eliminate A_I (one wavefront), every tile follows: X_I[s] = Y_I[s] L_II^-T ----------------------
         const int npiv = (nrw + 3) & ~3;                                   // pivots of this block (16 but for a short first one)
-        const int half = I & 1;
+        const int half = J & 1;
         const unsigned sw_half = sw_addr + half * (16 * 17 * 8);
         double* sri = sRi + half * 16;
         if (wv == WV - 1) {

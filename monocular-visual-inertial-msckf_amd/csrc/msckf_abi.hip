@@ -26,6 +26,7 @@
 #include "k_fold.h"
 #include "k_gain.h"
 #include "k_gstream.h"
+#include "k_gram.h"
 #include "k_select.h"
 #include "k_sweep.h"
 #include "k_wsweep.h"
@@ -280,6 +281,7 @@ struct msckf_ctx {
     // plan cache: the K5 plan is a function of (N, exchange mode, the sorted tracks' first slot / last slot / view count);
     // a batch with the same key reuses the plan, its device tables and the zero pattern of the R workspace
     bool plan_valid = false;
+    bool plan_no_wide = false;            // the cached plan was made by msckf_run_compress's re-plan
     int plan_N = -1;
     bool plan_xchg = false;
     std::vector<int> plan_fmin, plan_fmax, plan_view;
@@ -342,6 +344,14 @@ struct msckf_ctx {
     int root_band = 0;                    // widest row of the root block in columns (the local plan's / the merge plan's)
     bool gs_stamp = false;                // msckf_run_timed: k_root_gain notes when its sweep ends and when its update ends
     bool gs_fused_last = false;           // the last pipeline ran k_root_gain (stage events cannot split it)
+    // tracks that span more than WIDE_SPAN clone slots go through the information form (k_gram.h): they are sorted behind the
+    // band tracks ([0, Fb) band, [Fb, F) wide), compressed to the square root of their Gram matrix and taken by K6-K7 as a
+    // second source of rows
+    int Fb = 0, Fw = 0, Mmax_band = 0, Mmax_wide = 0;
+    bool wide_active = false;             // the current plan keeps the wide tracks out of the band pipeline / tree
+    bool no_wide = false;                 // the batch was re-planned with every track in one plan (msckf_run_compress: the
+                                          // exported block must hold the wide tracks' rows too)
+    Buf dGramPart, dGramS, dGramU, dGramL, dGramInvd;
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
     int fetched_rc = 0;                   // ... and that code: msckf_commit_covariance need not read the gate results again
@@ -455,6 +465,14 @@ void invalidate_batch(msckf_ctx* c) {
     c->use_select = false;
     c->ran = false;
     c->F = 0;
+}
+
+constexpr int WIDE_SPAN = 15;                    // the band pipeline's widest track (90-column tiles)
+// may tracks wider than that take the information form on this context at N clones?
+bool wide_ok(const msckf_ctx* c, int N) {
+    if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) || c->xchg) return false;
+    static const bool off = [] { const char* e = std::getenv("MSCKF_WIDE_GRAM"); return e && std::atoi(e) == 0; }();
+    return !off && N > WIDE_SPAN && 6 * N + 1 <= 16 * GRAM_MAX_NT;
 }
 
 // ---- QR tree plan ---------------------------------------------------------
@@ -655,7 +673,8 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         //  wavefronts of two: 142 against 116 us at 10000 features)
         c->leaf_tall = wide_leaf && tall_mode != 0;
         const int rb = wide_leaf ? (c->leaf_tall ? LSweepGeom<6, LS_RS6T>::RB : LSweepGeom<6, LS_RS6>::RB) : LSweepGeom<4, LS_RS4>::RB;
-        const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * c->Mmax - 3, 1)));
+        const int mm = (c->Fw > 0 && !c->no_wide) ? c->Mmax_band : c->Mmax;      // longest track the leaves will see
+        const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * mm - 3, 1)));
         c->leaf_nf = (F >= big_batch && !c->leaf_tall) ? 12 : 8;
         const int unit = c->leaf_nf * fpb;
         static const int leaf_target = [] { const char* e = std::getenv("MSCKF_LEAF_TARGET"); return e ? std::max(1, atoi(e)) : 240; }();
@@ -814,6 +833,13 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
 void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
     c->xchg_planned = false;
+    c->wide_active = false;
+    if (c->Fw > 0 && !c->no_wide) {
+        // band plan over the band tracks only ([0, Fb) of the sorted order; with k_select: those of them that are valid)
+        std::vector<unsigned char> mask(c->F, 0);
+        for (int i = 0; i < c->Fb; ++i) mask[i] = valid ? ((*valid)[i] & 1) : 1;
+        if (build_plan_band(c, fmin, fmax, view_sorted, &mask)) { c->band_plan = true; c->wide_active = true; return; }
+    }
     c->band_plan = build_plan_band(c, fmin, fmax, view_sorted, valid);
     if (!c->band_plan) {
         c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
@@ -1026,13 +1052,21 @@ int launch_feature(msckf_ctx* c) {
     a.select = c->use_select ? ptr<unsigned char>(c->dSelFlags) : nullptr;
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
     a.zero_idx = c->stack_elems;
-    const bool chunked = 2 * c->Mmax + 1 > 32;                 // k_feature<64>: column chunks, S in registers
-    int lds_d = 0;                       // (the footprint is not monotone in the track length: whole-view chunks)
-    for (int m = 1; m <= c->Mmax; ++m) lds_d = std::max(lds_d, feature_lds_doubles(m, chunked));
-    const size_t lds = (size_t)lds_d * 8;
-    if (c->Mmax <= 10) hipLaunchKernelGGL(k_feature<24>, dim3(c->F), dim3(64), lds, c->stream, a);            // one chunk of <= 60 columns
-    else if (2 * c->Mmax + 1 <= 32) hipLaunchKernelGGL(k_feature<32>, dim3(c->F), dim3(64), lds, c->stream, a);
-    else hipLaunchKernelGGL(k_feature<64>, dim3(c->F), dim3(64), lds, c->stream, a);
+    // one launch per class of tracks: the band tracks [0, Fb) and, where they are kept apart (wide_active), the wide ones
+    // [Fb, F), each with the instance its own longest track asks for
+    auto go = [&](int f0, int nf, int mmax) {
+        if (nf <= 0) return;
+        a.f0 = f0; a.F = nf;
+        const bool chunked = 2 * mmax + 1 > 32;                // k_feature<64>: column chunks, S in registers
+        int lds_d = 0;                   // (the footprint is not monotone in the track length: whole-view chunks)
+        for (int m = 1; m <= mmax; ++m) lds_d = std::max(lds_d, feature_lds_doubles(m, chunked));
+        const size_t lds = (size_t)lds_d * 8;
+        if (mmax <= 10) hipLaunchKernelGGL(k_feature<24>, dim3(nf), dim3(64), lds, c->stream, a);            // one chunk of <= 60 columns
+        else if (2 * mmax + 1 <= 32) hipLaunchKernelGGL(k_feature<32>, dim3(nf), dim3(64), lds, c->stream, a);
+        else hipLaunchKernelGGL(k_feature<64>, dim3(nf), dim3(64), lds, c->stream, a);
+    };
+    if (c->Fw > 0) { go(0, c->Fb, c->Mmax_band); go(c->Fb, c->Fw, c->Mmax_wide); }
+    else go(0, c->F, c->Mmax);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -1209,7 +1243,8 @@ bool gstream_ok(const msckf_ctx* c, int band) {
     if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || c->dc < 1) return false;
     const int nb = (c->dc + 15) / 16, ns = nb + 1;
     if (ns > GS_MAX_NS) return false;
-    return gstream_lds_doubles(ns, gstream_ncb(c->dc, band)) * 8 <= (size_t)(LDS_MAX_BYTES - 1024);
+    const int ncb = c->wide_active ? nb : gstream_ncb(c->dc, band);      // (the wide tracks' rows are dense)
+    return gstream_lds_doubles(ns, ncb) * 8 <= (size_t)(LDS_MAX_BYTES - 1024);
 }
 // Tblk: the root block [T | r_n]; band: its widest row in columns
 void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int band, bool beside) {
@@ -1224,6 +1259,8 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.status = ptr<int>(c->dStatus);
     a.sigma2 = c->sigma * c->sigma;
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
+    a.nb1 = Tblk ? nb : 0;
+    if (c->wide_active) { a.T2 = ptr<double>(c->dGramU); a.ldt2 = dc + 1; a.nb2 = nb; }
     a.stamps = nullptr;
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
 }
@@ -1232,7 +1269,7 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
     ++c->gs_epoch;
     GStreamArgs a;
     fill_gstream_args(c, a, Tblk, band, false);
-    const size_t lds = gstream_lds_doubles(a.ns, a.ncb) * 8;
+    const size_t lds = gstream_lds_doubles(a.ns, a.nb2 > 0 ? a.nb : a.ncb) * 8;
     if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
     else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
@@ -1254,10 +1291,41 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
     GStreamArgs ga;
     fill_gstream_args(c, ga, Tblk, band, true);
     // (every workgroup asks for more than half of a CU's LDS: one per CU, the sweep has its CU to itself)
-    const size_t lds = std::max<size_t>(std::max(sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps), gstream_lds_doubles(ga.ns, ga.ncb) * 8), (size_t)84 * 1024);
+    const size_t lds = std::max<size_t>(std::max(sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps), gstream_lds_doubles(ga.ns, ga.nb2 > 0 ? ga.nb : ga.ncb) * 8),
+                                        (size_t)84 * 1024);
     hipLaunchKernelGGL((k_root_gain<SWEEP_NW, 2>), dim3(1 + ga.ns), dim3(64 * (SWEEP_NW + 1)), lds, c->stream, sa, ga);
     HIPCHK(c, hipGetLastError());
     c->gain_blocked = false;
+    return MSCKF_OK;
+}
+
+// The wide tracks [Fb, F): Gram matrix of their K4 blocks on the matrix cores, summed, factored (k_gram.h).  The rows of the
+// factor ([T2 | r2], 6N x (6N + 1) of the (6N + 1)^2 matrix U) are K6-K7's second source.
+int launch_gram_chain(msckf_ctx* c) {
+    const int dc = c->dc, n = dc + 1, nt = (n + 15) / 16, npairs = nt * (nt + 1) / 2;
+    const int G = std::max(1, std::min(c->Fw, 128));
+    if (int rc = ensure(c, c->dGramPart, (size_t)G * npairs * 256 * 8)) return rc;
+    const size_t nn = (size_t)(6 * c->maxN + 1) * (6 * c->maxN + 1) * 8;
+    if (int rc = ensure(c, c->dGramS, nn)) return rc;
+    if (int rc = ensure(c, c->dGramU, nn)) return rc;
+    if (int rc = ensure(c, c->dGramL, nn)) return rc;
+    if (int rc = ensure(c, c->dGramInvd, (size_t)(6 * c->maxN + 1) * 8)) return rc;
+    GramArgs g{};
+    g.view_ptr = ptr<int>(c->dViewPtr); g.obs_slot = ptr<int>(c->dObsSlot);
+    g.blk_off = ptr<long long>(c->dBlkOff); g.stack = ptr<double>(c->dStack);
+    g.rank = ptr<int>(c->dRank); g.accepted = ptr<unsigned char>(c->dAcc);
+    g.f0 = c->Fb; g.nf = c->Fw; g.dc = dc; g.nt = nt; g.part = ptr<double>(c->dGramPart);
+    hipLaunchKernelGGL(k_gram, dim3(G), dim3(64 * GRAM_WAVES), gram_lds_bytes(nt), c->stream, g);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, c->stream, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS));
+    HIPCHK(c, hipGetLastError());
+    // (k_chol16 writes the factor's upper triangle only; N changes the layout of U)
+    HIPCHK(c, hipMemsetAsync(c->dGramU.p, 0, (size_t)n * n * 8, c->stream));
+    CholArgs a{};
+    a.S = ptr<double>(c->dGramS); a.lds_ = n; a.L = ptr<double>(c->dGramL); a.U = ptr<double>(c->dGramU);
+    a.invd = ptr<double>(c->dGramInvd); a.n = n; a.work = nullptr; a.status = ptr<int>(c->dStatus) + 1;
+    a.diag_rel = 1e-14;
+    hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * CHOL16_W), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
 
@@ -1282,8 +1350,8 @@ int launch_root_and_gain_w(msckf_ctx* c, int node, int nsteps, int rc_log2, cons
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
     GStreamArgs ga;
     fill_gstream_args(c, ga, Tblk, band, true);
-    const size_t lds = std::max<size_t>(std::max(wsweep_lds_bytes<CS>(1 << rc_log2, SWEEP_NW, nsteps), gstream_lds_doubles(ga.ns, ga.ncb) * 8),
-                                        (size_t)84 * 1024);
+    const size_t lds = std::max<size_t>(std::max(wsweep_lds_bytes<CS>(1 << rc_log2, SWEEP_NW, nsteps),
+                                                 gstream_lds_doubles(ga.ns, ga.nb2 > 0 ? ga.nb : ga.ncb) * 8), (size_t)84 * 1024);
     if (ga.ns <= 2 * (SWEEP_NW - 1))
         hipLaunchKernelGGL((k_root_gain_w<SWEEP_NW, CS, 2>), dim3(1 + ga.ns), dim3(64 * SWEEP_NW), lds, c->stream, a, ga);
     else
@@ -1326,9 +1394,12 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c)) != MSCKF_OK) return rc;
     if (c->F > 0 && !c->band_plan && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
+    if (c->F > 0 && c->wide_active && (rc = launch_gram_chain(c)) != MSCKF_OK) return rc;
     // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront and the update's strips in ONE launch
-    const bool gs = with_gain && c->F > 0 && c->root >= 0 && gstream_ok(c, c->root_band);
-    const bool beside = gs && c->band_plan &&
+    const bool have_rows = c->root >= 0 || c->wide_active;
+    const bool gs = with_gain && c->F > 0 && have_rows && gstream_ok(c, c->root_band);
+    if (c->wide_active && !gs) { c->last_error = "wide tracks need the streamed K6-K7"; return MSCKF_ERR_STATE; }
+    const bool beside = gs && c->band_plan && c->root >= 0 &&
                         (c->sweep_mode == 0 ? (!c->h_root_flush.empty() && root_gain_ok(c, c->root_band)) : root_gain_w_ok(c, c->root_band));
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, (with_gain || !c->xchg_planned) && !beside)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
@@ -1360,8 +1431,8 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     } else {
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
-        if (with_gain && c->F > 0 && c->root >= 0) {
-            if (gs) rc = launch_gain_stream(c, root_block(c), c->root_band);
+        if (with_gain && c->F > 0 && have_rows) {
+            if (gs) rc = launch_gain_stream(c, c->root >= 0 ? root_block(c) : nullptr, c->root_band);
             else rc = launch_gain(c, root_block(c));
             if (rc != MSCKF_OK) return rc;
         }
@@ -1456,6 +1527,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain<SWEEP_NW, 2>), LDS_MAX_BYTES - 1024, "k_root_gain LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_gram), LDS_MAX_BYTES - 1024, "k_gram LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 3>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 6, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
@@ -1511,8 +1583,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     E(c->dCholWork, (size_t)dc * (dc + 1) / 2 * 8);
     {   // k_gain_stream: exchange tiles and (epoch-tagged, hence zeroed once) flags, the root sweep's progress word
         const size_t nbm = (size_t)(dc + 15) / 16, nsm = nbm + 1;
-        E(c->dGsEx, nbm * nsm * 256 * 8);
-        E(c->dGsFlag, (nbm * nsm + 8) * 8, true);
+        E(c->dGsEx, 2 * nbm * nsm * 256 * 8);          // (two sources of row blocks: the band root and the wide tracks' factor)
+        E(c->dGsFlag, (2 * nbm * nsm + 8) * 8, true);
         E(c->dGsProg, 512, true);                      // (progress word at 0, k_root_gain's time stamps on a line of their own at byte 256)
     }
     if (rc != MSCKF_OK) { msckf_destroy(c); return rc; }
@@ -1554,7 +1626,8 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
                   &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf, &c->dAssocUV, &c->dAssocRes,
-                  &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dRootFlush, &c->dXRootFlush};
+                  &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dRootFlush, &c->dXRootFlush,
+                  &c->dGramPart, &c->dGramS, &c->dGramU, &c->dGramL, &c->dGramInvd};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
@@ -1614,10 +1687,12 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     c->ran = false;
     c->have_tracks = false;
     c->use_select = false;
+    c->no_wide = false;
     if (F == 0) {
         c->F = 0;
         c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->band_plan = false; c->root = -1; c->perm.clear();
+        c->Fb = c->Fw = 0; c->wide_active = false;
         c->plan_valid = false;
         c->xchg_planned = false;
         if (c->xchg) {
@@ -1688,13 +1763,24 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     if (c->n_chi2 <= 2 * Mmax) return MSCKF_ERR_ARG;
     const int sumM = view_ptr[F];
     c->F = F; c->sumM = sumM; c->Mmax = Mmax;            // validated: commit the batch size
-    // counting sort by (first slot, last slot): stable, O(F + N^2)
+    // counting sort by (class, first slot, last slot): stable, O(F + N^2); class 1 = tracks wider than the band pipeline takes,
+    // where the information form is available for them (k_gram.h): they follow the band tracks
     c->perm.resize(F);
     {
-        std::vector<int> cnt((size_t)N * N + 1, 0);
-        for (int f = 0; f < F; ++f) cnt[(size_t)fmin_in[f] * N + fmax_in[f] + 1]++;
+        const bool wide = wide_ok(c, N);
+        const size_t NN = (size_t)N * N;
+        std::vector<int> cnt(2 * NN + 1, 0);
+        auto key = [&](int f) { return ((wide && fmax_in[f] - fmin_in[f] + 1 > WIDE_SPAN) ? NN : 0) + (size_t)fmin_in[f] * N + fmax_in[f]; };
+        for (int f = 0; f < F; ++f) cnt[key(f) + 1]++;
         for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
-        for (int f = 0; f < F; ++f) c->perm[cnt[(size_t)fmin_in[f] * N + fmax_in[f]]++] = f;
+        c->Fb = cnt[NN];                                                  // band tracks: sorted positions [0, Fb)
+        c->Fw = F - c->Fb;
+        for (int f = 0; f < F; ++f) c->perm[cnt[key(f)]++] = f;
+        c->Mmax_band = c->Mmax_wide = 0;
+        for (int sidx = 0; sidx < F; ++sidx) {
+            const int f = c->perm[sidx], M = view_ptr[f + 1] - view_ptr[f];
+            if (sidx < c->Fb) c->Mmax_band = std::max(c->Mmax_band, M); else c->Mmax_wide = std::max(c->Mmax_wide, M);
+        }
     }
     const double ts = now_us();
     // arena layout (8-byte aligned pieces): doubles first, then the 64-bit offsets, then the ints
@@ -1805,7 +1891,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->feature_launched = true;
     }
     const double t2 = now_us();
-    const bool plan_hit = c->plan_valid && c->plan_N == N && c->plan_xchg == c->xchg && c->plan_view == h_view &&
+    const bool plan_hit = c->plan_valid && !c->plan_no_wide && c->plan_N == N && c->plan_xchg == c->xchg && c->plan_view == h_view &&
                           c->plan_fmin == h_fmin && c->plan_fmax == h_fmax;
     if (!plan_hit) {
         c->plan_valid = false;
@@ -1831,6 +1917,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         if (int rcp = upload_plan(c)) return rcp;
         c->plan_fmin = h_fmin; c->plan_fmax = h_fmax;
         c->plan_valid = true;
+        c->plan_no_wide = false;
     }
     if (!c->oneshot) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->us_h2d += (float)((t2 - t1) + (now_us() - t3));
@@ -1848,6 +1935,25 @@ int msckf_run(msckf_ctx* c) {
 int msckf_run_compress(msckf_ctx* c) {
     if (!c) return MSCKF_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->have_features && c->wide_active) {
+        // the compressed block leaves this context (msckf_export_block): one plan for every track, the wide ones included
+        // (the merge tree, as before the information form existed)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->no_wide = true;
+        c->plan_valid = false;
+        plan_batch(c, c->h_fmin, c->h_fmax, c->h_view_sorted, nullptr);
+        c->plan_no_wide = true;
+        c->gather_off = c->rbuf_doubles;
+        const size_t need = (c->rbuf_doubles + 16) * 8;
+        if (c->dRbuf.bytes < need) {
+            if (c->dRbuf.p) HIPCHK(c, hipFree(c->dRbuf.p));
+            c->dRbuf.p = nullptr; c->dRbuf.bytes = 0;
+            HIPCHK(c, hipMalloc(&c->dRbuf.p, need + need / 2));
+            c->dRbuf.bytes = need + need / 2;
+        }
+        HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
+        if (int rcp = upload_plan(c)) return rcp;
+    }
     return run_pipeline(c, false, nullptr);
 }
 
@@ -1931,7 +2037,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (!(c->ran_gain && n_acc > 0)) status[0] = status[1] = 0;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
-    if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || (c->gain_blocked && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
+    if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
     if (rc == MSCKF_ERR_NOT_SPD && status[0] == 2) {       // k_gain_stream gave up waiting for rows of T or for another workgroup
         c->last_error = "k_gain_stream: timeout (the root sweep or a workgroup of the update did not make progress)";
         rc = MSCKF_ERR_HIP;
@@ -1986,7 +2092,7 @@ int msckf_commit_covariance(msckf_ctx* c) {
     const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
     if (status[0] == 2) return MSCKF_ERR_HIP;                                  // k_gain_stream timed out
-    if (status[0] != 0 || (c->gain_blocked && status[1] != 0)) return MSCKF_ERR_NOT_SPD;
+    if (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0)) return MSCKF_ERR_NOT_SPD;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MSCKF_OK;
@@ -2914,12 +3020,14 @@ int msckf_debug_gate(msckf_ctx* c, double* gamma, int32_t* qdim) {
 }
 
 int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
-    if (!c || !c->ran || c->root < 0) return MSCKF_ERR_STATE;
+    // (a batch with band AND wide tracks has two sources of rows: no single [T | r_n] to hand out)
+    if (!c || !c->ran || (c->root < 0 && !c->wide_active) || (c->root >= 0 && c->wide_active)) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int dc = c->dc;
     std::vector<double> blk((size_t)dc * (dc + 1));
-    HIPCHK(c, hipMemcpy(blk.data(), root_block(c), blk.size() * 8, hipMemcpyDeviceToHost));
+    const double* src = c->root >= 0 ? root_block(c) : ptr<double>(c->dGramU);     // rows 0 .. dc - 1 of the factor: same layout
+    HIPCHK(c, hipMemcpy(blk.data(), src, blk.size() * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < dc; ++i) {
         if (T) for (int j = 0; j < dc; ++j) T[(size_t)i * dc + j] = (j >= i) ? blk[(size_t)i * (dc + 1) + j] : 0.0;
         if (rn) rn[i] = blk[(size_t)i * (dc + 1) + dc];

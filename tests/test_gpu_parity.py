@@ -407,7 +407,7 @@ def _drop_views(prob, rng, keep_first=True, p_drop=0.35, only_first_slots=None):
     (30, 500, 15, 38, {"variable_tracks": True}, 90),   # ragged tracks up to 15 slots
     (24, 300, 13, 39, {"outlier_fraction": 0.1, "outlier_px": 500.0}, 90),
     (52, 300, 10, 40, {}, 60),                          # 60-column tiles, 312 rows of R: ring of 256 rows (k_wsweep<4>)
-    (31, 64, 31, 24, {}, None),                         # tracks wider than any sweep tile: the merge tree
+    (31, 64, 31, 24, {}, None),                         # tracks wider than any sweep tile: the information form (k_gram.h)
 ])
 def test_wide_sweep_and_ring(N, F, M, seed, kw, band):
     """Batches the plain sweep kernel cannot take -- tracks spanning 11-15 clone slots, band R larger than
@@ -434,6 +434,71 @@ def test_wide_sweep_and_ring(N, F, M, seed, kw, band):
         e.run(); r1 = e.result()
         e.run(); r2 = e.result()
         assert np.array_equal(r1.dx, r2.dx) and np.array_equal(r1.P_new, r2.P_new)
+
+
+def _concat_problems(a, b):
+    from msckf_amd import synth
+    vp = np.concatenate([a.view_ptr, a.view_ptr[-1] + b.view_ptr[1:]])
+    cat = lambda x, y: np.concatenate([x, y])
+    return synth.UpdateProblem(**{**a.__dict__, "view_ptr": vp.astype(np.int32), "obs_uv": cat(a.obs_uv, b.obs_uv),
+                                  "obs_slot": cat(a.obs_slot, b.obs_slot), "idp_base": cat(a.idp_base, b.idp_base),
+                                  "idp_m": cat(a.idp_m, b.idp_m), "idp_rho": cat(a.idp_rho, b.idp_rho)})
+
+
+@pytest.mark.parametrize("N,F,M,seed,kw", [
+    (30, 400, 30, 51, {"variable_tracks": True, "min_track": 2}),                 # tracks of 2 .. 30 slots: every class at once
+    (30, 300, 30, 52, {"variable_tracks": True, "min_track": 2, "outlier_fraction": 0.15, "outlier_px": 300.0}),
+    (24, 200, 24, 53, {"variable_tracks": True, "min_track": 12}),                # 90-column band tracks + wide ones
+    (31, 120, 31, 54, {"variable_tracks": True, "min_track": 16}),                # wide tracks only, 6N + 1 = 187 columns
+    (16, 80, 16, 55, {}),                                                         # the narrowest wide track: 16 slots
+    (20, 150, 20, 56, {"variable_tracks": True, "min_track": 2}),
+])
+def test_mixed_track_spans(N, F, M, seed, kw):
+    """The reference's window is 30 clones (MSCKF.py:45), a track grows one view per frame until it is lost (:404-412) and
+    both pruning callers hand `update` every feature of the removed clones (:669-678, :726-735): a batch mixes spans.  Tracks
+    of up to 15 slots take the band pipeline, wider ones the information form (k_gram.h), K6-K7 takes both sources of rows.
+    Against the oracle at the parity tolerance; bit-reproducible."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=seed, **kw)
+    ref = oracle.update(prob, dense_noise=False)
+    with UpdateEngine(max_clones=N, max_features=F, max_track=max(M, 2)) as e:
+        res = e.update_problem(prob)
+        assert res.status == ref["status"] == 0
+        assert np.array_equal(res.accepted, ref["accepted"])
+        assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        assert np.array_equal(res.P_new, res.P_new.T)
+        e.load(prob)
+        e.run(); r1 = e.result()
+        e.run(); r2 = e.result()
+        assert np.array_equal(r1.dx, r2.dx) and np.array_equal(r1.P_new, r2.P_new)
+
+
+def test_a_few_long_tracks_among_short_ones():
+    """1990 ten-view tracks + 10 thirty-view tracks (the shape one long-lived feature gives a frame's batch): the long ones must
+    not drag the batch out of the band pipeline.  Parity against the oracle on a smaller instance of the same shape, and the
+    all-rejected corner of the wide class (its Gram matrix is then exactly zero)."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from oracle import msckf_oracle as oracle
+    a = synth.make_problem(30, 300, 10, seed=61)
+    b = synth.make_problem(30, 6, 30, seed=62, P=a.P, poses=(a.cam_R, a.cam_t))
+    prob = _concat_problems(a, b)
+    ref = oracle.update(prob, dense_noise=False)
+    with UpdateEngine(max_clones=30, max_features=400, max_track=30) as e:
+        res = e.update_problem(prob)
+        assert res.status == ref["status"] == 0
+        assert np.array_equal(res.accepted, ref["accepted"])
+        assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+        # the wide tracks all rejected by the gate (gross outliers on every one of them): the band tracks alone update
+        bad = synth.make_problem(30, 6, 30, seed=63, P=a.P, poses=(a.cam_R, a.cam_t), outlier_fraction=1.0, outlier_px=800.0)
+        prob2 = _concat_problems(a, bad)
+        ref2 = oracle.update(prob2, dense_noise=False)
+        res2 = e.update_problem(prob2)
+        assert res2.status == ref2["status"] == 0
+        assert np.array_equal(res2.accepted, ref2["accepted"]) and not res2.accepted[300:].any()
+        assert rel_err(res2.dx, ref2["dx"]) < TOL and rel_err(res2.P_new, ref2["P_new"]) < TOL
 
 
 @pytest.mark.parametrize("seed,first_slots", [(44, None), (45, {0, 3, 20, 21}), (46, {11})])
