@@ -267,6 +267,8 @@ struct CholArgs {
     int* status;                  // [0] set to 1 when a pivot is not positive
     long long* stamps;            // debug builds (CHOL16_STAMPS) only: s_memtime stamps per step and wavefront
     double diag_rel;              // k_chol16: factor S + diag_rel * trace(S) / n * I (0: S itself); k_gram.h says why
+    unsigned long long* done_flag;   // k_chol16, optional: set to done_val once L / U / status are visible device-wide (a kernel of
+    unsigned long long done_val;     //   another stream -- k_root_gain -- waits for the factor inside its launch)
 };
 
 template <int T>
@@ -1083,6 +1085,17 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
     }
     __syncthreads();
     if (sBad && t == 0) c.status[0] = 1;
+    if (c.done_flag) {
+        // plain stores -> every wavefront's wait -> barrier -> one agent-scope release -> wait -> the flag (MI355X_MICROARCH.md,
+        // inter-workgroup visibility: valid forms, producer)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)c.done_flag, c.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 }  // namespace msckf

@@ -77,6 +77,9 @@ struct GStreamArgs {
     // A second, COMPLETE source of rows taken first (while the sweep that publishes T is still on its first rows): the
     // square root of the wide tracks' Gram matrix (k_gram.h).  nb2 = 0: none.  Its rows are dense right of the diagonal.
     const double* T2; int ldt2; int nb2;
+    const unsigned long long* t2_flag;       // null: T2 is complete when the launch starts; else (epoch << 32) | 1 once it is
+                                             // (k_chol16 of another stream sets it): strip 0 looks once when it starts and tells
+    unsigned long long* order_word;          // every strip which source goes first -- (epoch << 32) | 1: T2 (it is ready), 2: T
     int nb1;                                 // row blocks of T to take (nb, or 0 when there is no band root at all)
     long long* stamps;                       // -DGS_STAMPS builds: wall-clock stamps of workgroup 0, 8 per row block
     long long* tstamp;                       // optional: [2] wall clock (10 ns ticks) when strip 0 has stored its results
@@ -278,9 +281,33 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
     const long long t_start = wall_clock64();
     bool failed = false;
     const int nb2 = p.nb2;
-    for (int J = 0; J < nb2 + p.nb1; ++J) {
-        const bool src2 = J < nb2;                                         // the complete source first
-        const int I = src2 ? J : J - nb2;
+    // which source first: the complete one (T2) while the sweep is on its first rows -- unless T2 is still being made by
+    // another stream's kernels: then the sweep's rows first and T2 behind them
+    bool t2_first = true;
+    if (nb2 > 0 && p.t2_flag) {
+        if (wv == WV - 1) {
+            const unsigned long long ep64 = (unsigned long long)p.epoch << 32;
+            if (r == 0) {
+                const bool ready = gs_ld(p.t2_flag) == (ep64 | 1ull);
+                if (lane == 0) gs_st(p.order_word, ep64 | (ready ? 1ull : 2ull));
+                if (lane == 0) sCtl[2] = ready ? 1 : 2;
+            } else {
+                for (;;) {
+                    const unsigned long long v = gs_ld(p.order_word);
+                    if ((v >> 32) == p.epoch) { if (lane == 0) sCtl[2] = (int)(v & 3); break; }
+                    if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) { sCtl[1] = 1; sCtl[2] = 1; } break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+        }
+        __syncthreads();
+        t2_first = sCtl[2] == 1;
+    }
+    bool t2_seen = !(nb2 > 0 && p.t2_flag) || t2_first;                   // the factor's rows may be read
+    const int nb1 = p.nb1;
+    for (int J = 0; J < nb2 + nb1; ++J) {
+        const bool src2 = t2_first ? (J < nb2) : (J >= nb1);
+        const int I = t2_first ? (src2 ? J : J - nb2) : (src2 ? J - nb1 : J);
         const double* Tsrc = src2 ? p.T2 : p.T;
         const int ldts = src2 ? p.ldt2 : p.ldt;
         const int ncbs = src2 ? nb : ncb;
@@ -295,6 +322,19 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
                 if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) sCtl[1] = 1; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
+        }
+        if (src2 && !t2_seen) {                                             // (uniform) the factor is another stream's work
+            if (wv == WV - 1) {
+                const unsigned long long want = ((unsigned long long)p.epoch << 32) | 1ull;
+                for (;;) {
+                    if (gs_ld(p.t2_flag) == want) break;
+                    if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) sCtl[1] = 1; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (its producer stored plain + one release: drop this CU's L1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            t2_seen = true;
         }
         GS_STAMP(WV - 1, 0);                                      // rows of T seen
         if (p.tstamp && !src2 && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();

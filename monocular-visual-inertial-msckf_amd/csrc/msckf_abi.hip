@@ -352,6 +352,10 @@ struct msckf_ctx {
     bool no_wide = false;                 // the batch was re-planned with every track in one plan (msckf_run_compress: the
                                           // exported block must hold the wide tracks' rows too)
     Buf dGramPart, dGramS, dGramU, dGramL, dGramInvd;
+    hipStream_t stream2 = nullptr;        // the wide tracks' chain (k_feature, k_gram, k_gram_reduce, k_chol16) runs beside the band pipeline
+    hipEvent_t ev_fork = nullptr, ev_wfeat = nullptr;   // uploads done -> stream2 may start; the wide tracks' K4 blocks are written
+    bool wide_on_stream2 = false;         // this batch's wide k_feature went to stream2 (ev_wfeat pending)
+    bool wide_concurrent = true;          // MSCKF_WIDE_STREAM=0: everything on one stream
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
     int fetched_rc = 0;                   // ... and that code: msckf_commit_covariance need not read the gate results again
@@ -1054,6 +1058,7 @@ int launch_feature(msckf_ctx* c) {
     a.zero_idx = c->stack_elems;
     // one launch per class of tracks: the band tracks [0, Fb) and, where they are kept apart (wide_active), the wide ones
     // [Fb, F), each with the instance its own longest track asks for
+    hipStream_t st = c->stream;
     auto go = [&](int f0, int nf, int mmax) {
         if (nf <= 0) return;
         a.f0 = f0; a.F = nf;
@@ -1061,12 +1066,27 @@ int launch_feature(msckf_ctx* c) {
         int lds_d = 0;                   // (the footprint is not monotone in the track length: whole-view chunks)
         for (int m = 1; m <= mmax; ++m) lds_d = std::max(lds_d, feature_lds_doubles(m, chunked));
         const size_t lds = (size_t)lds_d * 8;
-        if (mmax <= 10) hipLaunchKernelGGL(k_feature<24>, dim3(nf), dim3(64), lds, c->stream, a);            // one chunk of <= 60 columns
-        else if (2 * mmax + 1 <= 32) hipLaunchKernelGGL(k_feature<32>, dim3(nf), dim3(64), lds, c->stream, a);
-        else hipLaunchKernelGGL(k_feature<64>, dim3(nf), dim3(64), lds, c->stream, a);
+        if (mmax <= 10) hipLaunchKernelGGL(k_feature<24>, dim3(nf), dim3(64), lds, st, a);            // one chunk of <= 60 columns
+        else if (2 * mmax + 1 <= 32) hipLaunchKernelGGL(k_feature<32>, dim3(nf), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL(k_feature<64>, dim3(nf), dim3(64), lds, st, a);
     };
-    if (c->Fw > 0) { go(0, c->Fb, c->Mmax_band); go(c->Fb, c->Fw, c->Mmax_wide); }
-    else go(0, c->F, c->Mmax);
+    c->wide_on_stream2 = false;
+    if (c->Fw > 0) {
+        // the wide tracks' kernel is ONE wavefront's latency per track (~6 us per view: 180 us at 30 views) however few they
+        // are: it and the chain behind it (k_gram, k_chol16) run on the second stream beside the band pipeline
+        if (!c->no_wide && c->wide_concurrent) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            st = c->stream2;
+            go(c->Fb, c->Fw, c->Mmax_wide);
+            HIPCHK(c, hipEventRecord(c->ev_wfeat, c->stream2));
+            c->wide_on_stream2 = true;
+            st = c->stream;
+            go(0, c->Fb, c->Mmax_band);
+        } else {
+            go(0, c->Fb, c->Mmax_band); go(c->Fb, c->Fw, c->Mmax_wide);
+        }
+    } else go(0, c->F, c->Mmax);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -1260,7 +1280,10 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.sigma2 = c->sigma * c->sigma;
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.nb1 = Tblk ? nb : 0;
-    if (c->wide_active) { a.T2 = ptr<double>(c->dGramU); a.ldt2 = dc + 1; a.nb2 = nb; }
+    if (c->wide_active) {
+        a.T2 = ptr<double>(c->dGramU); a.ldt2 = dc + 1; a.nb2 = nb;
+        if (c->wide_on_stream2) { a.t2_flag = ptr<unsigned long long>(c->dGsProg) + 16; a.order_word = ptr<unsigned long long>(c->dGsProg) + 24; }
+    }
     a.stamps = nullptr;
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
 }
@@ -1303,6 +1326,7 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
 // factor ([T2 | r2], 6N x (6N + 1) of the (6N + 1)^2 matrix U) are K6-K7's second source.
 int launch_gram_chain(msckf_ctx* c) {
     const int dc = c->dc, n = dc + 1, nt = (n + 15) / 16, npairs = nt * (nt + 1) / 2;
+    hipStream_t st = c->wide_on_stream2 ? c->stream2 : c->stream;
     const int G = std::max(1, std::min(c->Fw, 128));
     if (int rc = ensure(c, c->dGramPart, (size_t)G * npairs * 256 * 8)) return rc;
     const size_t nn = (size_t)(6 * c->maxN + 1) * (6 * c->maxN + 1) * 8;
@@ -1315,16 +1339,20 @@ int launch_gram_chain(msckf_ctx* c) {
     g.blk_off = ptr<long long>(c->dBlkOff); g.stack = ptr<double>(c->dStack);
     g.rank = ptr<int>(c->dRank); g.accepted = ptr<unsigned char>(c->dAcc);
     g.f0 = c->Fb; g.nf = c->Fw; g.dc = dc; g.nt = nt; g.part = ptr<double>(c->dGramPart);
-    hipLaunchKernelGGL(k_gram, dim3(G), dim3(64 * GRAM_WAVES), gram_lds_bytes(nt), c->stream, g);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, c->stream, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS));
+    hipLaunchKernelGGL(k_gram, dim3(G), dim3(64 * GRAM_WAVES), gram_lds_bytes(nt), st, g);
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS));
     HIPCHK(c, hipGetLastError());
     // (k_chol16 writes the factor's upper triangle only; N changes the layout of U)
-    HIPCHK(c, hipMemsetAsync(c->dGramU.p, 0, (size_t)n * n * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->dGramU.p, 0, (size_t)n * n * 8, st));
     CholArgs a{};
     a.S = ptr<double>(c->dGramS); a.lds_ = n; a.L = ptr<double>(c->dGramL); a.U = ptr<double>(c->dGramU);
     a.invd = ptr<double>(c->dGramInvd); a.n = n; a.work = nullptr; a.status = ptr<int>(c->dStatus) + 1;
     a.diag_rel = 1e-14;
-    hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * CHOL16_W), 0, c->stream, a);
+    if (c->wide_on_stream2) {             // K6-K7 of THIS update (the next epoch) waits for the factor inside its launch
+        a.done_flag = ptr<unsigned long long>(c->dGsProg) + 16;
+        a.done_val = ((unsigned long long)(c->gs_epoch + 1) << 32) | 1ull;
+    }
+    hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * CHOL16_W), 0, st, a);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -1394,6 +1422,8 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c)) != MSCKF_OK) return rc;
     if (c->F > 0 && !c->band_plan && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
+    if (c->F > 0 && c->wide_on_stream2 && !c->wide_active)               // (one plan for every track after all: its leaves read the wide blocks)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wfeat, 0));
     if (c->F > 0 && c->wide_active && (rc = launch_gram_chain(c)) != MSCKF_OK) return rc;
     // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront and the update's strips in ONE launch
     const bool have_rows = c->root >= 0 || c->wide_active;
@@ -1489,10 +1519,12 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { msckf_destroy(c); return MSCKF_ERR_HIP; }
     {
         const char* e1 = std::getenv("MSCKF_GAIN_STREAM");
         const char* e2 = std::getenv("MSCKF_GAIN_OVERLAP");
         c->gs_enabled = !(e1 && std::atoi(e1) == 0);
+        { const char* e3 = std::getenv("MSCKF_WIDE_STREAM"); c->wide_concurrent = !(e3 && std::atoi(e3) == 0); }
         c->gs_overlap = !(e2 && std::atoi(e2) == 0);
     }
     // every failure here is reported at create time (a dropped attribute would only surface later as an
@@ -1501,6 +1533,8 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     const char* cwhat = "";
     auto CK = [&](hipError_t e, const char* what) { if (cerr == hipSuccess && e != hipSuccess) { cerr = e; cwhat = what; } };
     for (auto& e : c->ev) CK(hipEventCreate(&e), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_wfeat, hipEventDisableTiming), "hipEventCreate");
     auto lds_attr = [&](const void* f, int bytes, const char* what) {
         CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
     };
@@ -1619,6 +1653,7 @@ void msckf_destroy(msckf_ctx* c) {
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
@@ -1632,6 +1667,9 @@ void msckf_destroy(msckf_ctx* c) {
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_wfeat) (void)hipEventDestroy(c->ev_wfeat);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
