@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-FLAG_TREE_PLAN = 1      # msckf_config.flags: always plan the K5 merge tree (no band pipeline)
+FLAG_TREE_PLAN = 1
+FLAG_BAND_ONLY = 2      # msckf_config.flags: always plan the K5 merge tree (no band pipeline)
 LIB_PATH = os.environ.get("MSCKF_LIB") or os.path.join(_HERE, "libmsckf_mi355x.so")   # MSCKF_LIB: A/B builds
 ABI_VERSION = 2
 DTYPE_F64, DTYPE_F32 = 0, 1

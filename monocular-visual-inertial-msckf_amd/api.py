@@ -73,20 +73,22 @@ class UpdateEngine:
 
     def __init__(self, max_clones: int = 30, max_features: int = 4096, max_track: int = 30,
                  device: int = 0, leaf_rows: int = 0, merge_arity: int = 0, plan: str = "auto", dtype: str = "f64"):
-        """plan: "auto" = band pipeline (k_sweep) whenever the tracks fit the sweep tiles, else the merge
-        tree; "tree" = always the merge tree (A/B, tests).
+        """plan: "auto" = band pipeline (k_sweep) for tracks of up to 10 clone slots and, on windows of up to 31 clones,
+        the information form (k_gram) for wider ones; "band" = no information form: 90-column band tiles for tracks of
+        11 - 15 slots, the merge tree beyond (what windows of more than 31 clones get anyway); "tree" = always the merge
+        tree (A/B, tests).
         dtype: "f64" = the reference's arithmetic (parity 1e-8); "f32" = fp32 storage of the stacked system and
         the Joseph covariance update on the f32 matrix cores (BASELINE.json configs[4]; tolerance in DESIGN.md)."""
         self._lib = _ffi.load()
         if max_track > _ffi.MAX_TRACK:
             raise ValueError(f"max_track {max_track} > {_ffi.MAX_TRACK}")
-        if plan not in ("auto", "tree"):
-            raise ValueError("plan must be 'auto' or 'tree'")
+        if plan not in ("auto", "band", "tree"):
+            raise ValueError("plan must be 'auto', 'band' or 'tree'")
         if dtype not in ("f64", "f32"):
             raise ValueError("dtype must be 'f64' or 'f32'")
         self.dtype = dtype
         cfg = _ffi.Config(_ffi.ABI_VERSION, device, max_clones, max_features, max_track, leaf_rows, merge_arity,
-                          _ffi.FLAG_TREE_PLAN if plan == "tree" else 0, _ffi.DTYPE_F32 if dtype == "f32" else _ffi.DTYPE_F64, 0)
+                          {"tree": _ffi.FLAG_TREE_PLAN, "band": _ffi.FLAG_BAND_ONLY}.get(plan, 0), _ffi.DTYPE_F32 if dtype == "f32" else _ffi.DTYPE_F64, 0)
         h = C.c_void_p()
         rc = self._lib.msckf_create(C.byref(h), C.byref(cfg))
         if rc != 0:

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * GRAM_WAVES) void k_gram(GramArgs p) {
 }
 
 // Sum of the partial tiles in a fixed order (bit-reproducible), written to both halves of the symmetric n x n matrix S.
-__global__ __launch_bounds__(256) void k_gram_reduce(const double* part, int nparts, int nt, int n, double* S) {
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* part, int nparts, int nt, int n, double* S, double* Uz) {
     const int npairs = nt * (nt + 1) / 2;
     int pi = blockIdx.x, ta = 0;
     while (pi >= nt - ta) { pi -= nt - ta; ++ta; }
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* part, int npa
     if (r < n && c < n) {
         S[(size_t)r * n + c] = s;
         S[(size_t)c * n + r] = s;
+        if (Uz) { Uz[(size_t)r * n + c] = 0.0; Uz[(size_t)c * n + r] = 0.0; }     // (the factor's buffer: k_chol16 fills its upper triangle)
     }
 }
 

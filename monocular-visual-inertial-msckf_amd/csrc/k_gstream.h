@@ -77,9 +77,8 @@ struct GStreamArgs {
     // A second, COMPLETE source of rows taken first (while the sweep that publishes T is still on its first rows): the
     // square root of the wide tracks' Gram matrix (k_gram.h).  nb2 = 0: none.  Its rows are dense right of the diagonal.
     const double* T2; int ldt2; int nb2;
-    const unsigned long long* t2_flag;       // null: T2 is complete when the launch starts; else (epoch << 32) | 1 once it is
-                                             // (k_chol16 of another stream sets it): strip 0 looks once when it starts and tells
-    unsigned long long* order_word;          // every strip which source goes first -- (epoch << 32) | 1: T2 (it is ready), 2: T
+    const unsigned long long* t2_flag;       // null: T2 is complete when the launch starts and is taken FIRST; else it is another
+                                             // stream's work, taken LAST, once the word reads (epoch << 32) | 1 (k_chol16 sets it)
     int nb1;                                 // row blocks of T to take (nb, or 0 when there is no band root at all)
     long long* stamps;                       // -DGS_STAMPS builds: wall-clock stamps of workgroup 0, 8 per row block
     long long* tstamp;                       // optional: [2] wall clock (10 ns ticks) when strip 0 has stored its results
@@ -282,27 +281,10 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
     bool failed = false;
     const int nb2 = p.nb2;
     // which source first: the complete one (T2) while the sweep is on its first rows -- unless T2 is still being made by
-    // another stream's kernels: then the sweep's rows first and T2 behind them
-    bool t2_first = true;
-    if (nb2 > 0 && p.t2_flag) {
-        if (wv == WV - 1) {
-            const unsigned long long ep64 = (unsigned long long)p.epoch << 32;
-            if (r == 0) {
-                const bool ready = gs_ld(p.t2_flag) == (ep64 | 1ull);
-                if (lane == 0) gs_st(p.order_word, ep64 | (ready ? 1ull : 2ull));
-                if (lane == 0) sCtl[2] = ready ? 1 : 2;
-            } else {
-                for (;;) {
-                    const unsigned long long v = gs_ld(p.order_word);
-                    if ((v >> 32) == p.epoch) { if (lane == 0) sCtl[2] = (int)(v & 3); break; }
-                    if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) { sCtl[1] = 1; sCtl[2] = 1; } break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-            }
-        }
-        __syncthreads();
-        t2_first = sCtl[2] == 1;
-    }
+    // another stream's kernels (t2_flag): then the sweep's rows first and T2 behind them.  A FIXED order per launch
+    // configuration: an order that followed the factor's arrival (tried: strip 0 handing "ready" to every strip in its
+    // exchange flag, block by block) made the result depend on timing in its last bits.
+    const bool t2_first = !(nb2 > 0 && p.t2_flag);
     bool t2_seen = !(nb2 > 0 && p.t2_flag) || t2_first;                   // the factor's rows may be read
     const int nb1 = p.nb1;
     for (int J = 0; J < nb2 + nb1; ++J) {

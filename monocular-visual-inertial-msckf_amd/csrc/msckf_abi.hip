@@ -347,7 +347,7 @@ struct msckf_ctx {
     // tracks that span more than WIDE_SPAN clone slots go through the information form (k_gram.h): they are sorted behind the
     // band tracks ([0, Fb) band, [Fb, F) wide), compressed to the square root of their Gram matrix and taken by K6-K7 as a
     // second source of rows
-    int Fb = 0, Fw = 0, Mmax_band = 0, Mmax_wide = 0;
+    int Fb = 0, Fw = 0, Fw1 = 0, Mmax_band = 0, Mmax_wide = 0, Mmax_w1 = 0;   // (Fw1 of the Fw wide tracks have <= 15 views)
     bool wide_active = false;             // the current plan keeps the wide tracks out of the band pipeline / tree
     bool no_wide = false;                 // the batch was re-planned with every track in one plan (msckf_run_compress: the
                                           // exported block must hold the wide tracks' rows too)
@@ -471,10 +471,12 @@ void invalidate_batch(msckf_ctx* c) {
     c->F = 0;
 }
 
-constexpr int WIDE_SPAN = 15;                    // the band pipeline's widest track (90-column tiles)
-// may tracks wider than that take the information form on this context at N clones?
+// Tracks of more than WIDE_SPAN clone slots take the information form where it applies (6N + 1 <= 192 columns: windows of up
+// to 31 clones): the 60-column band pipeline then never sees a track it would need the 90-column tiles for (whose root
+// sweep is 2.5 times as long) and the batch's widest track no longer decides the plan of all the others.
+constexpr int WIDE_SPAN = 10;
 bool wide_ok(const msckf_ctx* c, int N) {
-    if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || (c->cfg.flags & MSCKF_FLAG_TREE_PLAN) || c->xchg) return false;
+    if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || (c->cfg.flags & (MSCKF_FLAG_TREE_PLAN | MSCKF_FLAG_BAND_ONLY)) || c->xchg) return false;
     static const bool off = [] { const char* e = std::getenv("MSCKF_WIDE_GRAM"); return e && std::atoi(e) == 0; }();
     return !off && N > WIDE_SPAN && 6 * N + 1 <= 16 * GRAM_MAX_NT;
 }
@@ -1078,13 +1080,14 @@ int launch_feature(msckf_ctx* c) {
             HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             st = c->stream2;
-            go(c->Fb, c->Fw, c->Mmax_wide);
+            go(c->Fb + c->Fw1, c->Fw - c->Fw1, c->Mmax_wide);        // (the long ones first: theirs is the longer wavefront)
+            go(c->Fb, c->Fw1, c->Mmax_w1);
             HIPCHK(c, hipEventRecord(c->ev_wfeat, c->stream2));
             c->wide_on_stream2 = true;
             st = c->stream;
             go(0, c->Fb, c->Mmax_band);
         } else {
-            go(0, c->Fb, c->Mmax_band); go(c->Fb, c->Fw, c->Mmax_wide);
+            go(0, c->Fb, c->Mmax_band); go(c->Fb, c->Fw1, c->Mmax_w1); go(c->Fb + c->Fw1, c->Fw - c->Fw1, c->Mmax_wide);
         }
     } else go(0, c->F, c->Mmax);
     HIPCHK(c, hipGetLastError());
@@ -1282,7 +1285,7 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.nb1 = Tblk ? nb : 0;
     if (c->wide_active) {
         a.T2 = ptr<double>(c->dGramU); a.ldt2 = dc + 1; a.nb2 = nb;
-        if (c->wide_on_stream2) { a.t2_flag = ptr<unsigned long long>(c->dGsProg) + 16; a.order_word = ptr<unsigned long long>(c->dGsProg) + 24; }
+        if (c->wide_on_stream2) a.t2_flag = ptr<unsigned long long>(c->dGsProg) + 16;
     }
     a.stamps = nullptr;
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
@@ -1340,10 +1343,9 @@ int launch_gram_chain(msckf_ctx* c) {
     g.rank = ptr<int>(c->dRank); g.accepted = ptr<unsigned char>(c->dAcc);
     g.f0 = c->Fb; g.nf = c->Fw; g.dc = dc; g.nt = nt; g.part = ptr<double>(c->dGramPart);
     hipLaunchKernelGGL(k_gram, dim3(G), dim3(64 * GRAM_WAVES), gram_lds_bytes(nt), st, g);
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS));
+    // (k_chol16 writes the factor's upper triangle only and N changes the layout of U: the reduction also zeroes U)
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS), ptr<double>(c->dGramU));
     HIPCHK(c, hipGetLastError());
-    // (k_chol16 writes the factor's upper triangle only; N changes the layout of U)
-    HIPCHK(c, hipMemsetAsync(c->dGramU.p, 0, (size_t)n * n * 8, st));
     CholArgs a{};
     a.S = ptr<double>(c->dGramS); a.lds_ = n; a.L = ptr<double>(c->dGramL); a.U = ptr<double>(c->dGramU);
     a.invd = ptr<double>(c->dGramInvd); a.n = n; a.work = nullptr; a.status = ptr<int>(c->dStatus) + 1;
@@ -1730,7 +1732,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->F = 0;
         c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->band_plan = false; c->root = -1; c->perm.clear();
-        c->Fb = c->Fw = 0; c->wide_active = false;
+        c->Fb = c->Fw = c->Fw1 = 0; c->wide_active = false;
         c->plan_valid = false;
         c->xchg_planned = false;
         if (c->xchg) {
@@ -1807,17 +1809,24 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     {
         const bool wide = wide_ok(c, N);
         const size_t NN = (size_t)N * N;
-        std::vector<int> cnt(2 * NN + 1, 0);
-        auto key = [&](int f) { return ((wide && fmax_in[f] - fmin_in[f] + 1 > WIDE_SPAN) ? NN : 0) + (size_t)fmin_in[f] * N + fmax_in[f]; };
+        std::vector<int> cnt(3 * NN + 1, 0);
+        // class 0: band tracks; 1: wide tracks of up to 15 views (k_feature<32>); 2: wide tracks of 16+ views (k_feature<64>)
+        auto key = [&](int f) {
+            const int cls = (wide && fmax_in[f] - fmin_in[f] + 1 > WIDE_SPAN) ? (view_ptr[f + 1] - view_ptr[f] > 15 ? 2 : 1) : 0;
+            return cls * NN + (size_t)fmin_in[f] * N + fmax_in[f];
+        };
         for (int f = 0; f < F; ++f) cnt[key(f) + 1]++;
         for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
         c->Fb = cnt[NN];                                                  // band tracks: sorted positions [0, Fb)
-        c->Fw = F - c->Fb;
+        c->Fw1 = cnt[2 * NN] - c->Fb;                                     // wide, <= 15 views: [Fb, Fb + Fw1)
+        c->Fw = F - c->Fb;                                                // all wide tracks: [Fb, F)
         for (int f = 0; f < F; ++f) c->perm[cnt[key(f)]++] = f;
-        c->Mmax_band = c->Mmax_wide = 0;
+        c->Mmax_band = c->Mmax_wide = c->Mmax_w1 = 0;
         for (int sidx = 0; sidx < F; ++sidx) {
             const int f = c->perm[sidx], M = view_ptr[f + 1] - view_ptr[f];
-            if (sidx < c->Fb) c->Mmax_band = std::max(c->Mmax_band, M); else c->Mmax_wide = std::max(c->Mmax_wide, M);
+            if (sidx < c->Fb) c->Mmax_band = std::max(c->Mmax_band, M);
+            else if (sidx < c->Fb + c->Fw1) c->Mmax_w1 = std::max(c->Mmax_w1, M);
+            else c->Mmax_wide = std::max(c->Mmax_wide, M);
         }
     }
     const double ts = now_us();
@@ -3058,14 +3067,42 @@ int msckf_debug_gate(msckf_ctx* c, double* gamma, int32_t* qdim) {
 }
 
 int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
-    // (a batch with band AND wide tracks has two sources of rows: no single [T | r_n] to hand out)
-    if (!c || !c->ran || (c->root < 0 && !c->wide_active) || (c->root >= 0 && c->wide_active)) return MSCKF_ERR_STATE;
+    if (!c || !c->ran || (c->root < 0 && !c->wide_active)) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
     const int dc = c->dc;
     std::vector<double> blk((size_t)dc * (dc + 1));
     const double* src = c->root >= 0 ? root_block(c) : ptr<double>(c->dGramU);     // rows 0 .. dc - 1 of the factor: same layout
     HIPCHK(c, hipMemcpy(blk.data(), src, blk.size() * 8, hipMemcpyDeviceToHost));
+    if (c->root >= 0 && c->wide_active) {
+        // band AND wide tracks: K6-K7 took two sources of rows.  For this diagnostic ONE [T | r_n] with the same Gram matrix:
+        // the Cholesky factor of [R1 r1]^T [R1 r1] + [U z]^T [U z] (shifted like the device's, k_gram.h), on the host
+        const int n = dc + 1;
+        std::vector<double> blk2((size_t)dc * n), G((size_t)n * n, 0.0);
+        HIPCHK(c, hipMemcpy(blk2.data(), c->dGramU.p, blk2.size() * 8, hipMemcpyDeviceToHost));
+        for (const std::vector<double>* B : {&blk, &blk2})
+            for (int k = 0; k < dc; ++k)
+                for (int i = k; i < n; ++i) {
+                    const double a = (*B)[(size_t)k * n + i];
+                    if (a == 0.0) continue;
+                    for (int j = i; j < n; ++j) G[(size_t)i * n + j] += a * (*B)[(size_t)k * n + j];
+                }
+        double tr = 0.0;
+        for (int i = 0; i < n; ++i) tr += G[(size_t)i * n + i];
+        for (int i = 0; i < n; ++i) G[(size_t)i * n + i] += 1e-14 * tr / n;
+        for (int i = 0; i < n; ++i) {                          // upper factor, row by row
+            for (int k = 0; k < i; ++k) {
+                const double u = G[(size_t)k * n + i];
+                if (u == 0.0) continue;
+                for (int j = i; j < n; ++j) G[(size_t)i * n + j] -= u * G[(size_t)k * n + j];
+            }
+            const double piv = std::sqrt(std::max(G[(size_t)i * n + i], 1e-300));
+            for (int j = i; j < n; ++j) G[(size_t)i * n + j] /= piv;
+        }
+        for (int i = 0; i < dc; ++i)
+            for (int j = 0; j < n; ++j) blk[(size_t)i * n + j] = (j >= i) ? G[(size_t)i * n + j] : 0.0;
+    }
     for (int i = 0; i < dc; ++i) {
         if (T) for (int j = 0; j < dc; ++j) T[(size_t)i * dc + j] = (j >= i) ? blk[(size_t)i * (dc + 1) + j] : 0.0;
         if (rn) rn[i] = blk[(size_t)i * (dc + 1) + dc];
