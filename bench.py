@@ -309,12 +309,14 @@ def main():
                  ("configs[3] on one GPU", 30, 8000, 10, "f64", 50, None),
                  ("configs[4] in fp64", 50, 20000, 15, "f64", 20, None),
                  ("configs[4] fp32 storage + f32 MFMA P-update", 50, 20000, 15, "f32", 20, None),
-                 # tracks of 2..30 consecutive clones (the reference's default window is 30 clones, MSCKF.py:45): spans over
-                 # 15 slots leave the band pipeline for the merge tree -- the cliff is on record here
+                 # tracks of 2..30 consecutive clones (the reference's default window is 30 clones, MSCKF.py:45): tracks of more
+                 # than 10 slots take the information form (k_gram.h) beside the band pipeline of the others
                  ("long spans: N=30, 2000 features, track ~ U[2, 30]", 30, 2000, 30, "f64", 20,
                   lambda sd: synth.make_problem(30, 2000, 30, seed=sd, variable_tracks=True, min_track=2)),
-                 ("spans <= 15: N=30, 2000 features, track ~ U[2, 15] (90-column tiles)", 30, 2000, 15, "f64", 50,
+                 ("spans <= 15: N=30, 2000 features, track ~ U[2, 15]", 30, 2000, 15, "f64", 50,
                   lambda sd: synth.make_problem(30, 2000, 15, seed=sd, variable_tracks=True, min_track=2)),
+                 ("a few long tracks: N=30, 1990 ten-view + 10 thirty-view tracks", 30, 2000, 30, "f64", 50,
+                  lambda sd: synth.few_long_tracks_problem(30, 2000, 10, 10, seed=sd)),
                  ("10 % gross outliers: N=30, 2000 features, track=10", 30, 2000, 10, "f64", 50,
                   lambda sd: synth.make_problem(30, 2000, 10, seed=sd, outlier_fraction=0.10, outlier_px=400.0))]
         for name, n, f, m, dt, st, mk in extra:

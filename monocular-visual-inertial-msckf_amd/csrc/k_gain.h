@@ -267,8 +267,8 @@ struct CholArgs {
     int* status;                  // [0] set to 1 when a pivot is not positive
     long long* stamps;            // debug builds (CHOL16_STAMPS) only: s_memtime stamps per step and wavefront
     double diag_rel;              // k_chol16: factor S + diag_rel * trace(S) / n * I (0: S itself); k_gram.h says why
-    unsigned long long* done_flag;   // k_chol16, optional: set to done_val once L / U / status are visible device-wide (a kernel of
-    unsigned long long done_val;     //   another stream -- k_root_gain -- waits for the factor inside its launch)
+    unsigned long long* done_flag;   // k_chol16, optional: done_val | rows of U (16 per step) that are final and visible device-wide:
+    unsigned long long done_val;     //   a kernel of another stream (k_root_gain) follows the factor row block by row block
 };
 
 template <int T>
@@ -848,7 +848,10 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
             if (r < n && col <= r) {
                 const double x = a[i];
                 c.L[(size_t)r * n + col] = x;
-                c.U[(size_t)col * n + r] = x;
+                if (c.done_flag)                                             // (read by another kernel while this one runs: write-through)
+                    __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)(c.U + (size_t)col * n + r),
+                                       (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else c.U[(size_t)col * n + r] = x;
                 if (c.work) c.work[r * (r + 1) / 2 + col] = (r == col) ? 1.0 : x * ri;
                 if (r == col) c.invd[col] = ri;
             }
@@ -880,6 +883,9 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
     const int oo = g * 16 + cc;                  // operand element (row cc, column 4 q + g) of a block at [q * 64 + oo]
     for (int k = 0; k < nb; ++k) {
         CHOL16_STAMP(0);
+        // (done_flag: block row k - 1 of U went out behind the last barrier; every wavefront waits for its stores here, the
+        //  barrier of this step orders the waits, and thread 0 then publishes the 16 k rows that are final and visible)
+        if (c.done_flag && k > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // The trailing update of step k - 1 (X blocks in buffer (k - 1) & 1) is split: T1 = my diagonal block and my block
         // of column k, right here; T2 = the rest, ahead of following THIS step's pivots -- a pivot costs the followers
         // less than its owner, they catch up -- or, for the owner of the diagonal block, behind its elimination (T2 must
@@ -1081,20 +1087,21 @@ __global__ __launch_bounds__(64 * CHOL16_W) void k_chol16(CholArgs c) {
         __syncthreads();
         CHOL16_STAMP(3);
         if (sBad) break;                                   // uniform: read after a barrier
+        if (c.done_flag && k > 0 && t == 0)
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)c.done_flag, c.done_val | (unsigned)(16 * k),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (i0 >= 0) store_block(asel, i0, k, ri_out);     // the finished panel block, off the critical path
     }
     __syncthreads();
     if (sBad && t == 0) c.status[0] = 1;
     if (c.done_flag) {
-        // plain stores -> every wavefront's wait -> barrier -> one agent-scope release -> wait -> the flag (MI355X_MICROARCH.md,
-        // inter-workgroup visibility: valid forms, producer)
+        // write-through stores of U -> every wavefront's wait -> barrier -> the count (MI355X_MICROARCH.md, inter-workgroup
+        // visibility); a failed factorisation publishes too: its reader must not wait for rows that never come
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)c.done_flag, c.done_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (t == 0)
+            __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)c.done_flag, c.done_val | (unsigned)(16 * nb),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -78,7 +78,7 @@ struct GStreamArgs {
     // square root of the wide tracks' Gram matrix (k_gram.h).  nb2 = 0: none.  Its rows are dense right of the diagonal.
     const double* T2; int ldt2; int nb2;
     const unsigned long long* t2_flag;       // null: T2 is complete when the launch starts and is taken FIRST; else it is another
-                                             // stream's work, taken LAST, once the word reads (epoch << 32) | 1 (k_chol16 sets it)
+                                             // stream's work, taken LAST, as the word (epoch << 32) | rows says its rows are final
     int nb1;                                 // row blocks of T to take (nb, or 0 when there is no band root at all)
     long long* stamps;                       // -DGS_STAMPS builds: wall-clock stamps of workgroup 0, 8 per row block
     long long* tstamp;                       // optional: [2] wall clock (10 ns ticks) when strip 0 has stored its results
@@ -305,18 +305,16 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
                 __builtin_amdgcn_s_sleep(8);
             }
         }
-        if (src2 && !t2_seen) {                                             // (uniform) the factor is another stream's work
-            if (wv == WV - 1) {
-                const unsigned long long want = ((unsigned long long)p.epoch << 32) | 1ull;
+        if (src2 && !t2_seen) {                                             // (uniform) the factor is another stream's work:
+            if (wv == WV - 1) {                                             // k_chol16 publishes its rows 16 at a time
                 for (;;) {
-                    if (gs_ld(p.t2_flag) == want) break;
+                    const unsigned long long v = gs_ld(p.t2_flag);
+                    if ((v >> 32) == p.epoch && (int)(v & 0xffffffffu) >= min(need, 16 * nb)) break;
                     if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) sCtl[1] = 1; break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (its producer stored plain + one release: drop this CU's L1)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            t2_seen = true;
+            if (I + 1 == nb) t2_seen = true;
         }
         GS_STAMP(WV - 1, 0);                                      // rows of T seen
         if (p.tstamp && !src2 && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();

@@ -1352,7 +1352,7 @@ int launch_gram_chain(msckf_ctx* c) {
     a.diag_rel = 1e-14;
     if (c->wide_on_stream2) {             // K6-K7 of THIS update (the next epoch) waits for the factor inside its launch
         a.done_flag = ptr<unsigned long long>(c->dGsProg) + 16;
-        a.done_val = ((unsigned long long)(c->gs_epoch + 1) << 32) | 1ull;
+        a.done_val = (unsigned long long)(c->gs_epoch + 1) << 32;
     }
     hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * CHOL16_W), 0, st, a);
     HIPCHK(c, hipGetLastError());

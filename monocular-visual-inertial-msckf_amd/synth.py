@@ -255,3 +255,19 @@ CONFIGS = {
     "cfg5": (50, 20000, 15),     # fp32 storage
     "north_star": (30, 10000, 10),
 }
+
+
+def concat_problems(a: UpdateProblem, b: UpdateProblem) -> UpdateProblem:
+    """The tracks of `b` appended to those of `a` (same state: build `b` with P=a.P, poses=(a.cam_R, a.cam_t))."""
+    vp = np.concatenate([a.view_ptr, a.view_ptr[-1] + b.view_ptr[1:]]).astype(np.int32)
+    cat = lambda x, y: np.concatenate([x, y])
+    return UpdateProblem(**{**a.__dict__, "view_ptr": vp, "obs_uv": cat(a.obs_uv, b.obs_uv), "obs_slot": cat(a.obs_slot, b.obs_slot),
+                            "idp_base": cat(a.idp_base, b.idp_base), "idp_m": cat(a.idp_m, b.idp_m), "idp_rho": cat(a.idp_rho, b.idp_rho)})
+
+
+def few_long_tracks_problem(N: int = 30, F: int = 2000, n_long: int = 10, M_short: int = 10, seed: int = 0) -> UpdateProblem:
+    """F - n_long tracks of M_short views and n_long tracks that span the whole window: the shape a handful of long-lived
+    features give a frame's batch (reference window: 30 clones, MSCKF.py:45; tracks grow a view per frame, :404-412)."""
+    a = make_problem(N, F - n_long, M_short, seed=seed)
+    b = make_problem(N, n_long, N, seed=seed + 100, P=a.P, poses=(a.cam_R, a.cam_t))
+    return concat_problems(a, b)
