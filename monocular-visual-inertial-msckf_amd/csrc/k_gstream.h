@@ -80,6 +80,8 @@ struct GStreamArgs {
     const unsigned long long* t2_flag;       // null: T2 is complete when the launch starts and is taken FIRST; else it is another
                                              // stream's work, taken LAST, as the word (epoch << 32) | rows says its rows are final
     int nb1;                                 // row blocks of T to take (nb, or 0 when there is no band root at all)
+    int f32_update;                          // msckf_config.dtype = f32: the rank-16 products X_I[s] X_I[r]^T of the P-update on the
+                                             // f32 matrix cores (fp32 operands and sums of 16 terms; P itself stays fp64)
     long long* stamps;                       // -DGS_STAMPS builds: wall-clock stamps of workgroup 0, 8 per row block
     long long* tstamp;                       // optional: [2] wall clock (10 ns ticks) when strip 0 has stored its results
 };
@@ -458,7 +460,18 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
                 const int s = (wv < TW) ? wv + TW * q : GS_MAX_NS + 1;
-                if (s < ns) {
+                if (s < ns && p.f32_update) {
+                    // v_mfma_f32_16x16x4_f32 leaves row 4 (lane >> 4) + reg of the product in a lane, the fp64 tile holds row
+                    // (lane >> 4) + 4 reg: the A operand takes the rows of X_I[s] in the order pi(m) = (m >> 2) + 4 (m & 3), which
+                    // puts product row (lane >> 4) + 4 reg exactly where the fp64 accumulator keeps it
+                    const double* xs = sX + (size_t)s * GS_XT + g * GS_XS + ((cc >> 2) + 4 * (cc & 3));
+                    v4f accf = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        accf = __builtin_amdgcn_mfma_f32_16x16x4f32((float)(-xs[4 * GS_XS * u]), (float)bv[u], accf, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Pt[q][i] += (double)accf[i];
+                } else if (s < ns) {
                     const double* xs = sX + (size_t)s * GS_XT + g * GS_XS + cc;
                     double av[4];
 #pragma unroll

@@ -1263,7 +1263,10 @@ int launch_gain(msckf_ctx* c, const double* Tblk) {
 
 // ---- K6-K7 as the sequential block update of k_gstream.h ---------------------------------------------------------
 bool gstream_ok(const msckf_ctx* c, int band) {
-    if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || c->dc < 1) return false;
+    // (dtype f32 = fp32 STORAGE of the K4 stack and the P-update's rank-16 products on the f32 matrix cores inside the
+    //  sequential block update -- in place of the f32-MFMA Joseph launches of rounds 2-3, 200 us behind the sweep at N = 50;
+    //  MSCKF_GAIN_STREAM=0 brings those back)
+    if (!c->gs_enabled || c->dc < 1) return false;
     const int nb = (c->dc + 15) / 16, ns = nb + 1;
     if (ns > GS_MAX_NS) return false;
     const int ncb = c->wide_active ? nb : gstream_ncb(c->dc, band);      // (the wide tracks' rows are dense)
@@ -1283,6 +1286,7 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.sigma2 = c->sigma * c->sigma;
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.nb1 = Tblk ? nb : 0;
+    a.f32_update = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
     if (c->wide_active) {
         a.T2 = ptr<double>(c->dGramU); a.ldt2 = dc + 1; a.nb2 = nb;
         if (c->wide_on_stream2) a.t2_flag = ptr<unsigned long long>(c->dGsProg) + 16;
@@ -3020,7 +3024,7 @@ int msckf_get_shared_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* ac
     std::memcpy(status, c->hRes, 16);
     const int dc = c->dc;
     // (as launch_gain decides; k_gain_stream -- dtype f64 -- uses the first status word only)
-    const bool blocked = !(c->gs_enabled && c->cfg.dtype == MSCKF_DTYPE_F64 && (dc + 15) / 16 + 1 <= GS_MAX_NS) &&
+    const bool blocked = !(c->gs_enabled && (dc + 15) / 16 + 1 <= GS_MAX_NS) &&
                          dc > 4 * CHOL_TILE_MAX_NT && dc <= 2 * GAIN_BLK && dc - GAIN_BLK >= 4;
     const int n_acc = status[2];
     int rc = (n_acc <= 0) ? MSCKF_NOOP : MSCKF_OK;
