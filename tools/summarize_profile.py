@@ -2,7 +2,7 @@
 """Condense the rocprofv3 outputs of tools/profile_round.sh into profiles/<tag>_*.{csv,md}."""
 import csv, glob, json, os, sys
 from collections import defaultdict
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/profiles_{tag}"
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
@@ -34,9 +34,13 @@ def pmc_multi(kind):
 mfma, sq = pmc_multi("mfma"), pmc_multi("sq")
 bench = [l for l in open(f"{src}/stats_bench.log") if l.startswith("{")]
 line = json.loads(bench[-1]) if bench else {}
+command = open(f"{src}/command.txt").read().strip() if os.path.exists(f"{src}/command.txt") else "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs"
+last_log = [l.strip() for l in open(f"{src}/stats_bench.log") if l.strip()][-1:]
 with open(f"{dst}/{tag}_summary.md", "w") as f:
-    f.write(f"# rocprofv3 summary {tag}\n\ncommand: `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs` "
-            "(+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)\n\n")
+    f.write(f"# rocprofv3 summary {tag}\n\ncommand: `rocprofv3 --kernel-trace --stats -- {command}` "
+            "(+ separate `--pmc` passes: FETCH_SIZE; WRITE_SIZE; matrix-core counters; SQ counters)\n\n")
+    if last_log and not line:
+        f.write(f"the profiled program's own report: `{last_log[0]}`\n\n")
     f.write("| kernel | calls | avg us | total % | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch |\n|---|---|---|---|---|---|\n")
     for r in rows:
         n = r["Name"].strip('"')
@@ -78,5 +82,9 @@ for r in rows:
     n = r["Name"].strip('"')
     pm[n] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1000.0,
              "fetch_kb": fetch.get(n, (None,))[0], "write_kb": write.get(n, (None,))[0]}
-json.dump({"tag": tag, "kernels": pm, "workload": line.get("config", {}).get("workload")}, open(f"{dst}/{tag}_pmc.json", "w"), indent=1)
+    for cname, src_d in (("SQ_INSTS_VALU_FMA_F64", sq), ("SQ_INSTS_VALU", sq), ("SQ_INSTS_VALU_MFMA_MOPS_F64", mfma),
+                         ("SQ_INSTS_VALU_MFMA_MOPS_F32", mfma), ("SQ_VALU_MFMA_BUSY_CYCLES", mfma), ("GRBM_GUI_ACTIVE", mfma)):
+        v = src_d.get(n, {}).get(cname)
+        pm[n][cname] = v[0] if v else None
+json.dump({"tag": tag, "kernels": pm, "command": command, "workload": line.get("config", {}).get("workload")}, open(f"{dst}/{tag}_pmc.json", "w"), indent=1)
 print(open(f"{dst}/{tag}_summary.md").read())
