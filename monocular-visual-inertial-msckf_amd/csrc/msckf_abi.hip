@@ -2812,16 +2812,19 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         int ms = 0;
         for (int i = 0; i < c->x_n_merges; ++i) ms = std::max(ms, c->x_snodes[i].nsteps);
         const int rs = c->x_snodes.back().nsteps;
+        const bool fused = root_gain_w_ok(c, XW);               // the root sweep and K6-K7 in one launch (k_root_gain_w)
         if (xmode == 1) {
             if (c->x_n_merges > 0) launch_wsweep<4>(c, nb, c->x_n_merges, WS_RC_LOG2_4, ms, rb + c->x_zero_off);
-            launch_wsweep<4>(c, nb + c->x_n_merges, 1, WS_RC_LOG2_4, rs, rb + c->x_zero_off);
+            if (!fused) launch_wsweep<4>(c, nb + c->x_n_merges, 1, WS_RC_LOG2_4, rs, rb + c->x_zero_off);
         } else {
             if (c->x_n_merges > 0) launch_wsweep<6>(c, nb, c->x_n_merges, WS_RC_LOG2_6, ms, rb + c->x_zero_off);
-            launch_wsweep<6>(c, nb + c->x_n_merges, 1, WS_RC_LOG2_6, rs, rb + c->x_zero_off);
+            if (!fused) launch_wsweep<6>(c, nb + c->x_n_merges, 1, WS_RC_LOG2_6, rs, rb + c->x_zero_off);
         }
         HIPCHK(c, hipGetLastError());
         int rcg;
-        if (gstream_ok(c, XW)) rcg = launch_gain_stream(c, rb + c->x_root_off, XW);
+        if (fused && xmode == 1) rcg = launch_root_and_gain_w<4>(c, nb + c->x_n_merges, rs, WS_RC_LOG2_4, rb + c->x_zero_off, rb + c->x_root_off, XW);
+        else if (fused) rcg = launch_root_and_gain_w<6>(c, nb + c->x_n_merges, rs, WS_RC_LOG2_6, rb + c->x_zero_off, rb + c->x_root_off, XW);
+        else if (gstream_ok(c, XW)) rcg = launch_gain_stream(c, rb + c->x_root_off, XW);
         else rcg = launch_gain(c, rb + c->x_root_off);
         if (rcg != MSCKF_OK) return rcg;
         if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
