@@ -1,4 +1,7 @@
-// K6-K7: Kalman gain and Joseph-form covariance update.
+// K6-K7 as separate launches behind K5 (rounds 1-3): Kalman gain and Joseph-form covariance update.  Since round 4 the
+// update runs as k_gstream.h's sequential block update beside the root sweep; what is still used of this file: k_chol16
+// (the wide tracks' Gram matrix, k_gram.h), the in-wave elimination it lent k_gstream.h, and the whole chain for windows
+// of more than 82 clones / MSCKF_GAIN_STREAM=0.
 //   reference MSCKF.py:604-607 : S = T P T^T + R_n ; K = P T^T S^-1 ; dx = K r_n
 //   reference MSCKF.py:612-614 : P+ = (I-KT) P (I-KT)^T + K R_n K^T ; P+ <- (P+ + P+^T)/2
 // with R_n = sigma^2 I (Q^T (sigma^2 I) Q, MSCKF.py:598) and T = [0 | R] acting

@@ -12,10 +12,11 @@
 //     X_I = Y_I L_II^-T,  L_II = chol(A_I)
 //     P^(I+1) = P^(I) - X_I X_I^T
 //
-// Row block I of T is final as soon as the root sweep has passed it, i.e. this whole stage runs BESIDE the sweep
-// (it polls the progress word the sweep's flusher publishes) and only the last block trails it: K6-K7 used to be
-// 102 us of launches behind K5 (two 180-deep products, a 180-column Cholesky, two triangular sweeps, the Joseph
-// products), every one of them waiting for the complete T.  Checked against the reference's own outputs in
+// Row block I of T is final as soon as the root sweep has passed it, i.e. this whole stage runs BESIDE the sweep, in
+// the same launch (k_root_gain / k_root_gain_w at the end of this file: workgroup 0 sweeps and publishes a progress
+// word, the other workgroups are the strips below), and only the last block trails it: K6-K7 used to be 102 us of
+// launches behind K5 (two 180-deep products, a 180-column Cholesky, two triangular sweeps, the Joseph products),
+// every one of them waiting for the complete T.  Checked against the reference's own outputs in
 // tests (1e-15 on P+ in NumPy on all golden fixtures, recipe B included: each A_I is a 16 x 16 matrix of modest
 // condition, where the reference inverts the whole S).
 //
@@ -44,15 +45,12 @@
 namespace msckf {
 
 typedef __attribute__((address_space(1))) unsigned long long gs_gu64;
-#ifndef GS_SCOPE
-#define GS_SCOPE __HIP_MEMORY_SCOPE_AGENT
-#endif
 __device__ __forceinline__ unsigned long long gs_ld(const void* p) {
-    return __hip_atomic_load((const gs_gu64*)(const unsigned long long*)p, __ATOMIC_RELAXED, GS_SCOPE);
+    return __hip_atomic_load((const gs_gu64*)(const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double gs_ldd(const double* p) { return __longlong_as_double((long long)gs_ld(p)); }
 __device__ __forceinline__ void gs_st(void* p, unsigned long long v) {
-    __hip_atomic_store((gs_gu64*)(unsigned long long*)p, v, __ATOMIC_RELAXED, GS_SCOPE);
+    __hip_atomic_store((gs_gu64*)(unsigned long long*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void gs_std(double* p, double v) { gs_st(p, (unsigned long long)__double_as_longlong(v)); }
 

@@ -396,3 +396,37 @@ def test_generated_feature_groups_header_is_current():
             else:
                 i, t = acc, oth - n_out
                 assert name.startswith("vq[") and entry == (num + i) * 3 + t and neg == "-" and in_list[oth - n_out] == "w%d" % t
+
+
+def test_concat_problems_and_few_long_tracks():
+    """synth.concat_problems / few_long_tracks_problem (the mixed-span batches of bench.py and tests): a valid CSR batch on one
+    state, and the oracle's update of it is the update of its parts' stacked rows (order independence, MSCKF.py:573)."""
+    import msckf_amd  # noqa: F401
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    a = synth.make_problem(12, 40, 5, seed=3)
+    b = synth.make_problem(12, 4, 12, seed=4, P=a.P, poses=(a.cam_R, a.cam_t))
+    c = synth.concat_problems(a, b)
+    assert c.F == 44 and c.view_ptr[0] == 0 and np.all(np.diff(c.view_ptr) >= 1)
+    assert c.view_ptr[-1] == len(c.obs_slot) == len(c.obs_uv)
+    assert np.array_equal(c.P, a.P) and np.array_equal(c.cam_t, a.cam_t)
+    out_c = oracle.update(c, dense_noise=False)
+    swapped = synth.concat_problems(b, synth.UpdateProblem(**{**a.__dict__}))
+    out_s = oracle.update(swapped, dense_noise=False)
+    assert out_c["status"] == out_s["status"] == 0
+    assert np.linalg.norm(out_c["dx"] - out_s["dx"]) < 1e-10 * np.linalg.norm(out_c["dx"])
+    assert np.linalg.norm(out_c["P_new"] - out_s["P_new"]) < 1e-11 * np.linalg.norm(out_c["P_new"])
+    p = synth.few_long_tracks_problem(16, 60, 3, 6, seed=1)
+    lens = np.diff(p.view_ptr)
+    assert p.F == 60 and (lens == 16).sum() == 3 and (lens == 6).sum() == 57
+
+
+def test_plan_flags_of_the_header_and_the_binding_agree():
+    """MSCKF_FLAG_* in include/msckf_mi355x.h == the values monocular-visual-inertial-msckf_amd/_ffi.py passes (plan="band")."""
+    import re
+    import msckf_amd  # noqa: F401
+    from msckf_amd import _ffi
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "msckf_mi355x.h")).read()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (MSCKF_FLAG_\w+) (\d+)", hdr)}
+    assert vals["MSCKF_FLAG_TREE_PLAN"] == _ffi.FLAG_TREE_PLAN == 1
+    assert vals["MSCKF_FLAG_BAND_ONLY"] == _ffi.FLAG_BAND_ONLY == 2

@@ -35,7 +35,7 @@ mfma, sq = pmc_multi("mfma"), pmc_multi("sq")
 bench = [l for l in open(f"{src}/stats_bench.log") if l.startswith("{")]
 line = json.loads(bench[-1]) if bench else {}
 command = open(f"{src}/command.txt").read().strip() if os.path.exists(f"{src}/command.txt") else "python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extra-configs"
-last_log = [l.strip() for l in open(f"{src}/stats_bench.log") if l.strip()][-1:]
+last_log = [l.strip() for l in open(f"{src}/stats_bench.log") if l.startswith("N=")][-1:]
 with open(f"{dst}/{tag}_summary.md", "w") as f:
     f.write(f"# rocprofv3 summary {tag}\n\ncommand: `rocprofv3 --kernel-trace --stats -- {command}` "
             "(+ separate `--pmc` passes: FETCH_SIZE; WRITE_SIZE; matrix-core counters; SQ counters)\n\n")
