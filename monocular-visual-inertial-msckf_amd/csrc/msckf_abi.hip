@@ -31,6 +31,7 @@
 #include "k_sweep.h"
 #include "k_wsweep.h"
 #include "k_lsweep.h"
+#include "k_gather.h"
 #include "k_state.h"
 #include "k_assoc.h"
 
@@ -320,7 +321,7 @@ struct msckf_ctx {
     std::vector<double> h_cam[4];         // host mirror of cam_R / cam_t / cam_R0 / cam_t0 (clone bookkeeping, f2)
     // arenas: what travels together lives together, so each direction is ONE copy through pinned memory
     // (a pageable hipMemcpyAsync costs ~9 us apiece; the 15 + 6 of them were 270 us of the host-inclusive call)
-    Buf dPoseArena, dFeatArena, dResArena, dGateArena;
+    Buf dPoseArena, dFeatArena, dRawArena, dResArena, dGateArena;     // dRawArena: the tracks in the caller's order (k_gather.h)
     void *hPose = nullptr, *hFeat = nullptr, *hRes = nullptr, *hGate = nullptr, *hP = nullptr;   // pinned staging
     size_t hFeatCap = 0, res_dx_off = 0, res_p_off = 0;
     size_t res_mask_off = 0, res_mask_cap = 0, res_cap = 0;   // gate bytes of the whole (sharded) batch behind P_out; arena bytes
@@ -355,6 +356,12 @@ struct msckf_ctx {
     hipStream_t stream2 = nullptr;        // the wide tracks' chain (k_feature, k_gram, k_gram_reduce, k_chol16) runs beside the band pipeline
     hipEvent_t ev_fork = nullptr, ev_wfeat = nullptr;   // uploads done -> stream2 may start; the wide tracks' K4 blocks are written
     bool wide_on_stream2 = false;         // this batch's wide k_feature went to stream2 (ev_wfeat pending)
+    // The one-shot call's K5 plan (a memset of the workspace + four to six tables of a few KB, each a ~5 us blit kernel) goes up on
+    // a stream of its own beside K1-K4; the main stream waits for ev_plan in front of K5.  (In the main stream the copies sat
+    // between k_feature and k_lsweep: 25 us of the call at the headline, rocprofv3 --memory-copy-trace.)
+    hipStream_t stream_up = nullptr;
+    hipEvent_t ev_plan = nullptr;
+    hipStream_t plan_stream = nullptr;    // where upload_plan puts its copies (stream, or stream_up in the one-shot call)
     bool wide_concurrent = true;          // MSCKF_WIDE_STREAM=0: everything on one stream
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
@@ -1012,30 +1019,31 @@ int launch_sweeps(msckf_ctx* c, bool with_root = true) {
 
 // node / fold tables of the current plan -> HBM (async on the context's stream)
 int upload_plan(msckf_ctx* c) {
+    hipStream_t ps = c->plan_stream ? c->plan_stream : c->stream;
     if (int rc = ensure(c, c->dNodes, std::max<size_t>(c->nodes.size(), 1) * sizeof(FoldNode))) return rc;
     if (!c->nodes.empty())
         HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
-                                 c->stream));
+                                 ps));
     c->x_plan_valid = false;               // the sweep tables are rewritten: a cached merge plan behind them is gone
     if (c->xchg_planned)                   // (behind the workspace memset of set_features / replan, same stream)
-        HIPCHK(c, hipMemcpyAsync(c->dRbuf.p, c->h_xflags.data(), c->h_xflags.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dRbuf.p, c->h_xflags.data(), c->h_xflags.size() * 8, hipMemcpyHostToDevice, ps));
     if (!c->snodes.empty()) {
         if (int rc = ensure(c, c->dSweepNodes, c->snodes.size() * sizeof(SweepNode))) return rc;
         if (int rc = ensure(c, c->dSweepFolds, c->sfolds.size() * sizeof(SweepFold))) return rc;
         HIPCHK(c, hipMemcpyAsync(c->dSweepNodes.p, c->snodes.data(), c->snodes.size() * sizeof(SweepNode),
-                                 hipMemcpyHostToDevice, c->stream));
+                                 hipMemcpyHostToDevice, ps));
         HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, c->sfolds.data(), c->sfolds.size() * sizeof(SweepFold),
-                                 hipMemcpyHostToDevice, c->stream));
+                                 hipMemcpyHostToDevice, ps));
         if (c->band_plan && !c->h_root_flush.empty()) {
             if (int rc = ensure(c, c->dRootFlush, c->h_root_flush.size() * 4)) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->dRootFlush.p, c->h_root_flush.data(), c->h_root_flush.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->dRootFlush.p, c->h_root_flush.data(), c->h_root_flush.size() * 4, hipMemcpyHostToDevice, ps));
         }
         if (c->sweep_mode > 0 && c->band_plan) {
             if (int rc = ensure(c, c->dFlush, c->h_flush.size() * 4)) return rc;
             if (int rc = ensure(c, c->dFlushOff, c->h_flush_off.size() * 4)) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->dFlush.p, c->h_flush.data(), c->h_flush.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->dFlush.p, c->h_flush.data(), c->h_flush.size() * 4, hipMemcpyHostToDevice, ps));
             HIPCHK(c, hipMemcpyAsync(c->dFlushOff.p, c->h_flush_off.data(), c->h_flush_off.size() * 4, hipMemcpyHostToDevice,
-                                     c->stream));
+                                     ps));
         }
     }
     return MSCKF_OK;
@@ -1526,6 +1534,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { msckf_destroy(c); return MSCKF_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking) != hipSuccess) { msckf_destroy(c); return MSCKF_ERR_HIP; }
     {
         const char* e1 = std::getenv("MSCKF_GAIN_STREAM");
         const char* e2 = std::getenv("MSCKF_GAIN_OVERLAP");
@@ -1541,6 +1550,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     for (auto& e : c->ev) CK(hipEventCreate(&e), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_wfeat, hipEventDisableTiming), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming), "hipEventCreate");
     auto lds_attr = [&](const void* f, int bytes, const char* what) {
         CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
     };
@@ -1660,6 +1670,7 @@ void msckf_destroy(msckf_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream_up) (void)hipStreamSynchronize(c->stream_up);
     if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
     Buf* all[] = {&c->dP, &c->dPout, &c->dCamR, &c->dCamT, &c->dCamR0, &c->dCamT0, &c->dChi2, &c->dViewPtr,
                   &c->dObsUV, &c->dObsSlot, &c->dBase, &c->dMvec, &c->dRho, &c->dFmin, &c->dBlkOff, &c->dStack,
@@ -1670,12 +1681,14 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dRootFlush, &c->dXRootFlush,
                   &c->dGramPart, &c->dGramS, &c->dGramU, &c->dGramL, &c->dGramInvd};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
-    for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
+    for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dRawArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_wfeat) (void)hipEventDestroy(c->ev_wfeat);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1759,9 +1772,9 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->us_host_prep = (float)(now_us() - t0);
         return MSCKF_OK;
     }
-    // validate + first/last slot of each track (feature ranges on the host pool; the lowest failing range decides the code)
-    std::vector<int> fmin_in(F), fmax_in(F);
-    int Mmax = 0;
+    // The caller's arrays go up as they are (k_gather.h brings them into the pipeline's order on the device): copy into the
+    // pinned image + upload in two pieces, so that the first (the observations, 60 % of the bytes) crosses PCIe while the
+    // host still copies and validates the second, and both while it sorts.
     if (view_ptr[0] != 0) return MSCKF_ERR_ARG;
     // the CSR offsets first, all of them (a few microseconds): the feature ranges below read obs_slot[view_ptr[f] ..] and must
     // not do so through an offset no earlier range has vouched for (a malformed view_ptr would send them out of bounds)
@@ -1769,17 +1782,58 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         const int M = view_ptr[f + 1] - view_ptr[f];
         if (M < 1 || M > c->maxM) return MSCKF_ERR_ARG;
     }
+    const int sumM = view_ptr[F];
+    // raw image (input order): doubles first, then the ints
+    const size_t r_uv = 0, r_base = r_uv + (size_t)sumM * 16, r_m = r_base + (size_t)F * 24, r_rho = r_m + (size_t)F * 24;
+    const size_t r_view = r_rho + (size_t)F * 8, r_slot = r_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7);
+    const size_t raw_bytes = (r_slot + (size_t)sumM * 4 + 15) & ~(size_t)15;
+    // sorted image (what the kernels read): written by k_gather but for the three tables of the host's sort, which are contiguous
+    const size_t o_uv = 0, o_base = o_uv + (size_t)sumM * 16, o_m = o_base + (size_t)F * 24, o_rho = o_m + (size_t)F * 24;
+    const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
+    const size_t o_perm = o_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7);                  // sorted position -> input index
+    const size_t o_slot = (o_perm + (size_t)F * 4 + 7) & ~(size_t)7, o_fmin = o_slot + (((size_t)sumM * 4 + 7) & ~(size_t)7);
+    const size_t o_info = (o_fmin + (size_t)F * 4 + 15) & ~(size_t)15;                    // FeatInfo records (16-byte aligned)
+    const size_t feat_bytes = o_info + (size_t)F * sizeof(FeatInfo);
+    const size_t tab_bytes = o_slot - o_blk;                                              // blk | view | perm
+    const size_t pin_bytes = raw_bytes + tab_bytes;
+    if (c->hFeatCap < pin_bytes) {
+        if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
+        c->hFeat = nullptr; c->hFeatCap = 0;
+        HIPCHK(c, hipHostMalloc(&c->hFeat, pin_bytes + pin_bytes / 2));
+        c->hFeatCap = pin_bytes + pin_bytes / 2;
+    }
+    if (int rca = ensure(c, c->dFeatArena, feat_bytes)) return rca;
+    if (int rca = ensure(c, c->dRawArena, raw_bytes)) return rca;
+    char* hb = static_cast<char*>(c->hFeat);
+    char* draw = static_cast<char*>(c->dRawArena.p);
+    const bool par = c->pool && F >= host_par_min();
+    if (par) c->pool->copy(hb + r_uv, obs_uv, (size_t)sumM * 16); else std::memcpy(hb + r_uv, obs_uv, (size_t)sumM * 16);
+    HIPCHK(c, hipMemcpyAsync(draw + r_uv, hb + r_uv, (size_t)sumM * 16, hipMemcpyHostToDevice, c->stream));
+    // validate + first/last slot of each track + sort key (feature ranges on the host pool; the lowest failing range decides
+    // the code), and the range's share of the remaining arrays into the pinned image
+    // key = (class, first slot, last slot); class 0: band tracks; 1: wide tracks of up to 15 views (k_feature<32>); 2: wide tracks
+    // of 16+ views (k_feature<64>) -- wide = wider than the band pipeline takes, where the information form is available (k_gram.h)
+    const bool wide = wide_ok(c, N);
+    const size_t NN = (size_t)N * N;
+    std::vector<int> key_in(F);
+    std::vector<unsigned char> M_in(F);
+    int Mmax = 0, Mmax_cls[3] = {0, 0, 0};
     {
-        const int nch = (c->pool && F >= host_par_min()) ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
-        std::vector<int> ch_err(nch, MSCKF_OK), ch_mmax(nch, 0);
+        const int nch = par ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
+        std::vector<int> ch_err(nch, MSCKF_OK), ch_mmax(3 * nch, 0);
         const int maxM = c->maxM;
         auto validate = [&](int ch) {
             const int f0 = (int)((long long)F * ch / nch), f1 = (int)((long long)F * (ch + 1) / nch);
-            int mm = 0;
+            const int a0 = view_ptr[f0], a1 = view_ptr[f1];
+            std::memcpy(hb + r_slot + (size_t)a0 * 4, obs_slot + a0, (size_t)(a1 - a0) * 4);
+            std::memcpy(hb + r_base + (size_t)f0 * 24, idp_base + (size_t)f0 * 3, (size_t)(f1 - f0) * 24);
+            std::memcpy(hb + r_m + (size_t)f0 * 24, idp_m + (size_t)f0 * 3, (size_t)(f1 - f0) * 24);
+            std::memcpy(hb + r_rho + (size_t)f0 * 8, idp_rho + f0, (size_t)(f1 - f0) * 8);
+            std::memcpy(hb + r_view + (size_t)f0 * 4, view_ptr + f0, (size_t)(f1 - f0 + (f1 == F ? 1 : 0)) * 4);
+            int mm[3] = {0, 0, 0};
             for (int f = f0; f < f1; ++f) {
                 const int a = view_ptr[f], b = view_ptr[f + 1], M = b - a;
                 if (M < 1 || M > maxM) { ch_err[ch] = MSCKF_ERR_ARG; return; }
-                mm = std::max(mm, M);
                 int lo = N, hi = -1;
                 unsigned long long seen = 0;    // N <= 64 fast path; general check below
                 for (int i = a; i < b; ++i) {
@@ -1793,125 +1847,65 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
                         for (int k = a; k < i; ++k) if (obs_slot[k] == sl) { ch_err[ch] = MSCKF_ERR_DUP_SLOT; return; }
                     }
                 }
-                fmin_in[f] = lo; fmax_in[f] = hi;
+                const int cls = (wide && hi - lo + 1 > WIDE_SPAN) ? (M > 15 ? 2 : 1) : 0;
+                key_in[f] = (int)(cls * NN + (size_t)lo * N + hi);
+                M_in[f] = (unsigned char)M;
+                mm[cls] = std::max(mm[cls], M);
             }
-            ch_mmax[ch] = mm;
+            for (int k = 0; k < 3; ++k) ch_mmax[3 * ch + k] = mm[k];
         };
         if (nch > 1) c->pool->run(nch, validate); else validate(0);
         for (int ch = 0; ch < nch; ++ch) {
-            if (ch_err[ch] != MSCKF_OK) return ch_err[ch];
-            Mmax = std::max(Mmax, ch_mmax[ch]);
+            if (ch_err[ch] != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); return ch_err[ch]; }      // (the pinned image is in flight)
+            for (int k = 0; k < 3; ++k) Mmax_cls[k] = std::max(Mmax_cls[k], ch_mmax[3 * ch + k]);
         }
+        Mmax = std::max(Mmax_cls[0], std::max(Mmax_cls[1], Mmax_cls[2]));
     }
+    HIPCHK(c, hipMemcpyAsync(draw + r_base, hb + r_base, raw_bytes - r_base, hipMemcpyHostToDevice, c->stream));
     const double tv = now_us();
-    if (c->n_chi2 <= 2 * Mmax) return MSCKF_ERR_ARG;
-    const int sumM = view_ptr[F];
+    if (c->n_chi2 <= 2 * Mmax) { (void)hipStreamSynchronize(c->stream); return MSCKF_ERR_ARG; }
     c->F = F; c->sumM = sumM; c->Mmax = Mmax;            // validated: commit the batch size
-    // counting sort by (class, first slot, last slot): stable, O(F + N^2); class 1 = tracks wider than the band pipeline takes,
-    // where the information form is available for them (k_gram.h): they follow the band tracks
+    // counting sort by the key: stable, O(F + N^2); the band tracks first, the wide ones behind them
     c->perm.resize(F);
+    std::vector<int> h_view(F + 1), h_fmin(F), h_fmax(F);
+    long long blk = 0;
     {
-        const bool wide = wide_ok(c, N);
-        const size_t NN = (size_t)N * N;
         std::vector<int> cnt(3 * NN + 1, 0);
-        // class 0: band tracks; 1: wide tracks of up to 15 views (k_feature<32>); 2: wide tracks of 16+ views (k_feature<64>)
-        auto key = [&](int f) {
-            const int cls = (wide && fmax_in[f] - fmin_in[f] + 1 > WIDE_SPAN) ? (view_ptr[f + 1] - view_ptr[f] > 15 ? 2 : 1) : 0;
-            return cls * NN + (size_t)fmin_in[f] * N + fmax_in[f];
-        };
-        for (int f = 0; f < F; ++f) cnt[key(f) + 1]++;
+        for (int f = 0; f < F; ++f) cnt[key_in[f] + 1]++;
+        // first / last slot of the sorted tracks: a run per occupied key
+        for (size_t k = 0, pos = 0; k < 3 * NN; ++k) {
+            const int n = cnt[k + 1];
+            if (n == 0) continue;
+            const int lo = (int)((k % NN) / N), hi = (int)(k % N);
+            std::fill(h_fmin.begin() + pos, h_fmin.begin() + pos + n, lo);
+            std::fill(h_fmax.begin() + pos, h_fmax.begin() + pos + n, hi);
+            pos += n;
+        }
         for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
         c->Fb = cnt[NN];                                                  // band tracks: sorted positions [0, Fb)
         c->Fw1 = cnt[2 * NN] - c->Fb;                                     // wide, <= 15 views: [Fb, Fb + Fw1)
         c->Fw = F - c->Fb;                                                // all wide tracks: [Fb, F)
-        for (int f = 0; f < F; ++f) c->perm[cnt[key(f)]++] = f;
-        c->Mmax_band = c->Mmax_wide = c->Mmax_w1 = 0;
+        int* perm = c->perm.data();
+        for (int f = 0; f < F; ++f) perm[cnt[key_in[f]]++] = f;
+        c->Mmax_band = Mmax_cls[0]; c->Mmax_w1 = Mmax_cls[1]; c->Mmax_wide = Mmax_cls[2];
+        // the sorted CSR offsets and the offsets of the K4 blocks: a prefix over the sorted order
+        long long* h_blk = reinterpret_cast<long long*>(hb + raw_bytes);
+        int pos = 0;
         for (int sidx = 0; sidx < F; ++sidx) {
-            const int f = c->perm[sidx], M = view_ptr[f + 1] - view_ptr[f];
-            if (sidx < c->Fb) c->Mmax_band = std::max(c->Mmax_band, M);
-            else if (sidx < c->Fb + c->Fw1) c->Mmax_w1 = std::max(c->Mmax_w1, M);
-            else c->Mmax_wide = std::max(c->Mmax_wide, M);
+            const int M = M_in[perm[sidx]];
+            h_view[sidx] = pos;
+            h_blk[sidx] = blk;
+            blk += (long long)(6 * M + 1) * (2 * M);
+            pos += M;
         }
+        h_view[F] = pos;
+        std::memcpy(hb + raw_bytes + (o_view - o_blk), h_view.data(), (size_t)(F + 1) * 4);
+        std::memcpy(hb + raw_bytes + (o_perm - o_blk), perm, (size_t)F * 4);
     }
-    const double ts = now_us();
-    // arena layout (8-byte aligned pieces): doubles first, then the 64-bit offsets, then the ints
-    const size_t o_uv = 0, o_base = o_uv + (size_t)sumM * 16, o_m = o_base + (size_t)F * 24, o_rho = o_m + (size_t)F * 24;
-    const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
-    const size_t o_slot = o_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7), o_fmin = o_slot + (((size_t)sumM * 4 + 7) & ~(size_t)7);
-    const size_t o_info = (o_fmin + (size_t)F * 4 + 15) & ~(size_t)15;                    // FeatInfo records (16-byte aligned)
-    const size_t o_perm = o_info + (size_t)F * sizeof(FeatInfo);                          // sorted position -> input index
-    const size_t feat_bytes = o_perm + (size_t)F * 4;
-    if (c->hFeatCap < feat_bytes) {
-        if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
-        c->hFeat = nullptr; c->hFeatCap = 0;
-        HIPCHK(c, hipHostMalloc(&c->hFeat, feat_bytes + feat_bytes / 2));
-        c->hFeatCap = feat_bytes + feat_bytes / 2;
-    }
-    if (int rca = ensure(c, c->dFeatArena, feat_bytes)) return rca;
-    char* hb = static_cast<char*>(c->hFeat);
-    double* h_uv = reinterpret_cast<double*>(hb + o_uv);
-    double* h_base = reinterpret_cast<double*>(hb + o_base);
-    double* h_m = reinterpret_cast<double*>(hb + o_m);
-    double* h_rho = reinterpret_cast<double*>(hb + o_rho);
-    long long* h_blk = reinterpret_cast<long long*>(hb + o_blk);
-    int* h_viewp = reinterpret_cast<int*>(hb + o_view);
-    int* h_slot = reinterpret_cast<int*>(hb + o_slot);
-    int* h_fminp = reinterpret_cast<int*>(hb + o_fmin);
-    FeatInfo* h_info = reinterpret_cast<FeatInfo*>(hb + o_info);
-    // gather into sorted order, straight into the pinned image: offsets first (a prefix over the sorted order), then the
-    // copies by feature ranges on the host pool
-    std::vector<int> h_view(F + 1), h_fmin(F), h_fmax(F);
-    long long blk = 0;
-    int pos = 0;
-    for (int sidx = 0; sidx < F; ++sidx) {
-        const int f = c->perm[sidx];
-        const int M = view_ptr[f + 1] - view_ptr[f];
-        h_view[sidx] = pos;
-        h_blk[sidx] = blk;
-        blk += (long long)(6 * M + 1) * (2 * M);
-        pos += M;
-    }
-    {
-        const int nch = (c->pool && F >= host_par_min()) ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
-        const int* perm = c->perm.data();
-        auto gather = [&](int ch) {
-            const int s0 = (int)((long long)F * ch / nch), s1 = (int)((long long)F * (ch + 1) / nch);
-            for (int sidx = s0; sidx < s1; ++sidx) {
-                const int f = perm[sidx];
-                const int a = view_ptr[f], M = view_ptr[f + 1] - a, p0 = h_view[sidx];
-                {   // (short, variable-length runs: plain loops beat the memcpy calls)
-                    const int* ss = obs_slot + a; int* sd = h_slot + p0;
-                    const double* us = obs_uv + (size_t)a * 2; double* ud = h_uv + (size_t)p0 * 2;
-                    for (int v = 0; v < M; ++v) { sd[v] = ss[v]; ud[2 * v] = us[2 * v]; ud[2 * v + 1] = us[2 * v + 1]; }
-                    const double* bs = idp_base + (size_t)f * 3; double* bd = h_base + (size_t)sidx * 3;
-                    const double* ms = idp_m + (size_t)f * 3; double* md = h_m + (size_t)sidx * 3;
-                    bd[0] = bs[0]; bd[1] = bs[1]; bd[2] = bs[2]; md[0] = ms[0]; md[1] = ms[1]; md[2] = ms[2];
-                }
-                h_rho[sidx] = idp_rho[f];
-                h_fmin[sidx] = fmin_in[f]; h_fmax[sidx] = fmax_in[f];
-                h_fminp[sidx] = fmin_in[f];
-                {
-                    FeatInfo& fi = h_info[sidx];
-                    fi.blk_off = h_blk[sidx]; fi.M = M; fi.pad = 0;
-                    unsigned long long c8[2] = {~0ull, ~0ull};
-                    unsigned char* colb = reinterpret_cast<unsigned char*>(c8);
-                    for (int v = 0; v < M; ++v) {
-                        const int j = obs_slot[a + v] - fmin_in[f];
-                        if (j < 16) colb[j] = (unsigned char)v;
-                    }
-                    std::memcpy(fi.col, c8, 16);
-                }
-            }
-        };
-        if (nch > 1) c->pool->run(nch, gather); else gather(0);
-    }
-    h_view[F] = pos;
-    std::memcpy(h_viewp, h_view.data(), (size_t)(F + 1) * 4);
-    std::memcpy(hb + o_perm, c->perm.data(), (size_t)F * 4);
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
     c->h_fmin = h_fmin; c->h_fmax = h_fmax;
-    const double t1 = now_us();
+    const double ts = now_us(), t1 = ts;
 
     set_view(c->dObsUV, c->dFeatArena.p, o_uv, (size_t)sumM * 16);
     set_view(c->dBase, c->dFeatArena.p, o_base, (size_t)F * 24);
@@ -1931,13 +1925,26 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const size_t stack_es = c->cfg.dtype == MSCKF_DTYPE_F32 ? 4 : 8;
     E(c->dStack, ((size_t)blk + 8) * stack_es); E(c->dGamma, (size_t)F * 8);
     c->stack_elems = blk;
-    if (rc != MSCKF_OK) return rc;
-    // the tracks go first; in the one-shot call K1-K4 starts behind them while the host plans K5
-    HIPCHK(c, hipMemcpyAsync(c->dFeatArena.p, c->hFeat, feat_bytes, hipMemcpyHostToDevice, c->stream));
+    if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    // the sort's tables behind the raw arrays, then the permutation on the device; in the one-shot call K1-K4 starts behind
+    // it while the host plans K5
+    HIPCHK(c, hipMemcpyAsync(static_cast<char*>(c->dFeatArena.p) + o_blk, hb + raw_bytes, tab_bytes, hipMemcpyHostToDevice, c->stream));
+    if (c->oneshot) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    {
+        GatherArgs g;
+        g.view_in = reinterpret_cast<const int*>(draw + r_view); g.slot_in = reinterpret_cast<const int*>(draw + r_slot);
+        g.uv_in = reinterpret_cast<const double*>(draw + r_uv); g.base_in = reinterpret_cast<const double*>(draw + r_base);
+        g.m_in = reinterpret_cast<const double*>(draw + r_m); g.rho_in = reinterpret_cast<const double*>(draw + r_rho);
+        g.perm = ptr<int>(c->dPerm); g.view_s = ptr<int>(c->dViewPtr); g.blk = ptr<long long>(c->dBlkOff);
+        g.uv = ptr<double>(c->dObsUV); g.base = ptr<double>(c->dBase); g.m = ptr<double>(c->dMvec); g.rho = ptr<double>(c->dRho);
+        g.slot = ptr<int>(c->dObsSlot); g.fmin = ptr<int>(c->dFmin); g.info = ptr<FeatInfo>(c->dFeatInfo);
+        g.F = F;
+        hipLaunchKernelGGL(k_gather, dim3((F + GATHER_THREADS / 32 - 1) / (GATHER_THREADS / 32)), dim3(GATHER_THREADS), 0, c->stream, g);
+        HIPCHK(c, hipGetLastError());
+    }
     // (k_lsweep's zero words behind the stack are written by k_feature itself: one launch less in front of it)
     c->feature_launched = false;
     if (c->oneshot) {
-        HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         if (int rcf = launch_feature(c)) return rcf;
         c->feature_launched = true;
     }
@@ -1963,9 +1970,17 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             HIPCHK(c, hipMalloc(&c->dRbuf.p, want));
             c->dRbuf.bytes = want;
         }
-        HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
+        // (one-shot: the previous call ended with a wait for the device, nothing reads the workspace or the tables now)
+        c->plan_stream = c->oneshot ? c->stream_up : c->stream;
+        HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->plan_stream));
         c->plan_valid = false;
-        if (int rcp = upload_plan(c)) return rcp;
+        const int rcp = upload_plan(c);
+        if (c->oneshot) {
+            HIPCHK(c, hipEventRecord(c->ev_plan, c->stream_up));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan, 0));
+        }
+        c->plan_stream = nullptr;
+        if (rcp) return rcp;
         c->plan_fmin = h_fmin; c->plan_fmax = h_fmax;
         c->plan_valid = true;
         c->plan_no_wide = false;
