@@ -52,6 +52,8 @@ struct FeatureArgs {
     double* gamma;               // [F]
     long long* stamps;           // optional diagnostics (8 per feature), may be null
     long long zero_idx;          // index (scalars) of the 8 zero words behind the last block (k_lsweep loads them for absent entries)
+    int* rank_h;                 // optional mirrors of rank / accepted in pinned host memory (the one-shot call: the gate results
+    unsigned char* acc_h;        //   are on the host when the stream has drained, without a copy command behind K7)
 };
 
 // The 6M columns of a track's clone block are worked on in chunks of whole views, at most 64 columns each (one
@@ -158,7 +160,10 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         }
     };
     if (p.select && !(p.select[f] & 1)) {      // not in valid_features (MSCKF.py:453-455): no rows, not a rejection
-        if (lane == 0) { p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3; }
+        if (lane == 0) {
+            p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3;
+            if (p.acc_h) { p.rank_h[f] = 0; p.acc_h[f] = 3; }
+        }
         return;
     }
     long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -799,6 +804,7 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         // (No global counters: 2000 workgroups adding to one word serialise at ~13 ns each and
         // were 50 us of this kernel; the host sums the per-feature results instead.)
         p.accepted[f] = ok ? 1 : (bad ? 2 : 0);
+        if (p.acc_h) { p.rank_h[f] = rank; p.acc_h[f] = ok ? 1 : (bad ? 2 : 0); }
         if (p.stamps) { tq[7] = wall_clock64(); for (int i = 0; i < 8; ++i) p.stamps[8 * f + i] = tq[i]; }
     }
 }

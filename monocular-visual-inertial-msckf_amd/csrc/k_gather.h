@@ -2,33 +2,39 @@
 //   reference MSCKF.py:570-582 : `for feature in features.values()` -- the reference walks its dict in insertion order;
 // the engine's kernels want the tracks sorted by (class, first slot, last slot) (k_lsweep's leaves, the per-class launches
 // of k_feature).  Until round 3 the host gathered every array into that order before the upload (29 us of the call at 2000
-// tracks, 155 us at 10000, all of it in front of K1-K4).  Now the caller's arrays go up AS THEY ARE while the host is still
-// validating and sorting; the host sends three short tables behind them (sorted position -> input index, the sorted CSR
-// offsets, the offsets of the K4 blocks) and this kernel writes the sorted image the other kernels read: an HBM-bound
-// permutation (5.3 MB read + written at 10000 tracks), one 32-lane group per track.
+// tracks, 155 us at 10000, all of it in front of K1-K4).  Now the caller's arrays stay AS THEY ARE: the observations (60 % of
+// the bytes) cross PCIe by DMA while the host is still validating and sorting, everything else sits in the pinned image and
+// is read from there by this kernel (zero-copy: no copy command, and none of the ~9 us a copy command waits behind its
+// predecessor), which writes the sorted image the other kernels read.  The host's sort contributes one 24-byte record per
+// track.  An HBM / PCIe-bound permutation, one 32-lane group per track.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "k_lsweep.h"
 
 namespace msckf {
 
+struct __attribute__((aligned(8))) GatherRec {
+    int f;                        // input index of the track at this sorted position
+    int a;                        // its first view in the caller's arrays
+    int M;                        // views
+    int o;                        // its first view in the sorted arrays
+    long long blk;                // offset of its K4 block
+};
+
 struct GatherArgs {
-    // the caller's arrays, input order
-    const int* view_in;           // [F + 1] CSR offsets
-    const int* slot_in;           // [sumM]
+    // the caller's arrays, input order (uv: HBM, uploaded by DMA; the others: the pinned host image)
     const double* uv_in;          // [sumM][2]
+    const int* slot_in;           // [sumM]
     const double* base_in;        // [F][3]
     const double* m_in;           // [F][3]
     const double* rho_in;         // [F]
-    // from the host's sort
-    const int* perm;              // [F] sorted position -> input index
-    const int* view_s;            // [F + 1] CSR offsets of the sorted order
-    const long long* blk;         // [F] offset of the track's K4 block
+    const GatherRec* rec;         // [F] from the host's sort (pinned host image)
     // the sorted image
     double* uv; double* base; double* m; double* rho;
-    int* slot; int* fmin;
+    int* slot; int* fmin; int* view; int* perm;
+    long long* blk;
     FeatInfo* info;
-    int F;
+    int F, sumM;
 };
 
 constexpr int GATHER_THREADS = 256;
@@ -38,14 +44,21 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(GatherArgs p) {
     const int t = threadIdx.x, grp = t >> 5, v = t & 31;
     const int s = blockIdx.x * (GATHER_THREADS / 32) + grp;
     const bool live = s < p.F;
-    int f = 0, a = 0, M = 0, o = 0;
-    if (live) { f = p.perm[s]; a = p.view_in[f]; M = p.view_in[f + 1] - a; o = p.view_s[s]; }
+    GatherRec r{0, 0, 0, 0, 0};
+    if (live) r = p.rec[s];
+    const int f = r.f, a = r.a, M = r.M, o = r.o;
     int sl = 1 << 30;
+    double hv = 0.0;
+    if (live) {                   // (the host reads first, all of them in flight together)
+        if (v < M) sl = p.slot_in[a + v];
+        if (v < 3) hv = p.base_in[3 * (size_t)f + v];
+        else if (v < 6) hv = p.m_in[3 * (size_t)f + v - 3];
+        else if (v == 6) hv = p.rho_in[f];
+    }
     if (v < M) {
-        sl = p.slot_in[a + v];
-        p.slot[o + v] = sl;
         const double2 q = *reinterpret_cast<const double2*>(p.uv_in + 2 * (size_t)(a + v));
         *reinterpret_cast<double2*>(p.uv + 2 * (size_t)(o + v)) = q;
+        p.slot[o + v] = sl;
     }
     int lo = sl;
 #pragma unroll
@@ -55,16 +68,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(GatherArgs p) {
     if (v < M && sl - lo < 16) reinterpret_cast<unsigned char*>(scol[grp])[sl - lo] = (unsigned char)v;
     __syncthreads();
     if (!live) return;
-    if (v < 3) p.base[3 * (size_t)s + v] = p.base_in[3 * (size_t)f + v];
-    else if (v < 6) p.m[3 * (size_t)s + v - 3] = p.m_in[3 * (size_t)f + v - 3];
-    else if (v == 6) p.rho[s] = p.rho_in[f];
+    if (v < 3) p.base[3 * (size_t)s + v] = hv;
+    else if (v < 6) p.m[3 * (size_t)s + v - 3] = hv;
+    else if (v == 6) p.rho[s] = hv;
     else if (v == 7) p.fmin[s] = lo;
     else if (v == 8) {
         FeatInfo fi;
-        fi.blk_off = p.blk[s]; fi.M = M; fi.pad = 0;
+        fi.blk_off = r.blk; fi.M = M; fi.pad = 0;
         *reinterpret_cast<unsigned long long*>(fi.col) = scol[grp][0];
         *reinterpret_cast<unsigned long long*>(fi.col + 8) = scol[grp][1];
         p.info[s] = fi;
+    } else if (v == 9) {
+        p.view[s] = o; p.perm[s] = f; p.blk[s] = r.blk;
+        if (s == p.F - 1) p.view[p.F] = p.sumM;
     }
 }
 

@@ -69,6 +69,7 @@ struct GStreamArgs {
     double* ex;                              // exchange tiles [nb][ns][256]
     unsigned long long* exflag;              // [nb][ns]: (epoch, row block + 1) in the upper 32 bits
     double* dx; double* Pout; int ldo;
+    double* dx_h; double* Pout_h; int* status_h;     // optional mirrors in pinned host memory (same layout; the one-shot call)
     int* status;                             // [0]: 0 ok, 1 a pivot was not a positive normal number, 2 timeout
     double sigma2;
     int d, dc, nb, ns, ncb;                  // nb row blocks of T, ns = nb + 1 strips, ncb column blocks per row block
@@ -484,10 +485,10 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         }
     }
     if (failed) {
-        if (r == 0 && t == 0) p.status[0] = sCtl[1] ? 2 : 1;
+        if (r == 0 && t == 0) { p.status[0] = sCtl[1] ? 2 : 1; if (p.status_h) p.status_h[0] = sCtl[1] ? 2 : 1; }
         return;
     }
-    if (r == 0 && t == 0) p.status[0] = 0;
+    if (r == 0 && t == 0) { p.status[0] = 0; if (p.status_h) p.status_h[0] = 0; }
     // ---- P+ tiles and dx (= minus the augmented row) -----------------------------------------------------------
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
@@ -497,9 +498,12 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = g + 4 * i;
-                if (m < ms && cc < nr) p.Pout[(size_t)(gsr + m) * p.ldo + gr + cc] = Pt[q][i];
+                if (m < ms && cc < nr) {
+                    p.Pout[(size_t)(gsr + m) * p.ldo + gr + cc] = Pt[q][i];
+                    if (p.Pout_h) p.Pout_h[(size_t)(gsr + m) * p.ldo + gr + cc] = Pt[q][i];
+                }
             }
-            if (s == 0 && g == 3 && cc < nr) p.dx[gr + cc] = -Pt[q][3];
+            if (s == 0 && g == 3 && cc < nr) { p.dx[gr + cc] = -Pt[q][3]; if (p.dx_h) p.dx_h[gr + cc] = -Pt[q][3]; }
         }
     }
     if (p.tstamp && r == 0) {

@@ -362,6 +362,24 @@ struct msckf_ctx {
     hipStream_t stream_up = nullptr;
     hipEvent_t ev_plan = nullptr;
     hipStream_t plan_stream = nullptr;    // where upload_plan puts its copies (stream, or stream_up in the one-shot call)
+    // The one-shot call's P and poses go up on stream_up too, beside the tracks; the main stream waits for ev_state in front of K1.
+    hipEvent_t ev_state = nullptr;
+    bool state_pending = false;           // ev_state recorded, the main stream has not been told to wait for it yet
+    // The one-shot call's results are written to the pinned host buffers by the kernels themselves (k_feature: rank / accepted,
+    // the fused K6-K7 kernels: status, dx, P+) next to the HBM copies: the two copy commands behind K7 (and the ~10 us each of
+    // them waits behind its predecessor) are gone, the host reads hGate / hRes when the stream has drained.
+    bool want_direct = false;             // msckf_update is running (and MSCKF_DIRECT_RESULT is not 0)
+    bool gate_direct = false;             // this batch's k_feature mirrored its results into hGate
+    bool res_direct = false;              // this run's K6-K7 mirrored status | dx | P+ into hRes
+    long direct_serial = -1;              // ... the run it did so for (run_serial)
+    // ... and the gate results are on the host when K1-K4 have ended (ev_gate): msckf_update sums them and fills the caller's mask
+    // while K5-K7 run, msckf_get_result finds the sums here
+    hipEvent_t ev_gate = nullptr;
+    bool gate_event = false;              // ev_gate sits behind this batch's k_feature
+    long gate_serial = -1;                // run whose gate sums are in gate_cnt (and whose mask the caller already has)
+    int gate_cnt[4] = {0, 0, 0, 0};
+    const uint8_t* gate_mask_dst = nullptr;
+    bool direct_enabled = true;
     bool wide_concurrent = true;          // MSCKF_WIDE_STREAM=0: everything on one stream
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
@@ -436,7 +454,8 @@ template <typename Tp>
 Tp* ptr(const Buf& b) { return reinterpret_cast<Tp*>(b.p); }
 
 // clone poses: host mirror -> pinned arena image -> HBM, one copy
-int upload_poses(msckf_ctx* c) {
+int upload_poses(msckf_ctx* c, hipStream_t st = nullptr) {
+    if (!st) st = c->stream;
     const size_t N = c->h_cam[1].size() / 3, mN = c->maxN;
     if (N == 0) return MSCKF_OK;
     double* h = static_cast<double*>(c->hPose);
@@ -444,7 +463,7 @@ int upload_poses(msckf_ctx* c) {
     std::memcpy(h + 9 * mN, c->h_cam[1].data(), N * 24);
     std::memcpy(h + 12 * mN, c->h_cam[2].data(), N * 72);
     std::memcpy(h + 21 * mN, c->h_cam[3].data(), N * 24);
-    HIPCHK(c, hipMemcpyAsync(c->dPoseArena.p, h, 24 * mN * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dPoseArena.p, h, 24 * mN * 8, hipMemcpyHostToDevice, st));
     return MSCKF_OK;
 }
 
@@ -1066,6 +1085,8 @@ int launch_feature(msckf_ctx* c) {
     a.select = c->use_select ? ptr<unsigned char>(c->dSelFlags) : nullptr;
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
     a.zero_idx = c->stack_elems;
+    c->gate_direct = c->want_direct && c->Fw == 0 && !c->use_select;
+    if (c->gate_direct) { a.rank_h = static_cast<int*>(c->hGate); a.acc_h = static_cast<unsigned char*>(c->hGate) + (size_t)c->F * 4; }
     // one launch per class of tracks: the band tracks [0, Fb) and, where they are kept apart (wide_active), the wide ones
     // [Fb, F), each with the instance its own longest track asks for
     hipStream_t st = c->stream;
@@ -1291,6 +1312,12 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.ex = ptr<double>(c->dGsEx); a.exflag = ptr<unsigned long long>(c->dGsFlag);
     a.dx = ptr<double>(c->dDx); a.Pout = ptr<double>(c->dPout); a.ldo = d;
     a.status = ptr<int>(c->dStatus);
+    if (c->res_direct && c->want_direct) {
+        char* h = static_cast<char*>(c->hRes);
+        a.status_h = reinterpret_cast<int*>(h); a.dx_h = reinterpret_cast<double*>(h + c->res_dx_off);
+        a.Pout_h = reinterpret_cast<double*>(h + c->res_p_off);
+        reinterpret_cast<int*>(h)[0] = 3; reinterpret_cast<int*>(h)[1] = 0; reinterpret_cast<int*>(h)[2] = 0;     // 3: not written
+    }
     a.sigma2 = c->sigma * c->sigma;
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.nb1 = Tblk ? nb : 0;
@@ -1430,6 +1457,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (!c->have_state || !c->have_features) return MSCKF_ERR_STATE;
     int rc;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[0], c->stream));
+    if (c->state_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_state, 0)); c->state_pending = false; }
     if (!c->feature_launched && (rc = launch_feature(c)) != MSCKF_OK) return rc;
     c->feature_launched = false;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
@@ -1454,6 +1482,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         HIPCHK(c, hipGetLastError());
     }
     c->gs_fused_last = beside;
+    c->res_direct = c->want_direct && c->gate_direct && gs && !c->wide_active;
     if (beside && c->sweep_mode > 0) {
         const SweepNode& rn = c->snodes.back();
         const double* zero = ptr<double>(c->dRbuf) + c->zero_off;
@@ -1487,6 +1516,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     c->acc_override = -1;
     c->acc_from_dev = false;
     ++c->run_serial;
+    if (c->res_direct) c->direct_serial = c->run_serial;
     return MSCKF_OK;
 }
 
@@ -1551,6 +1581,9 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_wfeat, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_state, hipEventDisableTiming), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming), "hipEventCreate");
+    if (const char* e = std::getenv("MSCKF_DIRECT_RESULT")) c->direct_enabled = std::atoi(e) != 0;
     auto lds_attr = [&](const void* f, int bytes, const char* what) {
         CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
     };
@@ -1662,10 +1695,10 @@ void msckf_destroy(msckf_ctx* c) {
     c->pool = nullptr;
     if (c->hp_calls > 0 && std::getenv("MSCKF_HOSTPROF")) {
         const double n = (double)c->hp_calls;
-        std::fprintf(stderr, "msckf_update host phases, us per call over %ld calls: set_state %.1f | validate %.1f, sort %.1f, gather %.1f, "
-                     "upload + K1-K4 launch %.1f, plan %.1f, plan upload %.1f | K5-K7 launches %.1f | wait for device + copies %.1f, "
-                     "unpack %.1f | whole call %.1f\n", c->hp_calls, c->hp[0] / n, c->hp[1] / n, c->hp[2] / n, c->hp[3] / n, c->hp[4] / n,
-                     c->hp[5] / n, c->hp[6] / n, c->hp[7] / n, c->hp[8] / n, c->hp[9] / n, c->hp[10] / n);
+        std::fprintf(stderr, "msckf_update host phases, us per call over %ld calls: set_state %.1f | pinned image + validate %.1f, sort %.1f, "
+                     "k_gather + K1-K4 launch %.1f, plan %.1f, plan upload %.1f | K5-K7 launches %.1f | wait for K1-K4 + gate sums %.1f | "
+                     "wait for device %.1f, unpack %.1f | whole call %.1f\n", c->hp_calls, c->hp[0] / n, c->hp[1] / n, c->hp[2] / n, c->hp[4] / n,
+                     c->hp[5] / n, c->hp[6] / n, c->hp[7] / n, c->hp[11] / n, c->hp[8] / n, c->hp[9] / n, c->hp[10] / n);
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1688,6 +1721,8 @@ void msckf_destroy(msckf_ctx* c) {
     if (c->ev_wfeat) (void)hipEventDestroy(c->ev_wfeat);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->ev_state) (void)hipEventDestroy(c->ev_state);
+    if (c->ev_gate) (void)hipEventDestroy(c->ev_gate);
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1708,20 +1743,23 @@ int msckf_set_state(msckf_ctx* c, int32_t N, const double* P, const double* cam_
     std::memcpy(c->g, gravity, 24);
     std::memcpy(c->Kinv, Kinv, 72);
     const size_t d = c->d;
+    // (one-shot call: the state goes up on stream_up, beside the tracks on the main stream)
+    hipStream_t st = c->defer_state_sync ? c->stream_up : c->stream;
     if (c->pool) c->pool->copy(c->hP, P, d * d * 8); else std::memcpy(c->hP, P, d * d * 8);
-    HIPCHK(c, hipMemcpyAsync(c->dP.p, c->hP, d * d * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dP.p, c->hP, d * d * 8, hipMemcpyHostToDevice, st));
     if (N > 0) {
         c->h_cam[0].assign(cam_R, cam_R + (size_t)N * 9); c->h_cam[1].assign(cam_t, cam_t + (size_t)N * 3);
         c->h_cam[2].assign(cam_R0, cam_R0 + (size_t)N * 9); c->h_cam[3].assign(cam_t0, cam_t0 + (size_t)N * 3);
-        if (int rcp = upload_poses(c)) return rcp;
+        if (int rcp = upload_poses(c, st)) return rcp;
     } else {
         for (auto& v : c->h_cam) v.clear();
     }
     if ((int)c->chi2_cache.size() != n_crit || std::memcmp(c->chi2_cache.data(), chi2_crit, (size_t)n_crit * 8) != 0) {
         c->chi2_cache.assign(chi2_crit, chi2_crit + n_crit);           // the table rarely changes between calls
-        HIPCHK(c, hipMemcpyAsync(c->dChi2.p, c->chi2_cache.data(), (size_t)n_crit * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->dChi2.p, c->chi2_cache.data(), (size_t)n_crit * 8, hipMemcpyHostToDevice, st));
     }
     if (!c->defer_state_sync) HIPCHK(c, hipStreamSynchronize(c->stream));
+    else { HIPCHK(c, hipEventRecord(c->ev_state, c->stream_up)); c->state_pending = true; }
     c->us_h2d = (float)(now_us() - t0);
     c->have_state = true;
     c->ran = false;
@@ -1772,9 +1810,9 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->us_host_prep = (float)(now_us() - t0);
         return MSCKF_OK;
     }
-    // The caller's arrays go up as they are (k_gather.h brings them into the pipeline's order on the device): copy into the
-    // pinned image + upload in two pieces, so that the first (the observations, 60 % of the bytes) crosses PCIe while the
-    // host still copies and validates the second, and both while it sorts.
+    // The caller's arrays stay as they are (k_gather.h brings them into the pipeline's order on the device): the observations
+    // (60 % of the bytes) into the pinned image and up by DMA at once -- they cross PCIe while the host validates and sorts --,
+    // the other arrays into the pinned image, from where k_gather reads them.
     if (view_ptr[0] != 0) return MSCKF_ERR_ARG;
     // the CSR offsets first, all of them (a few microseconds): the feature ranges below read obs_slot[view_ptr[f] ..] and must
     // not do so through an offset no earlier range has vouched for (a malformed view_ptr would send them out of bounds)
@@ -1785,17 +1823,16 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const int sumM = view_ptr[F];
     // raw image (input order): doubles first, then the ints
     const size_t r_uv = 0, r_base = r_uv + (size_t)sumM * 16, r_m = r_base + (size_t)F * 24, r_rho = r_m + (size_t)F * 24;
-    const size_t r_view = r_rho + (size_t)F * 8, r_slot = r_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7);
+    const size_t r_slot = r_rho + (size_t)F * 8;
     const size_t raw_bytes = (r_slot + (size_t)sumM * 4 + 15) & ~(size_t)15;
-    // sorted image (what the kernels read): written by k_gather but for the three tables of the host's sort, which are contiguous
+    // sorted image (what the kernels read), written by k_gather
     const size_t o_uv = 0, o_base = o_uv + (size_t)sumM * 16, o_m = o_base + (size_t)F * 24, o_rho = o_m + (size_t)F * 24;
     const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
     const size_t o_perm = o_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7);                  // sorted position -> input index
     const size_t o_slot = (o_perm + (size_t)F * 4 + 7) & ~(size_t)7, o_fmin = o_slot + (((size_t)sumM * 4 + 7) & ~(size_t)7);
     const size_t o_info = (o_fmin + (size_t)F * 4 + 15) & ~(size_t)15;                    // FeatInfo records (16-byte aligned)
     const size_t feat_bytes = o_info + (size_t)F * sizeof(FeatInfo);
-    const size_t tab_bytes = o_slot - o_blk;                                              // blk | view | perm
-    const size_t pin_bytes = raw_bytes + tab_bytes;
+    const size_t pin_bytes = raw_bytes + (size_t)F * sizeof(GatherRec);                   // the sort's records behind the arrays
     if (c->hFeatCap < pin_bytes) {
         if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
         c->hFeat = nullptr; c->hFeatCap = 0;
@@ -1803,12 +1840,17 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->hFeatCap = pin_bytes + pin_bytes / 2;
     }
     if (int rca = ensure(c, c->dFeatArena, feat_bytes)) return rca;
-    if (int rca = ensure(c, c->dRawArena, raw_bytes)) return rca;
+    // small batches: k_gather reads everything but the observations from the pinned image (zero-copy: 5 PCIe reads per track,
+    // cheaper than two more copy commands up to a few thousand tracks); large ones: DMA, beside the host's sort (measured at
+    // 10000 tracks: zero-copy 620 us per call, DMA 578)
+    static const int zc_max = [] { const char* e = std::getenv("MSCKF_ZEROCOPY_MAX"); return e ? std::atoi(e) : 4096; }();
+    const bool zc = F <= zc_max;
+    if (int rca = ensure(c, c->dRawArena, zc ? (size_t)sumM * 16 : pin_bytes)) return rca;
     char* hb = static_cast<char*>(c->hFeat);
     char* draw = static_cast<char*>(c->dRawArena.p);
     const bool par = c->pool && F >= host_par_min();
     if (par) c->pool->copy(hb + r_uv, obs_uv, (size_t)sumM * 16); else std::memcpy(hb + r_uv, obs_uv, (size_t)sumM * 16);
-    HIPCHK(c, hipMemcpyAsync(draw + r_uv, hb + r_uv, (size_t)sumM * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(draw, hb + r_uv, (size_t)sumM * 16, hipMemcpyHostToDevice, c->stream));
     // validate + first/last slot of each track + sort key (feature ranges on the host pool; the lowest failing range decides
     // the code), and the range's share of the remaining arrays into the pinned image
     // key = (class, first slot, last slot); class 0: band tracks; 1: wide tracks of up to 15 views (k_feature<32>); 2: wide tracks
@@ -1829,7 +1871,6 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             std::memcpy(hb + r_base + (size_t)f0 * 24, idp_base + (size_t)f0 * 3, (size_t)(f1 - f0) * 24);
             std::memcpy(hb + r_m + (size_t)f0 * 24, idp_m + (size_t)f0 * 3, (size_t)(f1 - f0) * 24);
             std::memcpy(hb + r_rho + (size_t)f0 * 8, idp_rho + f0, (size_t)(f1 - f0) * 8);
-            std::memcpy(hb + r_view + (size_t)f0 * 4, view_ptr + f0, (size_t)(f1 - f0 + (f1 == F ? 1 : 0)) * 4);
             int mm[3] = {0, 0, 0};
             for (int f = f0; f < f1; ++f) {
                 const int a = view_ptr[f], b = view_ptr[f + 1], M = b - a;
@@ -1861,7 +1902,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         }
         Mmax = std::max(Mmax_cls[0], std::max(Mmax_cls[1], Mmax_cls[2]));
     }
-    HIPCHK(c, hipMemcpyAsync(draw + r_base, hb + r_base, raw_bytes - r_base, hipMemcpyHostToDevice, c->stream));
+    if (!zc) HIPCHK(c, hipMemcpyAsync(draw + r_base, hb + r_base, raw_bytes - r_base, hipMemcpyHostToDevice, c->stream));
     const double tv = now_us();
     if (c->n_chi2 <= 2 * Mmax) { (void)hipStreamSynchronize(c->stream); return MSCKF_ERR_ARG; }
     c->F = F; c->sumM = sumM; c->Mmax = Mmax;            // validated: commit the batch size
@@ -1888,19 +1929,17 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         int* perm = c->perm.data();
         for (int f = 0; f < F; ++f) perm[cnt[key_in[f]]++] = f;
         c->Mmax_band = Mmax_cls[0]; c->Mmax_w1 = Mmax_cls[1]; c->Mmax_wide = Mmax_cls[2];
-        // the sorted CSR offsets and the offsets of the K4 blocks: a prefix over the sorted order
-        long long* h_blk = reinterpret_cast<long long*>(hb + raw_bytes);
+        // the sorted CSR offsets and the offsets of the K4 blocks: a prefix over the sorted order; k_gather's records
+        GatherRec* rec = reinterpret_cast<GatherRec*>(hb + raw_bytes);
         int pos = 0;
         for (int sidx = 0; sidx < F; ++sidx) {
-            const int M = M_in[perm[sidx]];
+            const int f = perm[sidx], M = M_in[f];
             h_view[sidx] = pos;
-            h_blk[sidx] = blk;
+            rec[sidx] = GatherRec{f, view_ptr[f], M, pos, blk};
             blk += (long long)(6 * M + 1) * (2 * M);
             pos += M;
         }
         h_view[F] = pos;
-        std::memcpy(hb + raw_bytes + (o_view - o_blk), h_view.data(), (size_t)(F + 1) * 4);
-        std::memcpy(hb + raw_bytes + (o_perm - o_blk), perm, (size_t)F * 4);
     }
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
@@ -1926,27 +1965,31 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     E(c->dStack, ((size_t)blk + 8) * stack_es); E(c->dGamma, (size_t)F * 8);
     c->stack_elems = blk;
     if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
-    // the sort's tables behind the raw arrays, then the permutation on the device; in the one-shot call K1-K4 starts behind
-    // it while the host plans K5
-    HIPCHK(c, hipMemcpyAsync(static_cast<char*>(c->dFeatArena.p) + o_blk, hb + raw_bytes, tab_bytes, hipMemcpyHostToDevice, c->stream));
+    // the permutation on the device; in the one-shot call K1-K4 starts behind it while the host plans K5
+    if (!zc) HIPCHK(c, hipMemcpyAsync(draw + raw_bytes, hb + raw_bytes, (size_t)F * sizeof(GatherRec), hipMemcpyHostToDevice, c->stream));
     if (c->oneshot) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     {
         GatherArgs g;
-        g.view_in = reinterpret_cast<const int*>(draw + r_view); g.slot_in = reinterpret_cast<const int*>(draw + r_slot);
-        g.uv_in = reinterpret_cast<const double*>(draw + r_uv); g.base_in = reinterpret_cast<const double*>(draw + r_base);
-        g.m_in = reinterpret_cast<const double*>(draw + r_m); g.rho_in = reinterpret_cast<const double*>(draw + r_rho);
-        g.perm = ptr<int>(c->dPerm); g.view_s = ptr<int>(c->dViewPtr); g.blk = ptr<long long>(c->dBlkOff);
+        const char* src = zc ? hb : draw;
+        g.uv_in = reinterpret_cast<const double*>(draw);
+        g.slot_in = reinterpret_cast<const int*>(src + r_slot); g.base_in = reinterpret_cast<const double*>(src + r_base);
+        g.m_in = reinterpret_cast<const double*>(src + r_m); g.rho_in = reinterpret_cast<const double*>(src + r_rho);
+        g.rec = reinterpret_cast<const GatherRec*>(src + raw_bytes);
         g.uv = ptr<double>(c->dObsUV); g.base = ptr<double>(c->dBase); g.m = ptr<double>(c->dMvec); g.rho = ptr<double>(c->dRho);
-        g.slot = ptr<int>(c->dObsSlot); g.fmin = ptr<int>(c->dFmin); g.info = ptr<FeatInfo>(c->dFeatInfo);
-        g.F = F;
+        g.slot = ptr<int>(c->dObsSlot); g.fmin = ptr<int>(c->dFmin); g.view = ptr<int>(c->dViewPtr); g.perm = ptr<int>(c->dPerm);
+        g.blk = ptr<long long>(c->dBlkOff); g.info = ptr<FeatInfo>(c->dFeatInfo);
+        g.F = F; g.sumM = sumM;
         hipLaunchKernelGGL(k_gather, dim3((F + GATHER_THREADS / 32 - 1) / (GATHER_THREADS / 32)), dim3(GATHER_THREADS), 0, c->stream, g);
         HIPCHK(c, hipGetLastError());
     }
     // (k_lsweep's zero words behind the stack are written by k_feature itself: one launch less in front of it)
     c->feature_launched = false;
+    if (c->state_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_state, 0)); c->state_pending = false; }
+    c->gate_event = false;
     if (c->oneshot) {
         if (int rcf = launch_feature(c)) return rcf;
         c->feature_launched = true;
+        if (c->gate_direct) { HIPCHK(c, hipEventRecord(c->ev_gate, c->stream)); c->gate_event = true; }
     }
     const double t2 = now_us();
     const bool plan_hit = c->plan_valid && !c->plan_no_wide && c->plan_N == N && c->plan_xchg == c->xchg && c->plan_view == h_view &&
@@ -2088,8 +2131,9 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     const double t0 = now_us();
     const size_t d = c->d;
     // gate results and (when the gain stage ran) status | dx | P_out: two copies behind the pipeline, one sync
-    if (c->F > 0) HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, (size_t)c->F * 5, hipMemcpyDeviceToHost, c->stream));
-    if (c->ran_gain) {
+    if (c->F > 0 && !c->gate_direct) HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, (size_t)c->F * 5, hipMemcpyDeviceToHost, c->stream));
+    const bool direct = c->res_direct && c->direct_serial == c->run_serial;     // (a merge behind the update wrote the HBM arena only)
+    if (c->ran_gain && !direct) {
         const size_t bytes = P_out ? c->res_p_off + d * d * 8 : c->res_dx_off + d * 8;
         HIPCHK(c, hipMemcpyAsync(c->hRes, c->dResArena.p, bytes, hipMemcpyDeviceToHost, c->stream));
     }
@@ -2098,17 +2142,23 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     int counters[4] = {0, 0, 0, 0};
     int status[4] = {0};
     std::vector<unsigned char> acc_sorted;
-    if (int rc0 = gate_counts(c, counters, &acc_sorted, true)) return rc0;
+    const bool gate_done = c->gate_serial == c->run_serial && (!accepted || accepted == c->gate_mask_dst);
+    if (gate_done) std::memcpy(counters, c->gate_cnt, sizeof(counters));
+    else if (int rc0 = gate_counts(c, counters, &acc_sorted, true)) return rc0;
     if (c->ran_gain) std::memcpy(status, c->hRes, 16);
     const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (!(c->ran_gain && n_acc > 0)) status[0] = status[1] = 0;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
+    if (rc == MSCKF_ERR_NOT_SPD && status[0] == 3) {       // the mirror of the status word in host memory was never written
+        c->last_error = "K6-K7 did not report a status";
+        rc = MSCKF_ERR_HIP;
+    }
     if (rc == MSCKF_ERR_NOT_SPD && status[0] == 2) {       // k_gain_stream gave up waiting for rows of T or for another workgroup
         c->last_error = "k_gain_stream: timeout (the root sweep or a workgroup of the update did not make progress)";
         rc = MSCKF_ERR_HIP;
     }
-    if (accepted && c->F > 0) {
+    if (accepted && c->F > 0 && !gate_done) {
         for (int s = 0; s < c->F; ++s) accepted[c->perm[s]] = (acc_sorted[s] == 1) ? 1 : 0;
     }
     const char* hres = static_cast<const char*>(c->hRes);
@@ -2171,15 +2221,22 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
                  int32_t n_crit, double* dx, double* P_out, uint8_t* accepted, msckf_stats* stats) {
     if (!c) return MSCKF_ERR_ARG;
     const double tu0 = now_us();
+    if (c->ran && c->fetched_serial != c->run_serial) HIPCHK(c, hipStreamSynchronize(c->stream));   // a run nobody waited for: the side stream below must not overtake it
     c->defer_state_sync = F > 0;
+    c->want_direct = c->direct_enabled && F > 0;
+    struct Reset { msckf_ctx* c; ~Reset() { c->want_direct = false; } } reset{c};
     int rc = msckf_set_state(c, N, P, cam_R, cam_t, cam_R0, cam_t0, gravity, Kinv, sigma, chi2_crit, n_crit);
     c->defer_state_sync = false;
-    if (rc != MSCKF_OK) return rc;
+    if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream_up); c->state_pending = false; return rc; }
     c->hp[0] += now_us() - tu0;
     c->oneshot = F > 0;
     rc = msckf_set_features(c, F, view_ptr, obs_uv, obs_slot, idp_base, idp_m, idp_rho);
     c->oneshot = false;
-    if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); c->feature_launched = false; return rc; }   // uploads / K1-K4 may be in flight
+    if (rc != MSCKF_OK) {            // uploads / K1-K4 may be in flight
+        (void)hipStreamSynchronize(c->stream_up); (void)hipStreamSynchronize(c->stream);
+        c->feature_launched = false; c->state_pending = false;
+        return rc;
+    }
     if (F == 0) {
         // empty feature dict: the reference returns at MSCKF.py:584-585
         const size_t d = c->d;
@@ -2193,6 +2250,28 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
     if (rc != MSCKF_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     c->hp[7] += now_us() - tu1;
+    if (c->gate_event && c->gate_direct) {
+        // K1-K4's results are in hGate once ev_gate has passed: sum them and fill the caller's mask while K5-K7 run
+        const double tg0 = now_us();
+        HIPCHK(c, hipEventSynchronize(c->ev_gate));
+        const int Fn = c->F;
+        const int* rk = static_cast<const int*>(c->hGate);
+        const unsigned char* acc = static_cast<const unsigned char*>(c->hGate) + (size_t)Fn * 4;
+        const int* perm = c->perm.data();
+        const int* hv = c->h_view_sorted.data();
+        int cnt[4] = {0, 0, 0, 0};
+        for (int s = 0; s < Fn; ++s) {
+            const unsigned char a = acc[s];
+            if (a == 1) { cnt[0]++; cnt[1] += 2 * (hv[s + 1] - hv[s]) - rk[s]; }
+            else if (a == 2) cnt[2]++;
+            else if (a == 3) cnt[3]++;
+            if (accepted) accepted[perm[s]] = a == 1 ? 1 : 0;
+        }
+        std::memcpy(c->gate_cnt, cnt, sizeof(cnt));
+        c->gate_serial = c->run_serial; c->gate_mask_dst = accepted;
+        c->gate_event = false;
+        c->hp[11] += now_us() - tg0;
+    }
     // the result copies go into the stream right behind the kernels: ONE host wait for kernels + copies
     rc = msckf_get_result(c, dx, P_out, accepted, stats);
     float ms = 0;

@@ -1,0 +1,154 @@
+"""The host side of the drop-in call (round 4): tracks uploaded in the caller's order and permuted on the device (k_gather),
+state and K5 plan on a side stream, results mirrored into pinned host memory by the kernels.  None of it may change a bit of
+the result: the one-shot call is compared with the resident sequence (which copies results the old way) and with itself
+under every switch, and the error paths are exercised while uploads are in flight."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+
+
+def _engine(monkeypatch, **env):
+    from msckf_amd.api import UpdateEngine
+    for k in ("MSCKF_DIRECT_RESULT", "MSCKF_ZEROCOPY_MAX", "MSCKF_HOST_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    return UpdateEngine(max_clones=30, max_features=12000, max_track=31)
+
+
+def _shuffled(prob, seed):
+    """The same batch with its tracks in a random order (the caller's order is arbitrary: a dict's insertion order)."""
+    from msckf_amd import synth
+    rng = np.random.default_rng(seed)
+    order = rng.permutation(prob.F)
+    M = np.diff(prob.view_ptr)
+    vp = np.zeros(prob.F + 1, dtype=np.int32)
+    vp[1:] = np.cumsum(M[order])
+    idx = np.concatenate([np.arange(prob.view_ptr[f], prob.view_ptr[f + 1]) for f in order])
+    q = synth.UpdateProblem(**{**prob.__dict__})
+    q.view_ptr = vp
+    q.obs_uv = prob.obs_uv[idx].copy(); q.obs_slot = prob.obs_slot[idx].copy()
+    q.idp_base = prob.idp_base[order].copy(); q.idp_m = prob.idp_m[order].copy(); q.idp_rho = prob.idp_rho[order].copy()
+    return q, order
+
+
+@pytest.mark.parametrize("N,F,M,kw", [
+    (30, 2000, 10, {}),                                                    # zero-copy tables, fused K6-K7, mirrored results
+    (30, 6000, 10, dict(outlier_fraction=0.2, outlier_px=300.0)),           # above the zero-copy size: DMA
+    (30, 1500, 10, dict(variable_tracks=True, outlier_fraction=0.1, outlier_px=300.0)),
+    (12, 300, 5, {}),                                                      # below the host pool's size
+])
+def test_one_shot_equals_resident_under_every_switch(monkeypatch, N, F, M, kw):
+    from msckf_amd import synth
+    prob = synth.make_problem(N, F, M, seed=7, **kw)
+    prob, _ = _shuffled(prob, 3)
+    with _engine(monkeypatch) as eng:
+        eng.load(prob)
+        eng.run()
+        ref = eng.result()                                                 # results copied back by hipMemcpyAsync
+        assert ref.status == 0 and 0 < ref.accepted.sum() <= F
+        one = eng.update_problem(prob)
+        again = eng.update_problem(prob)
+    for r in (one, again):
+        assert r.status == 0
+        assert np.array_equal(r.dx, ref.dx) and np.array_equal(r.P_new, ref.P_new) and np.array_equal(r.accepted, ref.accepted)
+        assert r.stats["n_accepted"] == ref.stats["n_accepted"] and r.stats["stacked_rows"] == ref.stats["stacked_rows"]
+        assert r.n_rejected == ref.n_rejected
+    for env in (dict(MSCKF_DIRECT_RESULT=0), dict(MSCKF_ZEROCOPY_MAX=0), dict(MSCKF_ZEROCOPY_MAX=100000), dict(MSCKF_HOST_THREADS=0)):
+        with _engine(monkeypatch, **env) as eng:
+            r = eng.update_problem(prob)
+        assert np.array_equal(r.dx, ref.dx) and np.array_equal(r.P_new, ref.P_new) and np.array_equal(r.accepted, ref.accepted), env
+
+
+def test_track_order_does_not_matter(monkeypatch):
+    """k_gather's permutation against the host's: the sorted image is the same whatever the caller's order, so dx / P+ are
+    bitwise those of the unshuffled batch and the mask comes back in the caller's order."""
+    from msckf_amd import synth
+    prob = synth.make_problem(30, 3000, 10, seed=11, variable_tracks=True, outlier_fraction=0.15, outlier_px=300.0)
+    with _engine(monkeypatch) as eng:
+        base = eng.update_problem(prob)
+        for seed in (1, 2):
+            q, order = _shuffled(prob, seed)
+            r = eng.update_problem(q)
+            assert np.array_equal(r.accepted, base.accepted[order])
+            # (tracks with equal first / last slot keep the caller's relative order: the sums differ in the last bits)
+            assert rel_err(r.dx, base.dx) < 1e-10 and rel_err(r.P_new, base.P_new) < 1e-10
+
+
+def test_golden_through_the_mirrored_results(monkeypatch):
+    with _engine(monkeypatch) as eng:
+        for case in ("cfg1_A", "cfg2_A", "cfg2_B", "edge_variable_tracks", "edge_all_rejected"):
+            try:
+                prob, ref = load_golden(case)
+            except FileNotFoundError:
+                continue
+            res = eng.update_problem(prob)
+            assert res.status == int(ref["status"]), case
+            assert np.array_equal(res.accepted, ref["accepted"]), case
+            assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL, case
+
+
+def test_commit_and_resident_run_behind_a_one_shot_call(monkeypatch):
+    """P+ of the one-shot call is in HBM as well as in the host mirror: commit it and run the next batch on it."""
+    from msckf_amd import synth
+    p1 = synth.make_problem(30, 2000, 10, seed=21)
+    p2 = synth.make_problem(30, 2000, 10, seed=22)
+    with _engine(monkeypatch) as eng:
+        r1 = eng.update_problem(p1)
+        assert eng.commit_covariance() == 0
+        assert np.array_equal(eng.covariance(), r1.P_new)
+        eng.set_poses(p2.cam_R, p2.cam_t, p2.cam_R0, p2.cam_t0)
+        eng.set_features(p2)
+        eng.run()
+        res = eng.result()                                   # the copy path again, behind a mirrored run
+        q = synth.UpdateProblem(**{**p2.__dict__})
+        q.P = r1.P_new
+        q.gravity = p1.gravity; q.K = p1.K; q.sigma = p1.sigma
+        chk = eng.update_problem(q)
+    assert res.status == 0
+    assert np.array_equal(res.dx, chk.dx) and np.array_equal(res.P_new, chk.P_new)
+
+
+def test_errors_while_uploads_are_in_flight(monkeypatch):
+    """A slot out of range / a duplicate slot is found AFTER the observations have started up by DMA (and the state on the side
+    stream): the call returns the code, the engine drains its streams and the next call is clean."""
+    from msckf_amd import synth
+    from msckf_amd._ffi import EngineError, ERR_ARG, ERR_DUP_SLOT
+    good = synth.make_problem(30, 5000, 10, seed=31)
+    with _engine(monkeypatch) as eng:
+        ref = eng.update_problem(good)
+        for where, val, code in ((40000, 30, ERR_ARG), (49999, -1, ERR_ARG), (123, None, ERR_DUP_SLOT)):
+            bad = synth.UpdateProblem(**{**good.__dict__})
+            sl = good.obs_slot.copy()
+            sl[where] = sl[where + 1] if val is None else val
+            bad.obs_slot = sl
+            with pytest.raises(EngineError) as ei:
+                eng.update_problem(bad)
+            assert ei.value.code == code, (where, val)
+            r = eng.update_problem(good)
+            assert np.array_equal(r.dx, ref.dx) and np.array_equal(r.P_new, ref.P_new)
+
+
+def test_no_accepted_track_and_empty_batch(monkeypatch):
+    """The reference's early returns (MSCKF.py:584-585, 591-592) through the mirrored results: status 1, dx = 0, P untouched."""
+    from msckf_amd import synth
+    prob, ref = load_golden("edge_all_rejected")
+    with _engine(monkeypatch) as eng:
+        r = eng.update_problem(prob)
+        assert r.status == 1 and r.accepted.sum() == 0
+        assert np.array_equal(r.P_new, prob.P) and not r.dx.any()
+        assert r.n_rejected == int(ref["n_rejected"])
+        good = synth.make_problem(20, 1500, 8, seed=6)
+        assert eng.update_problem(good).status == 0
+        empty = synth.UpdateProblem(**{**good.__dict__})
+        empty.view_ptr = np.zeros(1, dtype=np.int32)
+        empty.obs_uv = np.zeros((0, 2)); empty.obs_slot = np.zeros(0, dtype=np.int32)
+        empty.idp_base = np.zeros((0, 3)); empty.idp_m = np.zeros((0, 3)); empty.idp_rho = np.zeros(0)
+        r = eng.update_problem(empty)
+        assert r.status == 1 and np.array_equal(r.P_new, good.P) and not r.dx.any()
+        assert eng.update_problem(good).status == 0
