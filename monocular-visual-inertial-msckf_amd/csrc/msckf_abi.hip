@@ -380,6 +380,11 @@ struct msckf_ctx {
     int gate_cnt[4] = {0, 0, 0, 0};
     const uint8_t* gate_mask_dst = nullptr;
     bool direct_enabled = true;
+    // Resident calls that leave their work in the stream without waiting for it (msckf_set_features, msckf_set_poses,
+    // msckf_commit_covariance): the next call that rewrites a pinned staging buffer, or that uses the side stream, waits first.
+    bool feat_busy = false, pose_busy = false;   // hFeat / hPose may still be read by a copy or by k_gather
+    bool main_busy = false;                      // the main stream holds work nobody has waited for
+    bool run_pending = false;                    // ... a pipeline / merge among it (kernels that read the K5 plan and the workspace)
     bool wide_concurrent = true;          // MSCKF_WIDE_STREAM=0: everything on one stream
     long run_serial = 0;                  // bumped by every pipeline / merge launch
     long fetched_serial = -1;             // the run whose return code msckf_get_result derived last ...
@@ -458,12 +463,14 @@ int upload_poses(msckf_ctx* c, hipStream_t st = nullptr) {
     if (!st) st = c->stream;
     const size_t N = c->h_cam[1].size() / 3, mN = c->maxN;
     if (N == 0) return MSCKF_OK;
+    if (c->pose_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream_up)); c->pose_busy = false; }
     double* h = static_cast<double*>(c->hPose);
     std::memcpy(h, c->h_cam[0].data(), N * 72);
     std::memcpy(h + 9 * mN, c->h_cam[1].data(), N * 24);
     std::memcpy(h + 12 * mN, c->h_cam[2].data(), N * 72);
     std::memcpy(h + 21 * mN, c->h_cam[3].data(), N * 24);
     HIPCHK(c, hipMemcpyAsync(c->dPoseArena.p, h, 24 * mN * 8, hipMemcpyHostToDevice, st));
+    c->pose_busy = true;
     return MSCKF_OK;
 }
 
@@ -1515,7 +1522,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     c->ran_gain = with_gain;
     c->acc_override = -1;
     c->acc_from_dev = false;
-    ++c->run_serial;
+    ++c->run_serial; c->run_pending = true;
     if (c->res_direct) c->direct_serial = c->run_serial;
     return MSCKF_OK;
 }
@@ -1775,6 +1782,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     HIPCHK(c, hipSetDevice(c->device));
     const double t0 = now_us();
     const int N = c->N;
+    if (c->feat_busy) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->feat_busy = false; }     // (the pinned image is rewritten below)
     // the previous batch is gone from here on: a validation failure below must not leave `have_features`
     // standing over arenas / plan that describe another F (run() then returns MSCKF_ERR_STATE)
     c->have_features = false;
@@ -2013,12 +2021,13 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             HIPCHK(c, hipMalloc(&c->dRbuf.p, want));
             c->dRbuf.bytes = want;
         }
-        // (one-shot: the previous call ended with a wait for the device, nothing reads the workspace or the tables now)
-        c->plan_stream = c->oneshot ? c->stream_up : c->stream;
+        // (on the side stream unless a pipeline nobody waited for may still be reading the workspace or the tables)
+        const bool side = c->oneshot || !c->run_pending;
+        c->plan_stream = side ? c->stream_up : c->stream;
         HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->plan_stream));
         c->plan_valid = false;
         const int rcp = upload_plan(c);
-        if (c->oneshot) {
+        if (side) {
             HIPCHK(c, hipEventRecord(c->ev_plan, c->stream_up));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_plan, 0));
         }
@@ -2028,7 +2037,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->plan_valid = true;
         c->plan_no_wide = false;
     }
-    if (!c->oneshot) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->feat_busy = true; c->main_busy = true;       // (resident call: the uploads and k_gather stay in the stream)
     c->us_h2d += (float)((t2 - t1) + (now_us() - t3));
     c->hp[1] += tv - t0; c->hp[2] += ts - tv; c->hp[3] += t1 - ts; c->hp[4] += t2 - t1; c->hp[5] += t3 - t2; c->hp[6] += now_us() - t3;
     c->have_features = true;
@@ -2038,7 +2047,11 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
 int msckf_run(msckf_ctx* c) {
     if (!c) return MSCKF_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    return run_pipeline(c, true, nullptr);
+    c->want_direct = c->direct_enabled;             // results mirrored into the pinned host buffers, as in the one-shot call
+    const int rc = run_pipeline(c, true, nullptr);
+    c->want_direct = false;
+    c->main_busy = true;
+    return rc;
 }
 
 int msckf_run_compress(msckf_ctx* c) {
@@ -2070,6 +2083,8 @@ int msckf_sync(msckf_ctx* c) {
     if (!c) return MSCKF_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream_up));
+    c->feat_busy = c->pose_busy = c->main_busy = c->run_pending = false;
     return MSCKF_OK;
 }
 
@@ -2138,6 +2153,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
         HIPCHK(c, hipMemcpyAsync(c->hRes, c->dResArena.p, bytes, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->feat_busy = c->pose_busy = c->main_busy = c->run_pending = false;
     const double tsync = now_us();
     int counters[4] = {0, 0, 0, 0};
     int status[4] = {0};
@@ -2196,7 +2212,7 @@ int msckf_commit_covariance(msckf_ctx* c) {
     if (c->fetched_serial == c->run_serial) {          // msckf_get_result has already decided this run: no second read-back
         if (c->fetched_rc != MSCKF_OK) return c->fetched_rc;
         HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->main_busy = true;                           // (stays in the stream: every reader of P is behind it)
         return MSCKF_OK;
     }
     int counters[4] = {0, 0, 0, 0};
@@ -2221,7 +2237,10 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
                  int32_t n_crit, double* dx, double* P_out, uint8_t* accepted, msckf_stats* stats) {
     if (!c) return MSCKF_ERR_ARG;
     const double tu0 = now_us();
-    if (c->ran && c->fetched_serial != c->run_serial) HIPCHK(c, hipStreamSynchronize(c->stream));   // a run nobody waited for: the side stream below must not overtake it
+    if (c->main_busy || (c->ran && c->fetched_serial != c->run_serial)) {       // work nobody waited for: the side stream below must not overtake it
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->main_busy = c->feat_busy = c->pose_busy = c->run_pending = false;
+    }
     c->defer_state_sync = F > 0;
     c->want_direct = c->direct_enabled && F > 0;
     struct Reset { msckf_ctx* c; ~Reset() { c->want_direct = false; } } reset{c};
@@ -2560,8 +2579,8 @@ int msckf_set_poses(msckf_ctx* c, const double* cam_R, const double* cam_t, cons
     const size_t N = c->N;
     c->h_cam[0].assign(cam_R, cam_R + N * 9); c->h_cam[1].assign(cam_t, cam_t + N * 3);
     c->h_cam[2].assign(cam_R0, cam_R0 + N * 9); c->h_cam[3].assign(cam_t0, cam_t0 + N * 3);
-    if (int rc = upload_poses(c)) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (int rc = upload_poses(c)) return rc;       // (stays in the stream: whatever reads the poses is behind it)
+    c->main_busy = true;
     c->ran = false;
     return MSCKF_OK;
 }
@@ -2665,7 +2684,7 @@ int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int
     HIPCHK(c, hipGetLastError());
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
-    ++c->run_serial;
+    ++c->run_serial; c->run_pending = true;
     return MSCKF_OK;
 }
 
@@ -2897,7 +2916,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         }
         if (int rcm = collect_masks(c, recs, (long long)rec, n_rec)) return rcm;
         c->ran = true; c->ran_gain = false; c->acc_override = 0; c->acc_from_dev = false;
-        ++c->run_serial;
+        ++c->run_serial; c->run_pending = true;
         return MSCKF_OK;
     }
     const int nb = (int)c->snodes.size();
@@ -2925,7 +2944,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         c->ran = true; c->ran_gain = true;
         c->acc_override = total_accepted;
         c->acc_from_dev = count_on_device;
-        ++c->run_serial;
+        ++c->run_serial; c->run_pending = true;
         return MSCKF_OK;
     }
     SweepArgs a{};
@@ -2955,7 +2974,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     c->ran = true; c->ran_gain = true;
     c->acc_override = total_accepted;
     c->acc_from_dev = count_on_device;
-    ++c->run_serial;
+    ++c->run_serial; c->run_pending = true;
     return MSCKF_OK;
 }
 }  // namespace

@@ -152,3 +152,42 @@ def test_no_accepted_track_and_empty_batch(monkeypatch):
         r = eng.update_problem(empty)
         assert r.status == 1 and np.array_equal(r.P_new, good.P) and not r.dx.any()
         assert eng.update_problem(good).status == 0
+
+
+def test_resident_calls_without_waits_keep_their_order(monkeypatch):
+    """msckf_set_features / msckf_set_poses / msckf_commit_covariance / msckf_run leave their work in the stream; a call that
+    rewrites a pinned staging buffer or uses the side stream waits first.  Back-to-back sequences nobody waited for must give
+    the results of the same calls made one by one with a wait after each."""
+    from msckf_amd import synth
+    pa = synth.make_problem(30, 2000, 10, seed=41)
+    pb = synth.make_problem(30, 3000, 8, seed=42, variable_tracks=True)
+    pc = synth.make_problem(30, 1800, 10, seed=43)
+    with _engine(monkeypatch) as eng:
+        ref_a = eng.update_problem(pa)
+        qb = synth.UpdateProblem(**{**pb.__dict__}); qb.P = ref_a.P_new
+        qb.gravity = pa.gravity; qb.K = pa.K; qb.sigma = pa.sigma
+        ref_b = eng.update_problem(qb)                        # pb's tracks and poses on pa's P+
+        qc = synth.UpdateProblem(**{**pc.__dict__}); qc.P = ref_b.P_new
+        qc.gravity = pa.gravity; qc.K = pa.K; qc.sigma = pa.sigma
+        ref_c = eng.update_problem(qc)
+
+        eng.set_state(pa)
+        eng.set_features(pc)                                  # overwritten before anyone waited for it
+        eng.set_features(pa)
+        eng.run()
+        eng.set_features(pa)                                  # a run is pending: the plan must not overtake it on the side stream
+        eng.run()
+        ra = eng.result()
+        assert np.array_equal(ra.dx, ref_a.dx) and np.array_equal(ra.P_new, ref_a.P_new)
+        assert eng.commit_covariance() == 0
+        eng.set_poses(pc.cam_R, pc.cam_t, pc.cam_R0, pc.cam_t0)
+        eng.set_poses(pb.cam_R, pb.cam_t, pb.cam_R0, pb.cam_t0)          # the pose staging buffer twice in a row
+        eng.set_features(pb)
+        eng.run()
+        rb = eng.result()
+        assert np.array_equal(rb.dx, ref_b.dx) and np.array_equal(rb.P_new, ref_b.P_new)
+        assert np.array_equal(rb.accepted, ref_b.accepted)
+        assert eng.commit_covariance() == 0                   # left in the stream ...
+        rc = eng.update_problem(qc)                           # ... and the one-shot call's side stream waits for it
+        assert np.array_equal(rc.dx, ref_c.dx) and np.array_equal(rc.P_new, ref_c.P_new)
+        assert np.array_equal(eng.covariance(), ref_b.P_new)  # (the one-shot call does not commit)
