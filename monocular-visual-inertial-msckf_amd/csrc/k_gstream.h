@@ -525,10 +525,15 @@ __global__ __launch_bounds__(64 * GS_WAVES) void k_gain_stream(GStreamArgs p) {
 // grid of at most 33 workgroups that ask for more than half of a CU's LDS), so all of them are resident at once.
 // (As two launches on two streams the pair cost an event record in front of the sweep and a cross-stream wait behind
 //  the update: ~17 us per update around ~225 us of kernels.)
+// Workgroups behind the strips (mp.nodes != nullptr): the LAST level of group merges, in the same launch.  Each publishes the
+// rows of its triangle as they become final (blocks of 8, its own progress word) and the root's folds take them from there
+// (SweepFold::prod) instead of waiting for the level to end: the root runs ~27 macro steps behind the merges, where a launch
+// boundary put it 68 steps + a launch gap behind (k_sweep.h).
 template <int NF, int TPW>
-__global__ __launch_bounds__(64 * (NF + 1)) void k_root_gain(SweepArgs sp, GStreamArgs gp) {
-    if (blockIdx.x == 0) sweep_body<NF, 1, false, true>(sp);
-    else gain_stream_body<NF + 1, NF, TPW>(gp, (int)blockIdx.x - 1);
+__global__ __launch_bounds__(64 * (NF + 1)) void k_root_gain(SweepArgs sp, GStreamArgs gp, SweepArgs mp) {
+    const int b = (int)blockIdx.x;
+    if (b >= 1 && b <= gp.ns) gain_stream_body<NF + 1, NF, TPW>(gp, b - 1);
+    else sweep_body<NF, 1, false, true>(b == 0 ? sp : mp, b == 0 ? 0 : b - 1 - gp.ns);
 }
 
 // The same pairing for the ring-buffered sweeps (N > 37 clones or tracks of 11 - 15 slots): k_wsweep's fold wavefronts store

@@ -50,7 +50,11 @@ struct SweepFold {
     int w;               // rows / columns of the source triangle (<= SWEEP_MAX_W)
     int ew;              // tile width: columns [off, off+ew) may fill in (w <= ew <= SWEEP_MAX_W)
     int t0;              // macro step of the fold's first column
-    int pad0, pad1;
+    int prod;            // 0, or 1 + index of the progress word of the node that is still WRITING the source block in the same
+                         // launch (k_root_gain's merge workgroups): the flusher lets a macro step start only when the rows its
+                         // folds fetch in it are published (host table, sweep_gate_table)
+    int ld;              // doubles per row of the source block (0: w + 1).  A streamed block has whole cache lines per row (64):
+                         // a line fetched for a published row must not hold part of a row that is not final yet
 };
 
 struct SweepNode {
@@ -58,7 +62,9 @@ struct SweepNode {
                                 // run on fold slot (i - first scheduled) % NF
     int wtot;                   // columns of the node's R
     int nsteps;                 // macro steps
-    long long out_off;          // output block in rbuf: row-major wtot x (wtot+1)
+    long long out_off;          // output block in rbuf: row-major wtot x (wtot+1), or wtot x ldo
+    int ldo;                    // doubles per row of the output block (0: wtot + 1)
+    int pad;
 };
 
 struct SweepArgs {
@@ -74,11 +80,22 @@ struct SweepArgs {
     unsigned long long* progress;   // (epoch << 32) | rows of the output block that are final AND visible device-wide
     unsigned epoch;
     long long* tstamp;          // optional: [0] wall clock (10 ns ticks) when the sweep starts, [1] when its last row is published
+    const int* flush_off;       // optional: per node (index in the launch) the offset of its table in flush_tab
+    int prog_stride;            // progress word of node i of the launch: progress[i * prog_stride] (0: one word, the root's)
+    int pub_shift;              // rows are published in blocks of 1 << pub_shift (0 = 4: k_gstream.h's row blocks, aligned to
+                                // the END of the block; 3: blocks of 8 from row 0, what a fold fetches per chunk)
+    // the consumer of streamed sources (the root inside k_root_gain's launch):
+    const unsigned long long* src_progress;   // progress words of the producing nodes (SweepFold::prod), null: nothing is streamed
+    int n_prod;                               // ... how many (<= 64)
+    // behind the nsteps + 1 flush entries of the node's table (host: sweep_gate_table): nsteps + 2 step entries (what must be
+    // published before macro step t starts: up to two requirements prod << 6 | rows, 12 bits each) | n_gate requirements of step 0
+    int n_gate;
 };
 
 constexpr int SWEEP_MAX_W = 60;        // widest source / envelope (local column 63 holds the rhs)
 constexpr int SWEEP_RS = 64;           // doubles per R row in LDS: entry (c, col) at [c][col - c], rhs at [c][63]
 constexpr double SWEEP_TINY = 1e-290;  // |column|^2 under this is treated as an exact zero column
+constexpr long long SWEEP_TIMEOUT_TICKS = 50000000;   // 0.5 s of the 100 MHz wall clock: a streamed source that never arrives
 }  // namespace msckf
 #include "sweep_step.h"
 namespace msckf {
@@ -87,8 +104,8 @@ __host__ __device__ inline size_t sweep_lds_bytes(int wtot, int nf, int wpf) {
     return ((size_t)wtot * SWEEP_RS + (size_t)nf * wpf * 64 + 2) * 8;   // R | dump words | zero words
 }
 // ... with the flusher's table (nsteps + 1 ints) behind them
-__host__ __device__ inline size_t sweep_lds_bytes_fl(int wtot, int nf, int nsteps) {
-    return sweep_lds_bytes(wtot, nf, 1) + (((size_t)nsteps + 2) * 4 + 15) / 16 * 16;
+__host__ __device__ inline size_t sweep_lds_bytes_fl(int wtot, int nf, int nsteps, int n_gate = -1) {
+    return sweep_lds_bytes(wtot, nf, 1) + (((size_t)nsteps + 2 + (n_gate >= 0 ? nsteps + 2 + n_gate : 0)) * 4 + 15) / 16 * 16;
 }
 
 // Sum over the 4 lanes of a DPP quad; every lane of the quad gets the sum.
@@ -161,14 +178,14 @@ template <int KK> struct STag { static constexpr int value = KK; };
 // are reduce-scattered with the lane swaps (row r ends up with the dot of column slot r: 6 swaps and 3 additions)
 // and tau goes back the same way.
 template <int NF, int WPF, bool P2P, bool FL>
-__device__ __forceinline__ void sweep_body(const SweepArgs& p) {
+__device__ __forceinline__ void sweep_body(const SweepArgs& p, const int bidx) {
     static_assert(WPF == 1 && !P2P, "one wavefront per fold, one barrier per macro step");
     constexpr int NW = NF;              // fold wavefronts
     constexpr int NT = 64 * (NF + (FL ? 1 : 0));   // threads: with FL one more wavefront, the flusher
     constexpr int CL = 16;              // column lanes of a fold
     constexpr int CS = 4;               // column slots of a lane
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const SweepNode nd = p.nodes[p.node_base + blockIdx.x];
+    const SweepNode nd = p.nodes[p.node_base + bidx];
     const int t = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int lane = t & 63;
@@ -186,7 +203,9 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
     int* ftab = reinterpret_cast<int*>(smem + (size_t)nd.wtot * SWEEP_RS + NW * 64 + 2);
     if constexpr (FL) {
         // (the flusher reads its table from LDS: a vector-memory load per step would make it wait for its own stores)
-        for (int e = t; e <= nsteps; e += NT) ftab[e] = p.flush_tab[e];
+        const int* tab = p.flush_tab + (p.flush_off ? p.flush_off[bidx] : 0);
+        const int ntab = nsteps + 1 + (p.src_progress ? nsteps + 2 + p.n_gate : 0);
+        for (int e = t; e < ntab; e += NT) ftab[e] = tab[e];
     }
     // the node's first triangle (t0 == 0) is adopted: its rows ARE the first rows of R, nothing to eliminate
     const SweepFold f0 = p.folds[nd.fold_begin];
@@ -194,10 +213,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
     if (adopt) {
         __syncthreads();
         const double* src = p.rbuf + f0.src_off;
-        const int ldw = f0.w + 1;
+        const int ldw = f0.w + 1, lds_ = f0.ld ? f0.ld : ldw;
         for (int e = t; e < f0.w * ldw; e += NT) {
             const int r = e / ldw, lc = e - r * ldw;
-            if (lc >= r) Rb[(size_t)(f0.off + r) * SWEEP_RS + (lc == f0.w ? 63 : lc - r)] = src[e];
+            if (lc >= r) Rb[(size_t)(f0.off + r) * SWEEP_RS + (lc == f0.w ? 63 : lc - r)] = src[(size_t)r * lds_ + lc];
         }
     }
 
@@ -210,20 +229,46 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
         // step would hold the flusher -- and with it the step's barrier -- for a store's round trip.  It joins the
         // barriers bare (s_barrier without the waits of __syncthreads()).
         if (wv == NF) {
-            const int ldo = nd.wtot + 1;
+            const int ldo = nd.ldo ? nd.ldo : nd.wtot + 1;
             double* out = p.rbuf + nd.out_off;
             const int wtot = __builtin_amdgcn_readfirstlane(nd.wtot);
             const unsigned long long ep = (unsigned long long)p.epoch << 32;
             int c1 = 0, c2 = 0;                     // vector-memory instructions issued one / two steps ago
             int l1 = 0, l2 = 0, l3 = 0;             // rows final one / two / three steps ago
             int published = 0;
-            const int boff = (16 - (wtot & 15)) & 15;   // k_gstream.h's row blocks end at rows = wtot (mod 16)
+            const int psh = p.pub_shift ? p.pub_shift : 4;
+            const int boff = p.pub_shift ? 0 : (16 - (wtot & 15)) & 15;   // k_gstream.h's row blocks end at rows = wtot (mod 16)
+            auto* progw = (__attribute__((address_space(1))) unsigned long long*)(p.progress + (size_t)bidx * p.prog_stride);
+            // Streamed sources: `seen_rows` (lane l: rows of producer l published in this launch, as last read) is refreshed only
+            // when a requirement is not covered by it -- while the producers are still running the sweep has to wait for them
+            // anyway, and once they are through ONE refresh covers every later requirement.  Per step at most two requirements
+            // (prod << 6 | rows, 12 bits each: the host moves a third to an earlier step), read with the step's flush entry.
+            const bool gated = p.n_gate >= 0 && p.src_progress;
+            const int* gtab = ftab + nsteps + 1;            // [nsteps + 2]: entry t = what must be published before macro step t starts
+            const int* g0 = gtab + nsteps + 2;              // [n_gate]: ... before the first fetch (step 0)
+            int seen_rows = 0;
+            bool dead = false;
+            auto need = [&](int r) {
+                const int prod = r >> 6, rows = r & 63;
+                long long tstart = 0;
+                while (__builtin_amdgcn_readlane(seen_rows, prod) < rows) {
+                    if (tstart == 0) tstart = wall_clock64();
+                    else { __builtin_amdgcn_s_sleep(1); if (wall_clock64() - tstart > SWEEP_TIMEOUT_TICKS) { dead = true; break; } }
+                    const unsigned long long v = (lane < p.n_prod) ? __hip_atomic_load((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)(p.src_progress + lane),
+                                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    seen_rows = ((unsigned)(v >> 32) == p.epoch) ? (int)(unsigned)v : 0;
+                }
+            };
             if (p.tstamp && lane == 0) p.tstamp[0] = wall_clock64();
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // R zeroed / adopted, table in place
             asm volatile("" ::: "memory");
+            if (gated) for (int k = 0; k < p.n_gate && !dead; ++k) need(__builtin_amdgcn_readfirstlane(g0[k]));   // the rows the fold slots fetch before their first step
+            __builtin_amdgcn_s_barrier();           // (the fold wavefronts' second barrier in front of their first fetch)
+            asm volatile("" ::: "memory");
             for (int ts = 0; ts <= nsteps; ++ts) {
                 const int e = __builtin_amdgcn_readfirstlane(ftab[ts]);
+                const int ge = gated ? __builtin_amdgcn_readfirstlane(gtab[ts + 1]) : 0;     // (what the folds fetch at the head of the next step)
                 const int lo = e & 0xFFFF, n = e >> 16;
                 for (int c = lo; c < lo + n; ++c) {
                     const double x = Rb[(size_t)c * SWEEP_RS + lane];
@@ -234,7 +279,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
                     }
                 }
                 int issued = n;
-                if (((l3 + boff) >> 4) > ((published + boff) >> 4)) {   // (the reader takes rows in blocks of 16, the short block first)
+                if (((l3 + boff) >> psh) > ((published + boff) >> psh) && !dead) {   // (the reader takes rows in blocks of 16, the short block first)
                     // the stores of rows < l3 were issued three steps ago or earlier: c2 + c1 + n instructions since
                     const int m = c2 + c1 + n;
                     switch (m < 7 ? m : 7) {
@@ -247,25 +292,22 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
                         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
                         default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
                     }
-                    if (lane == 0)
-                        __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress, ep | (unsigned)l3,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(progw, ep | (unsigned)l3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     published = l3;
                     ++issued;
-                    if (p.tstamp && lane == 0) { const int kb = (l3 + boff) >> 4; if (kb < 14) p.tstamp[18 + kb] = wall_clock64(); }
+                    if (p.tstamp && lane == 0) { const int kb = (l3 + boff) >> psh; if (kb < 14) p.tstamp[18 + kb] = wall_clock64(); }
                 }
                 l3 = l2; l2 = l1; l1 = lo + n;
                 c2 = c1; c1 = issued;
                 if (ts < nsteps) {
+                    if (ge != 0 && !dead) { need(ge & 4095); if ((ge >> 12) != 0 && !dead) need(ge >> 12); }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)p.progress, ep | (unsigned)wtot,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && !dead) __hip_atomic_store(progw, ep | (unsigned)wtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (p.tstamp && lane == 0) p.tstamp[1] = wall_clock64();
             return;
         }
@@ -283,36 +325,37 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tprev = __builtin_readcyclecounter();
 #endif
-    int f_off = 0, f_w = 0, f_ew = 0, f_t0 = 0;
+    int f_off = 0, f_w = 0, f_ew = 0, f_t0 = 0, f_ld = 1;
     const double* f_src = p.rbuf;
-    int n_off = 0, n_w = 0, n_ew = 0, n_t0 = 0;
+    int n_off = 0, n_w = 0, n_ew = 0, n_t0 = 0, n_ld = 1;
     const double* n_src = p.rbuf;
 
-    auto read_desc = [&](int fi, int& o_off, int& o_w, int& o_ew, int& o_t0, const double*& o_src) {
+    auto read_desc = [&](int fi, int& o_off, int& o_w, int& o_ew, int& o_t0, int& o_ld, const double*& o_src) {
         const SweepFold f = p.folds[fi];
         o_off = __builtin_amdgcn_readfirstlane(f.off);
         o_w = __builtin_amdgcn_readfirstlane(f.w);
         o_ew = __builtin_amdgcn_readfirstlane(f.ew);
         o_t0 = __builtin_amdgcn_readfirstlane(f.t0);
+        o_ld = __builtin_amdgcn_readfirstlane(f.ld ? f.ld : f.w + 1);
         o_src = p.rbuf + f.src_off;
     };
     // element (row slot rr, column slot k) of a source triangle; unconditional load from a clamped address
     // (structural zeros are read from p.zero, a zero double of the workspace: no select after the load, so the
     //  wait for the data sits at its first use, chunks later)
-    auto load_elem = [&](const double* src, int w, int rr, int k) -> double {
+    auto load_elem = [&](const double* src, int w, int ld, int rr, int k) -> double {
         const int r = rq + 4 * rr, lc = cq + CL * k;
         const bool isr = (k == CS - 1) && (cq == CL - 1);
         const bool ok = (r < w) && (isr || (lc >= r && lc < w));
         const int col = isr ? w : lc;
         // (64-bit addresses: a fold's source need not live in the workspace -- rank 0 folds gathered records where they lie)
-        const double* q = ok ? src + (r * (w + 1) + col) : p.zero;
+        const double* q = ok ? src + (r * ld + col) : p.zero;
         return *q;
     };
     auto fetch_next_head = [&]() {      // row slots 0, 1 of the next fold
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int k = 0; k < CS; ++k) nxt[rr][k] = load_elem(n_src, n_w, rr, k);
+            for (int k = 0; k < CS; ++k) nxt[rr][k] = load_elem(n_src, n_w, n_ld, rr, k);
     };
 
     // Every lane looks after ONE entry of the pivot row of R: row lane rq takes column slot rq, i.e. local column
@@ -358,7 +401,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
         for (int rr = 2 * KK + 2; rr <= 2 * KK + 3 && rr < 16; ++rr) {
 #pragma unroll
             for (int k = 0; k < CS; ++k) {
-                if (CL * k + CL - 1 >= 4 * rr) a[rr][k] = load_elem(f_src, f_w, rr, k);   // else structurally zero, never read
+                if (CL * k + CL - 1 >= 4 * rr) a[rr][k] = load_elem(f_src, f_w, f_ld, rr, k);   // else structurally zero, never read
             }
         }
         if (have_next && KK == max((f_ew - 1) / 8 - 1, 0)) fetch_next_head();
@@ -382,14 +425,15 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
     };
 
     __syncthreads();                                       // R zeroed
+    if constexpr (FL) __syncthreads();                     // (the flusher has seen to it that the first rows are there)
     int fi = nd.fold_begin + adopt + fs;
     bool have = fi < fold_end;
     if (have) {
-        read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
+        read_desc(fi, n_off, n_w, n_ew, n_t0, n_ld, n_src);
         fetch_next_head();
     }
     while (have) {
-        f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_src = n_src;
+        f_off = n_off; f_w = n_w; f_ew = n_ew; f_t0 = n_t0; f_ld = n_ld; f_src = n_src;
         while (tcur < f_t0) { __syncthreads(); ++tcur; }   // (the host schedules t0 >= 1 and one spare step per slot reuse)
         init_addr();
 #pragma unroll
@@ -398,7 +442,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
             for (int k = 0; k < CS; ++k) a[rr][k] = nxt[rr][k];
         fi += NF;
         const bool have_next = fi < fold_end;
-        if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_src);
+        if (have_next) read_desc(fi, n_off, n_w, n_ew, n_t0, n_ld, n_src);
         chunk(STag<0>{}, have_next);
         chunk(STag<1>{}, have_next);
         chunk(STag<2>{}, have_next);
@@ -415,7 +459,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
     // ---- flush R: row-major wtot x (wtot+1), entries at and right of the diagonal ----
     __syncthreads();
     double* out = p.rbuf + nd.out_off;
-    const int ldo = nd.wtot + 1;
+    const int ldo = nd.ldo ? nd.ldo : nd.wtot + 1;
     for (int c = wv; c < nd.wtot; c += NW) {
         const double* Rrow = Rb + (size_t)c * SWEEP_RS;
         for (int col = c + lane; col < nd.wtot; col += 64) {
@@ -438,7 +482,7 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p) {
 
 template <int NF, int WPF, bool P2P = false, bool FL = false>
 __global__ __launch_bounds__(64 * (NF + (FL ? 1 : 0)) * WPF) void k_sweep(SweepArgs p) {
-    sweep_body<NF, WPF, P2P, FL>(p);
+    sweep_body<NF, WPF, P2P, FL>(p, (int)blockIdx.x);
 }
 
 }  // namespace msckf

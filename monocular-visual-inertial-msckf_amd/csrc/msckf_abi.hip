@@ -382,6 +382,14 @@ struct msckf_ctx {
     bool direct_enabled = true;
     // Resident calls that leave their work in the stream without waiting for it (msckf_set_features, msckf_set_poses,
     // msckf_commit_covariance): the next call that rewrites a pinned staging buffer, or that uses the side stream, waits first.
+    // The last level of group merges inside k_root_gain's launch, the root taking their rows as they are published (k_gstream.h):
+    bool root_streamed = false;           // this plan's root folds name their producers (SweepFold::prod), first fold not adopted
+    int stream_level = -1;                // index of that level in sweep_levels
+    std::vector<int> h_mflush;            // [n offsets | the nodes' flush tables]
+    int mflush_at = 0;                    // where h_mflush sits in the uploaded h_root_flush
+    int root_n_gate = -1;                 // step-0 requirements behind the root's flush + gate tables (sweep_gate_table), -1: no gate table
+    Buf dMFlush, dMProg;                  // ... on the device; the merge nodes' progress words (64)
+    bool stream_enabled = true;           // MSCKF_ROOT_STREAM=0: the level keeps its own launch
     bool feat_busy = false, pose_busy = false;   // hFeat / hPose may still be read by a copy or by k_gather
     bool main_busy = false;                      // the main stream holds work nobody has waited for
     bool run_pending = false;                    // ... a pipeline / merge among it (kernels that read the K5 plan and the workspace)
@@ -602,10 +610,10 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
 //             into the band R = the root block [T | r_n].
 // Returns false when the batch does not qualify (wide tracks, R band over the LDS budget): tree plan then.
 constexpr int SWEEP_NW_BIG = 12;                 // k_sweep group merges of more than SWEEP_NW + 1 triangles: twelve fold slots, one round
-void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps, int nf = SWEEP_NW) {
+void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps, int nf = SWEEP_NW, bool adopt = true) {
     int last = 0;
-    if (end > begin) folds[begin].t0 = 0;                  // adopted: copied into the empty R, no elimination steps
-    const int first = begin + 1;
+    if (end > begin && adopt) folds[begin].t0 = 0;         // adopted: copied into the empty R, no elimination steps
+    const int first = adopt ? begin + 1 : begin;           // (not adopted: a streamed first triangle is folded like the others)
     for (int g = first; g < end; ++g) {
         int t0 = 1;                                        // step t0 - 1 publishes the fold's first column
         if (g > first) t0 = folds[g - 1].t0 + (folds[g].off - folds[g - 1].off) + 1;
@@ -663,6 +671,45 @@ bool sweep_flush_table(const std::vector<SweepFold>& folds, int begin, int end, 
         lprev = L;
     }
     return ok;
+}
+
+// Streamed sources of a node (SweepFold::prod, k_root_gain's merge workgroups): which rows of which producer the fold
+// wavefronts fetch at the head of which macro step -- k_sweep.h fetches rows [0, 8) of a fold's source before step 0 (the first
+// nf folds) or in chunk max((ew' - 1) / 8 - 1, 0) of the fold that has the slot before it, and rows [8 KK + 8, 8 KK + 16) at
+// the head of the fold's chunk KK.  Appended to `tab`: nsteps + 2 step entries (up to two requirements prod << 6 | rows, 12 bits
+// each; a third moves to an earlier step, which only asks for it sooner) | the requirements of step 0.  Returns their count.
+int sweep_gate_table(const std::vector<SweepFold>& folds, int begin, int end, int nsteps, int nf, std::vector<int>& tab) {
+    const int first = (end > begin && folds[begin].t0 == 0) ? begin + 1 : begin;
+    // (step, requirement) pairs, then a counting sort by step: no per-step containers on the one-shot call's host path
+    static thread_local std::vector<std::pair<int, int>> req;
+    req.clear();
+    for (int i = first; i < end; ++i) {
+        const SweepFold& f = folds[i];
+        if (f.prod <= 0) continue;
+        int step = 0;
+        if (i - first >= nf) { const SweepFold& q = folds[i - nf]; step = q.t0 + 8 * std::max((q.ew - 1) / 8 - 1, 0); }
+        req.push_back({std::min(step, nsteps), ((f.prod - 1) << 6) | std::min(f.w, 8)});
+        for (int kk = 0; kk < 8 && 8 * kk < f.ew; ++kk)
+            if (8 * kk + 8 < f.w) req.push_back({std::min(f.t0 + 8 * kk, nsteps), ((f.prod - 1) << 6) | std::min(f.w, 8 * kk + 16)});
+    }
+    std::sort(req.begin(), req.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first > y.first; });   // latest step first
+    const size_t base = tab.size();
+    tab.resize(base + nsteps + 2, 0);
+    std::vector<int> step0;
+    int carry[64], ncarry = 0;                      // requirements pushed to an earlier step (a step takes two)
+    size_t k = 0;
+    for (int t = nsteps + 1; t >= 0; --t) {
+        int mine[2], n = 0;
+        auto take = [&](int r) { if (t == 0) step0.push_back(r); else if (n < 2) mine[n++] = r; else if (ncarry < 64) carry[ncarry++] = r; else step0.push_back(r); };
+        const int nc = ncarry; ncarry = 0;
+        int prev[64];
+        for (int j = 0; j < nc; ++j) prev[j] = carry[j];
+        for (int j = 0; j < nc; ++j) take(prev[j]);
+        while (k < req.size() && req[k].first == t) take(req[k++].second);
+        if (t > 0) tab[base + t] = (n > 0 ? mine[0] : 0) | (n > 1 ? mine[1] << 12 : 0);
+    }
+    tab.insert(tab.end(), step0.begin(), step0.end());
+    return (int)step0.size();
 }
 
 // k_wsweep with PUB: what wavefront 0 publishes at the head of macro step t -- the rows that were final WS_PUB_LAG + 1 steps
@@ -731,7 +778,8 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     const bool xchg = c->xchg;
     size_t off = xchg ? rec_head(c) + (size_t)N * XCHG_SLOT : 0;
     if (xchg) c->h_xflags.assign(N, 0.0);
-    struct Tri { long long src; int lo, w; };
+    struct Tri { long long src; int lo, w; int lvl = -1, idx = -1, ld = 0; };     // (lvl, idx): the merge node that writes it, if one does; ld: its row stride (0: w + 1)
+    const int merge_ld = (c->stream_enabled && mode == 0 && !xchg) ? 64 : 0;      // merge outputs with whole cache lines per row (streamable, k_sweep.h)
     std::vector<Tri> group_tri;                                           // one triangle per group, by first slot
     std::vector<std::vector<SweepNode>> merge_levels;                     // [level] -> nodes of every group at that depth
     int f = 0;
@@ -774,7 +822,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             int wtot = 0, env = 0;
             for (size_t i = b; i < e; ++i) {
                 env = std::max(env, cur[i].w);
-                SweepFold sf{}; sf.src_off = cur[i].src; sf.off = 0; sf.w = cur[i].w; sf.ew = env;
+                SweepFold sf{}; sf.src_off = cur[i].src; sf.off = 0; sf.w = cur[i].w; sf.ew = env; sf.ld = cur[i].ld;
                 c->sfolds.push_back(sf);
                 wtot = std::max(wtot, cur[i].w);
             }
@@ -782,10 +830,10 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             m.wtot = wtot;
             m.nsteps = 0;                                                  // (scheduled per level below: one kernel, one slot count)
             if (dest >= 0) m.out_off = dest;
-            else { m.out_off = (long long)off; off += (size_t)wtot * (wtot + 1); }
+            else { m.ldo = merge_ld; m.out_off = (long long)off; off += (size_t)wtot * (merge_ld ? merge_ld : wtot + 1); }
             if ((int)merge_levels.size() <= level) merge_levels.resize(level + 1);
             merge_levels[level].push_back(m);
-            return Tri{m.out_off, s, wtot};
+            return Tri{m.out_off, s, wtot, level, (int)merge_levels[level].size() - 1, m.ldo};
         };
         int level = 0;
         while (cur.size() > (size_t)(2 * SWEEP_NW)) {
@@ -822,18 +870,29 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         c->snodes.insert(c->snodes.end(), lv.begin(), lv.end());
     }
     c->n_group_merges = (int)c->snodes.size();
+    // the last merge level goes into the root's launch where that launch exists (k_root_gain: 60-column sweeps, eight fold
+    // slots) and its triangles are streamed to the root
+    c->root_streamed = false; c->stream_level = -1; c->h_mflush.clear();
+    {
+        const int last = (int)merge_levels.size() - 1;
+        if (c->stream_enabled && mode == 0 && !xchg && last >= 0 && c->sweep_level_nf[last] == SWEEP_NW && (int)merge_levels[last].size() <= 64 &&
+            group_tri.size() > 1) {
+            c->root_streamed = true; c->stream_level = last;
+        }
+    }
     if (!group_tri.empty()) {
         SweepNode r{};
         r.fold_begin = (int)c->sfolds.size();
         int env = 0;
         for (const Tri& g : group_tri) {
             env = std::max(env, 6 * g.lo + g.w);
-            SweepFold sf{}; sf.src_off = g.src; sf.off = 6 * g.lo; sf.w = g.w; sf.ew = env - 6 * g.lo;
+            SweepFold sf{}; sf.src_off = g.src; sf.off = 6 * g.lo; sf.w = g.w; sf.ew = env - 6 * g.lo; sf.ld = g.ld;
+            if (c->root_streamed && g.lvl == c->stream_level) sf.prod = g.idx + 1;
             c->sfolds.push_back(sf);
         }
         r.fold_end = (int)c->sfolds.size();
         r.wtot = dc;
-        sweep_schedule(c->sfolds, r.fold_begin, r.fold_end, &r.nsteps);
+        sweep_schedule(c->sfolds, r.fold_begin, r.fold_end, &r.nsteps, SWEEP_NW, !c->root_streamed);
         r.out_off = (long long)off;
         c->root_off = off;
         off += (size_t)dc * (dc + 1);
@@ -855,6 +914,29 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         const SweepNode& rn = c->snodes.back();
         for (int g = rn.fold_begin; g < rn.fold_end; ++g) c->root_band = std::max(c->root_band, c->sfolds[g].ew);
         if (mode == 0) sweep_flush_table(c->sfolds, rn.fold_begin, rn.fold_end, rn.nsteps, rn.wtot, 1 << 29, c->h_root_flush);
+        c->root_n_gate = -1;
+        if (c->root_streamed) {
+            c->root_n_gate = sweep_gate_table(c->sfolds, rn.fold_begin, rn.fold_end, rn.nsteps, SWEEP_NW, c->h_root_flush);
+            const auto& lv = c->sweep_levels[c->stream_level];
+            c->h_mflush.assign(lv.second, 0);
+            // (nodes with the same folds -- the same number of triangles of the same widths: most of them -- share one table)
+            std::vector<std::pair<std::vector<int>, int>> seen_shapes;
+            for (int i = 0; i < lv.second; ++i) {
+                const SweepNode& m = c->snodes[lv.first + i];
+                std::vector<int> shape{m.wtot, m.nsteps};
+                for (int g = m.fold_begin; g < m.fold_end; ++g) { shape.push_back(c->sfolds[g].w); shape.push_back(c->sfolds[g].ew); shape.push_back(c->sfolds[g].t0); shape.push_back(c->sfolds[g].off); }
+                int at = -1;
+                for (const auto& sh : seen_shapes) if (sh.first == shape) { at = sh.second; break; }
+                if (at < 0) {
+                    at = (int)c->h_mflush.size() - lv.second;
+                    sweep_flush_table(c->sfolds, m.fold_begin, m.fold_end, m.nsteps, m.wtot, 1 << 29, c->h_mflush);
+                    seen_shapes.push_back({std::move(shape), at});
+                }
+                c->h_mflush[i] = at;
+            }
+            c->mflush_at = (int)c->h_root_flush.size();         // (one upload: the merge nodes' tables ride behind the root's)
+            c->h_root_flush.insert(c->h_root_flush.end(), c->h_mflush.begin(), c->h_mflush.end());
+        }
     }
     if (mode > 0) {
         const int rc = 1 << (mode == 1 ? WS_RC_LOG2_4 : WS_RC_LOG2_6);
@@ -1003,7 +1085,7 @@ void launch_wsweep(msckf_ctx* c, int node_base, int count, int rc_log2, int nste
                        c->stream, a);
 }
 
-int launch_sweeps(msckf_ctx* c, bool with_root = true) {
+int launch_sweeps(msckf_ctx* c, bool with_root = true, int skip_level = -1) {
     if (c->snodes.empty()) return MSCKF_OK;
     if (c->sweep_mode > 0) {
         auto go = [&](int base, int count) {
@@ -1023,6 +1105,7 @@ int launch_sweeps(msckf_ctx* c, bool with_root = true) {
     a.zero = ptr<double>(c->dRbuf) + c->zero_off;          // inside the plan's (zero-initialised, never written) region
     const dim3 block(64 * SWEEP_NW * SWEEP_WPF);
     for (size_t li = 0; li < c->sweep_levels.size(); ++li) {
+        if ((int)li == skip_level) continue;               // (inside k_root_gain's launch, streamed to the root)
         const auto& lv = c->sweep_levels[li];
         int wmax = 0;
         for (int i = lv.first; i < lv.first + lv.second; ++i) wmax = std::max(wmax, c->snodes[i].wtot);
@@ -1064,6 +1147,7 @@ int upload_plan(msckf_ctx* c) {
             if (int rc = ensure(c, c->dRootFlush, c->h_root_flush.size() * 4)) return rc;
             HIPCHK(c, hipMemcpyAsync(c->dRootFlush.p, c->h_root_flush.data(), c->h_root_flush.size() * 4, hipMemcpyHostToDevice, ps));
         }
+
         if (c->sweep_mode > 0 && c->band_plan) {
             if (int rc = ensure(c, c->dFlush, c->h_flush.size() * 4)) return rc;
             if (int rc = ensure(c, c->dFlushOff, c->h_flush_off.size() * 4)) return rc;
@@ -1353,7 +1437,8 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
 bool root_gain_ok(const msckf_ctx* c, int band) {
     return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 2 * SWEEP_NW;      // two tiles on each fold-slot wavefront
 }
-int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const int* flush_tab, const double* Tblk, int band) {
+int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const int* flush_tab, const double* Tblk, int band,
+                         bool with_merges = false) {
     ++c->gs_epoch;
     sa.flush_tab = flush_tab;
     sa.progress = ptr<unsigned long long>(c->dGsProg);
@@ -1363,9 +1448,24 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
     GStreamArgs ga;
     fill_gstream_args(c, ga, Tblk, band, true);
     // (every workgroup asks for more than half of a CU's LDS: one per CU, the sweep has its CU to itself)
-    const size_t lds = std::max<size_t>(std::max(sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps), gstream_lds_doubles(ga.ns, ga.nb2 > 0 ? ga.nb : ga.ncb) * 8),
-                                        (size_t)84 * 1024);
-    hipLaunchKernelGGL((k_root_gain<SWEEP_NW, 2>), dim3(1 + ga.ns), dim3(64 * (SWEEP_NW + 1)), lds, c->stream, sa, ga);
+    size_t lds = std::max<size_t>(std::max(sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps), gstream_lds_doubles(ga.ns, ga.nb2 > 0 ? ga.nb : ga.ncb) * 8),
+                                  (size_t)84 * 1024);
+    SweepArgs ma{};
+    int nm = 0;
+    if (with_merges) {           // the plan's last merge level: workgroups behind the strips, streaming their rows to the root
+        const auto& lv = c->sweep_levels[c->stream_level];
+        nm = lv.second;
+        ma = sa;
+        ma.node_base = lv.first;
+        ma.flush_off = ptr<int>(c->dRootFlush) + c->mflush_at; ma.flush_tab = ptr<int>(c->dRootFlush) + c->mflush_at + nm;
+        ma.progress = ptr<unsigned long long>(c->dMProg); ma.prog_stride = 1; ma.pub_shift = 3;
+        ma.tstamp = nullptr;
+        sa.src_progress = ptr<unsigned long long>(c->dMProg); sa.n_prod = nm; sa.n_gate = c->root_n_gate;
+        lds = std::max(lds, sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps, c->root_n_gate));
+        for (int i = lv.first; i < lv.first + nm; ++i)
+            lds = std::max(lds, sweep_lds_bytes_fl(c->snodes[i].wtot, SWEEP_NW, c->snodes[i].nsteps));
+    }
+    hipLaunchKernelGGL((k_root_gain<SWEEP_NW, 2>), dim3(1 + ga.ns + nm), dim3(64 * (SWEEP_NW + 1)), lds, c->stream, sa, ga, ma);
     HIPCHK(c, hipGetLastError());
     c->gain_blocked = false;
     return MSCKF_OK;
@@ -1480,7 +1580,8 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (c->wide_active && !gs) { c->last_error = "wide tracks need the streamed K6-K7"; return MSCKF_ERR_STATE; }
     const bool beside = gs && c->band_plan && c->root >= 0 &&
                         (c->sweep_mode == 0 ? (!c->h_root_flush.empty() && root_gain_ok(c, c->root_band)) : root_gain_w_ok(c, c->root_band));
-    if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, (with_gain || !c->xchg_planned) && !beside)) != MSCKF_OK) return rc;
+    const bool streamed = beside && c->sweep_mode == 0 && c->root_streamed;     // the last merge level rides in the root's launch
+    if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, (with_gain || !c->xchg_planned) && !beside, streamed ? c->stream_level : -1)) != MSCKF_OK) return rc;
     if (c->F > 0 && c->xchg_planned && !with_gain) {       // the accepted count rides in the export record (double N)
         // (with msckf_set_exchange_mask the shard's gate bytes ride behind it, in input order)
         hipLaunchKernelGGL(k_count_accepted, dim3(1), dim3(256), 0, c->stream, ptr<unsigned char>(c->dAcc), c->F,
@@ -1507,7 +1608,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         // (one launch: the stage boundary K5 | K6-K7 is not observable; the events report the pair under K5 and only what
         //  trails the launch -- nothing -- under K6-K7)
         if ((rc = launch_root_and_gain(c, a, c->snodes.back().wtot, c->snodes.back().nsteps, ptr<int>(c->dRootFlush), root_block(c),
-                                       c->root_band)) != MSCKF_OK) return rc;
+                                       c->root_band, streamed)) != MSCKF_OK) return rc;
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     } else {
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
@@ -1591,6 +1692,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     CK(hipEventCreateWithFlags(&c->ev_state, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming), "hipEventCreate");
     if (const char* e = std::getenv("MSCKF_DIRECT_RESULT")) c->direct_enabled = std::atoi(e) != 0;
+    if (const char* e = std::getenv("MSCKF_ROOT_STREAM")) c->stream_enabled = std::atoi(e) != 0;
     auto lds_attr = [&](const void* f, int bytes, const char* what) {
         CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), what);
     };
@@ -1675,6 +1777,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         const size_t nbm = (size_t)(dc + 15) / 16, nsm = nbm + 1;
         E(c->dGsEx, 2 * nbm * nsm * 256 * 8);          // (two sources of row blocks: the band root and the wide tracks' factor)
         E(c->dGsFlag, (2 * nbm * nsm + 8) * 8, true);
+        E(c->dMProg, 512, true);                       // (progress words of the merge workgroups inside k_root_gain's launch)
         E(c->dGsProg, 512, true);                      // (progress word at 0, k_root_gain's time stamps on a line of their own at byte 256)
     }
     if (rc != MSCKF_OK) { msckf_destroy(c); return rc; }
@@ -1718,7 +1821,7 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dU, &c->dInvd, &c->dK, &c->dB2, &c->dD, &c->dPn, &c->dDx, &c->dCholWork, &c->dStatus,
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
                   &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf, &c->dAssocUV, &c->dAssocRes,
-                  &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dRootFlush, &c->dXRootFlush,
+                  &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dMProg, &c->dMFlush, &c->dRootFlush, &c->dXRootFlush,
                   &c->dGramPart, &c->dGramS, &c->dGramU, &c->dGramL, &c->dGramInvd};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dRawArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
