@@ -536,6 +536,17 @@ __global__ __launch_bounds__(64 * (NF + 1)) void k_root_gain(SweepArgs sp, GStre
     else sweep_body<NF, 1, false, true>(b == 0 ? sp : mp, b == 0 ? 0 : b - 1 - gp.ns);
 }
 
+// ... with merge nodes of NFM > NFR fold slots (groups of 9 - 12 leaf triangles: one round on eleven slots): every workgroup
+// has NFM + 1 wavefronts -- twelve, three per SIMD, which is what the sweep's 146 registers allow --, the root sweeps with its
+// NFR slots and lets the spare ones go, the strips spread their tiles over NFM wavefronts.
+template <int NFR, int NFM, int TPW>
+__global__ __launch_bounds__(64 * (NFM + 1)) void k_root_gain_m(SweepArgs sp, GStreamArgs gp, SweepArgs mp) {
+    const int b = (int)blockIdx.x;
+    if (b == 0) sweep_body<NFR, 1, false, true, NFM - NFR>(sp, 0);
+    else if (b <= gp.ns) gain_stream_body<NFM + 1, NFM, TPW>(gp, b - 1);
+    else sweep_body<NFM, 1, false, true>(mp, b - 1 - gp.ns);
+}
+
 // The same pairing for the ring-buffered sweeps (N > 37 clones or tracks of 11 - 15 slots): k_wsweep's fold wavefronts store
 // the final rows themselves (write-through) and wavefront 0 publishes the count; NF wavefronts per workgroup, the strips'
 // tiles on NF - 1 of them.

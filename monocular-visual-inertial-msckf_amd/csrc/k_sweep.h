@@ -177,11 +177,14 @@ template <int KK> struct STag { static constexpr int value = KK; };
 // hence one instantiation of the step per column of a 16-column period (KK, J).  The four row lanes' partial dots
 // are reduce-scattered with the lane swaps (row r ends up with the dot of column slot r: 6 swaps and 3 additions)
 // and tau goes back the same way.
-template <int NF, int WPF, bool P2P, bool FL>
+// XW: wavefronts of the workgroup between the fold slots and the flusher that have no part in the sweep (a launch whose other
+// workgroups need more wavefronts than this node has fold slots, k_root_gain_m): they help with the prologue and leave.
+template <int NF, int WPF, bool P2P, bool FL, int XW = 0>
 __device__ __forceinline__ void sweep_body(const SweepArgs& p, const int bidx) {
     static_assert(WPF == 1 && !P2P, "one wavefront per fold, one barrier per macro step");
+    static_assert(XW == 0 || FL, "spare wavefronts only in the fused launches");
     constexpr int NW = NF;              // fold wavefronts
-    constexpr int NT = 64 * (NF + (FL ? 1 : 0));   // threads: with FL one more wavefront, the flusher
+    constexpr int NT = 64 * (NF + XW + (FL ? 1 : 0));   // threads: with FL one more wavefront, the flusher
     constexpr int CL = 16;              // column lanes of a fold
     constexpr int CS = 4;               // column slots of a lane
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -228,7 +231,10 @@ __device__ __forceinline__ void sweep_body(const SweepArgs& p, const int bidx) {
         // `vmcnt(M)` with M <= the instructions issued since leaves exactly the younger ones in flight): a `vmcnt(0)` per
         // step would hold the flusher -- and with it the step's barrier -- for a store's round trip.  It joins the
         // barriers bare (s_barrier without the waits of __syncthreads()).
-        if (wv == NF) {
+        if constexpr (XW > 0) {
+            if (wv >= NF && wv < NF + XW) { __syncthreads(); return; }        // (their share of the zeroed R is in place)
+        }
+        if (wv == NF + XW) {
             const int ldo = nd.ldo ? nd.ldo : nd.wtot + 1;
             double* out = p.rbuf + nd.out_off;
             const int wtot = __builtin_amdgcn_readfirstlane(nd.wtot);

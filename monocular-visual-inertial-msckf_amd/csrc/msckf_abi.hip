@@ -610,6 +610,7 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
 //             into the band R = the root block [T | r_n].
 // Returns false when the batch does not qualify (wide tracks, R band over the LDS budget): tree plan then.
 constexpr int SWEEP_NW_BIG = 12;                 // k_sweep group merges of more than SWEEP_NW + 1 triangles: twelve fold slots, one round
+constexpr int SWEEP_NW_MID = 11;                 // ... of up to 12 triangles: eleven, so that the level fits k_root_gain_m's launch (twelve wavefronts with the flusher)
 void sweep_schedule(std::vector<SweepFold>& folds, int begin, int end, int* nsteps, int nf = SWEEP_NW, bool adopt = true) {
     int last = 0;
     if (end > begin && adopt) folds[begin].t0 = 0;         // adopted: copied into the empty R, no elimination steps
@@ -863,7 +864,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         // (groups of 9 - 16 leaf triangles at >= 10000 features: 60 + 9 macro steps instead of two rounds of 61)
         int most = 0;
         for (const SweepNode& m : lv) most = std::max(most, m.fold_end - m.fold_begin - 1);
-        const int nf = (mode == 0 && most > SWEEP_NW) ? SWEEP_NW_BIG : SWEEP_NW;
+        const int nf = (mode == 0 && most > SWEEP_NW) ? ((most <= SWEEP_NW_MID && c->stream_enabled && !xchg) ? SWEEP_NW_MID : SWEEP_NW_BIG) : SWEEP_NW;
         for (SweepNode& m : lv) sweep_schedule(c->sfolds, m.fold_begin, m.fold_end, &m.nsteps, nf);
         c->sweep_levels.push_back({(int)c->snodes.size(), (int)lv.size()});
         c->sweep_level_nf.push_back(nf);
@@ -875,7 +876,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     c->root_streamed = false; c->stream_level = -1; c->h_mflush.clear();
     {
         const int last = (int)merge_levels.size() - 1;
-        if (c->stream_enabled && mode == 0 && !xchg && last >= 0 && c->sweep_level_nf[last] == SWEEP_NW && (int)merge_levels[last].size() <= 64 &&
+        if (c->stream_enabled && mode == 0 && !xchg && last >= 0 && c->sweep_level_nf[last] <= SWEEP_NW_MID && (int)merge_levels[last].size() <= 64 &&
             group_tri.size() > 1) {
             c->root_streamed = true; c->stream_level = last;
         }
@@ -1111,7 +1112,7 @@ int launch_sweeps(msckf_ctx* c, bool with_root = true, int skip_level = -1) {
         for (int i = lv.first; i < lv.first + lv.second; ++i) wmax = std::max(wmax, c->snodes[i].wtot);
         a.node_base = lv.first;
         a.stamp_base = (int)c->nodes.size() + lv.first;
-        if (li < c->sweep_level_nf.size() && c->sweep_level_nf[li] == SWEEP_NW_BIG)
+        if (li < c->sweep_level_nf.size() && c->sweep_level_nf[li] > SWEEP_NW)      // (an eleven-slot schedule runs on twelve slots as well)
             hipLaunchKernelGGL((k_sweep<SWEEP_NW_BIG, 1>), dim3(lv.second), dim3(64 * SWEEP_NW_BIG), sweep_lds_bytes(wmax, SWEEP_NW_BIG, 1), c->stream, a);
         else
             hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(lv.second), block, sweep_lds_bytes(wmax, SWEEP_NW, SWEEP_WPF), c->stream, a);
@@ -1452,6 +1453,7 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
                                   (size_t)84 * 1024);
     SweepArgs ma{};
     int nm = 0;
+    bool mid = false;
     if (with_merges) {           // the plan's last merge level: workgroups behind the strips, streaming their rows to the root
         const auto& lv = c->sweep_levels[c->stream_level];
         nm = lv.second;
@@ -1462,10 +1464,12 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
         ma.tstamp = nullptr;
         sa.src_progress = ptr<unsigned long long>(c->dMProg); sa.n_prod = nm; sa.n_gate = c->root_n_gate;
         lds = std::max(lds, sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps, c->root_n_gate));
+        mid = c->sweep_level_nf[c->stream_level] == SWEEP_NW_MID;
         for (int i = lv.first; i < lv.first + nm; ++i)
-            lds = std::max(lds, sweep_lds_bytes_fl(c->snodes[i].wtot, SWEEP_NW, c->snodes[i].nsteps));
+            lds = std::max(lds, sweep_lds_bytes_fl(c->snodes[i].wtot, mid ? SWEEP_NW_MID : SWEEP_NW, c->snodes[i].nsteps));
     }
-    hipLaunchKernelGGL((k_root_gain<SWEEP_NW, 2>), dim3(1 + ga.ns + nm), dim3(64 * (SWEEP_NW + 1)), lds, c->stream, sa, ga, ma);
+    if (mid) hipLaunchKernelGGL((k_root_gain_m<SWEEP_NW, SWEEP_NW_MID, 2>), dim3(1 + ga.ns + nm), dim3(64 * (SWEEP_NW_MID + 1)), lds, c->stream, sa, ga, ma);
+    else hipLaunchKernelGGL((k_root_gain<SWEEP_NW, 2>), dim3(1 + ga.ns + nm), dim3(64 * (SWEEP_NW + 1)), lds, c->stream, sa, ga, ma);
     HIPCHK(c, hipGetLastError());
     c->gain_blocked = false;
     return MSCKF_OK;
@@ -1719,6 +1723,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW, SWEEP_WPF>), FOLD_LDS_BYTES, "k_sweep LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain<SWEEP_NW, 2>), LDS_MAX_BYTES - 1024, "k_root_gain LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_root_gain_m<SWEEP_NW, SWEEP_NW_MID, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_m LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gram), LDS_MAX_BYTES - 1024, "k_gram LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 3>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
