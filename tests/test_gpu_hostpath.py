@@ -191,3 +191,31 @@ def test_resident_calls_without_waits_keep_their_order(monkeypatch):
         rc = eng.update_problem(qc)                           # ... and the one-shot call's side stream waits for it
         assert np.array_equal(rc.dx, ref_c.dx) and np.array_equal(rc.P_new, ref_c.P_new)
         assert np.array_equal(eng.covariance(), ref_b.P_new)  # (the one-shot call does not commit)
+
+
+@pytest.mark.parametrize("N,F,M,kw", [
+    (30, 2000, 10, {}),                                   # one merge level, eight slots: k_root_gain with merge workgroups
+    (30, 10000, 10, {}),                                  # 9 - 12 triangles per group: k_root_gain_m (eleven slots)
+    (30, 3000, 10, dict(variable_tracks=True, outlier_fraction=0.1, outlier_px=300.0)),
+    (12, 8000, 5, {}),                                    # large groups: two merge levels, only the last one is streamed
+    (20, 500, 8, {}),
+])
+def test_streamed_merges_against_their_own_launch(monkeypatch, N, F, M, kw):
+    """The last merge level inside the root's launch (rows taken as they are published, first triangle folded instead of
+    adopted) against the same level in a launch of its own: the same R up to rounding (reference MSCKF.py:594-598 fixes
+    T_H only up to the signs of its rows), so dx / P+ agree to 1e-10, and the streamed run is bitwise repeatable."""
+    from msckf_amd import synth
+    prob = synth.make_problem(N, F, M, seed=17, **kw)
+    with _engine(monkeypatch, MSCKF_ROOT_STREAM=0) as eng:
+        ref = eng.update_problem(prob)
+    with _engine(monkeypatch) as eng:
+        one = eng.update_problem(prob)
+        assert one.status == ref.status == 0
+        assert np.array_equal(one.accepted, ref.accepted)
+        assert rel_err(one.dx, ref.dx) < 1e-10 and rel_err(one.P_new, ref.P_new) < 1e-10
+        assert np.array_equal(one.P_new, one.P_new.T)
+        eng.load(prob)
+        for _ in range(12):                               # race screen: polling / publication order must not show in the result
+            eng.run()
+            r = eng.result()
+            assert np.array_equal(r.dx, one.dx) and np.array_equal(r.P_new, one.P_new)
