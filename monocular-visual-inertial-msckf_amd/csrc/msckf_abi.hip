@@ -260,6 +260,7 @@ struct msckf_ctx {
     Buf dP, dPout, dCamR, dCamT, dCamR0, dCamT0, dChi2;
     Buf dViewPtr, dObsUV, dObsSlot, dBase, dMvec, dRho, dFmin, dBlkOff, dStack, dRank, dAcc, dGamma, dKeep;
     Buf dNodes, dRbuf, dStamps, dSweepNodes, dSweepFolds;
+    Buf dPlanArena;                       // the plan's tables in one allocation (upload_plan): dNodes, dSweepNodes, dSweepFolds, dRootFlush, dFlush, dFlushOff are views
     Buf dLineBase, dLineDir, dLineConf, dLostFor, dTrackedFor, dSelFlags, dWorld;   // f1 (k_select)
     Buf dY, dS, dL, dU, dInvd, dK, dB2, dD, dPn, dDx, dCholWork, dStatus;
     // host-side plan
@@ -362,6 +363,8 @@ struct msckf_ctx {
     hipStream_t stream_up = nullptr;
     hipEvent_t ev_plan = nullptr;
     hipStream_t plan_stream = nullptr;    // where upload_plan puts its copies (stream, or stream_up in the one-shot call)
+    void* hPlan = nullptr; size_t hPlanCap = 0;   // pinned staging image of the plan tables
+    hipEvent_t ev_plan_up = nullptr; bool plan_staged = false;   // ... its copies are through
     // The one-shot call's P and poses go up on stream_up too, beside the tracks; the main stream waits for ev_state in front of K1.
     hipEvent_t ev_state = nullptr;
     bool state_pending = false;           // ev_state recorded, the main stream has not been told to wait for it yet
@@ -453,6 +456,7 @@ RcclApi& rccl() {
 
 int ensure(msckf_ctx* c, Buf& b, size_t bytes, bool zero = false) {
     if (b.bytes >= bytes && b.p) return MSCKF_OK;
+    if (b.view) { b.p = nullptr; b.bytes = 0; b.view = false; }       // (a view into an arena that is too small: a buffer of its own)
     if (b.p) HIPCHK(c, hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
@@ -1130,33 +1134,48 @@ int launch_sweeps(msckf_ctx* c, bool with_root = true, int skip_level = -1) {
 // node / fold tables of the current plan -> HBM (async on the context's stream)
 int upload_plan(msckf_ctx* c) {
     hipStream_t ps = c->plan_stream ? c->plan_stream : c->stream;
-    if (int rc = ensure(c, c->dNodes, std::max<size_t>(c->nodes.size(), 1) * sizeof(FoldNode))) return rc;
-    if (!c->nodes.empty())
-        HIPCHK(c, hipMemcpyAsync(c->dNodes.p, c->nodes.data(), c->nodes.size() * sizeof(FoldNode), hipMemcpyHostToDevice,
-                                 ps));
+    // The tables (leaf nodes, sweep nodes and folds, the flush / gate tables) go up as ONE image: pinned staging -> one arena in
+    // HBM, the buffers the launches name are views into it.  (As four to six copies they cost the host ~5 us each inside the
+    // window of K1-K4, and the device a blit kernel each.)  The staging image is reused: wait for the previous plan's copy
+    // first (an event that has long passed by then).
+    size_t need = 0;
+    auto room = [&](size_t bytes) { const size_t o = need; need += (std::max<size_t>(bytes, 64) + 255) & ~(size_t)255; return o; };
+    const size_t b_nodes = c->nodes.size() * sizeof(FoldNode), b_sn = c->snodes.size() * sizeof(SweepNode), b_sf = c->sfolds.size() * sizeof(SweepFold);
+    const size_t b_rf = c->h_root_flush.size() * 4, b_fl = c->h_flush.size() * 4, b_fo = c->h_flush_off.size() * 4;
+    const size_t o_nodes = room(b_nodes), o_sn = room(b_sn), o_sf = room(b_sf), o_rf = room(b_rf), o_fl = room(b_fl), o_fo = room(b_fo);
+    if (c->plan_staged) { HIPCHK(c, hipEventSynchronize(c->ev_plan_up)); c->plan_staged = false; }
+    if (c->hPlanCap < need) {
+        if (c->hPlan) HIPCHK(c, hipHostFree(c->hPlan));
+        c->hPlan = nullptr; c->hPlanCap = 0;
+        HIPCHK(c, hipHostMalloc(&c->hPlan, 2 * need + 4096));
+        c->hPlanCap = 2 * need + 4096;
+    }
+    // (buffers of their own from a merge plan that outgrew the arena: released before they become views again)
+    for (Buf* bb : {&c->dNodes, &c->dSweepNodes, &c->dSweepFolds, &c->dRootFlush, &c->dFlush, &c->dFlushOff})
+        if (bb->p && !bb->view) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(bb->p)); bb->p = nullptr; bb->bytes = 0; }
+    if (c->dPlanArena.bytes < need) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));        // (kernels of an earlier run may still read the old arena)
+        if (int rc = ensure(c, c->dPlanArena, 2 * need)) return rc;
+    }
+    char* hp = static_cast<char*>(c->hPlan);
+    if (b_nodes) std::memcpy(hp + o_nodes, c->nodes.data(), b_nodes);
+    if (b_sn) std::memcpy(hp + o_sn, c->snodes.data(), b_sn);
+    if (b_sf) std::memcpy(hp + o_sf, c->sfolds.data(), b_sf);
+    if (b_rf) std::memcpy(hp + o_rf, c->h_root_flush.data(), b_rf);
+    if (b_fl) std::memcpy(hp + o_fl, c->h_flush.data(), b_fl);
+    if (b_fo) std::memcpy(hp + o_fo, c->h_flush_off.data(), b_fo);
+    HIPCHK(c, hipMemcpyAsync(c->dPlanArena.p, hp, need, hipMemcpyHostToDevice, ps));
+    set_view(c->dNodes, c->dPlanArena.p, o_nodes, std::max<size_t>(b_nodes, 64));
+    set_view(c->dSweepNodes, c->dPlanArena.p, o_sn, std::max<size_t>(b_sn, 64));
+    set_view(c->dSweepFolds, c->dPlanArena.p, o_sf, std::max<size_t>(b_sf, 64));
+    set_view(c->dRootFlush, c->dPlanArena.p, o_rf, std::max<size_t>(b_rf, 64));
+    set_view(c->dFlush, c->dPlanArena.p, o_fl, std::max<size_t>(b_fl, 64));
+    set_view(c->dFlushOff, c->dPlanArena.p, o_fo, std::max<size_t>(b_fo, 64));
     c->x_plan_valid = false;               // the sweep tables are rewritten: a cached merge plan behind them is gone
     if (c->xchg_planned)                   // (behind the workspace memset of set_features / replan, same stream)
         HIPCHK(c, hipMemcpyAsync(c->dRbuf.p, c->h_xflags.data(), c->h_xflags.size() * 8, hipMemcpyHostToDevice, ps));
-    if (!c->snodes.empty()) {
-        if (int rc = ensure(c, c->dSweepNodes, c->snodes.size() * sizeof(SweepNode))) return rc;
-        if (int rc = ensure(c, c->dSweepFolds, c->sfolds.size() * sizeof(SweepFold))) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->dSweepNodes.p, c->snodes.data(), c->snodes.size() * sizeof(SweepNode),
-                                 hipMemcpyHostToDevice, ps));
-        HIPCHK(c, hipMemcpyAsync(c->dSweepFolds.p, c->sfolds.data(), c->sfolds.size() * sizeof(SweepFold),
-                                 hipMemcpyHostToDevice, ps));
-        if (c->band_plan && !c->h_root_flush.empty()) {
-            if (int rc = ensure(c, c->dRootFlush, c->h_root_flush.size() * 4)) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->dRootFlush.p, c->h_root_flush.data(), c->h_root_flush.size() * 4, hipMemcpyHostToDevice, ps));
-        }
-
-        if (c->sweep_mode > 0 && c->band_plan) {
-            if (int rc = ensure(c, c->dFlush, c->h_flush.size() * 4)) return rc;
-            if (int rc = ensure(c, c->dFlushOff, c->h_flush_off.size() * 4)) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->dFlush.p, c->h_flush.data(), c->h_flush.size() * 4, hipMemcpyHostToDevice, ps));
-            HIPCHK(c, hipMemcpyAsync(c->dFlushOff.p, c->h_flush_off.data(), c->h_flush_off.size() * 4, hipMemcpyHostToDevice,
-                                     ps));
-        }
-    }
+    HIPCHK(c, hipEventRecord(c->ev_plan_up, ps));
+    c->plan_staged = true;
     return MSCKF_OK;
 }
 
@@ -1693,6 +1712,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_wfeat, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_plan_up, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_state, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_gate, hipEventDisableTiming), "hipEventCreate");
     if (const char* e = std::getenv("MSCKF_DIRECT_RESULT")) c->direct_enabled = std::atoi(e) != 0;
@@ -1829,13 +1849,15 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dMProg, &c->dMFlush, &c->dRootFlush, &c->dXRootFlush,
                   &c->dGramPart, &c->dGramS, &c->dGramU, &c->dGramL, &c->dGramInvd};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
-    for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dRawArena, &c->dResArena, &c->dGateArena}) if (b->p) (void)hipFree(b->p);
+    for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dRawArena, &c->dResArena, &c->dGateArena, &c->dPlanArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_wfeat) (void)hipEventDestroy(c->ev_wfeat);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
+    if (c->ev_plan_up) (void)hipEventDestroy(c->ev_plan_up);
+    if (c->hPlan) (void)hipHostFree(c->hPlan);
     if (c->ev_state) (void)hipEventDestroy(c->ev_state);
     if (c->ev_gate) (void)hipEventDestroy(c->ev_gate);
     if (c->stream_up) (void)hipStreamDestroy(c->stream_up);
