@@ -3,10 +3,11 @@
 // the engine's kernels want the tracks sorted by (class, first slot, last slot) (k_lsweep's leaves, the per-class launches
 // of k_feature).  Until round 3 the host gathered every array into that order before the upload (29 us of the call at 2000
 // tracks, 155 us at 10000, all of it in front of K1-K4).  Now the caller's arrays stay AS THEY ARE: the observations (60 % of
-// the bytes) cross PCIe by DMA while the host is still validating and sorting, everything else sits in the pinned image and
-// is read from there by this kernel (zero-copy: no copy command, and none of the ~9 us a copy command waits behind its
-// predecessor), which writes the sorted image the other kernels read.  The host's sort contributes one 24-byte record per
-// track.  An HBM / PCIe-bound permutation, one 32-lane group per track.
+// the bytes) cross PCIe by DMA while the host is still validating and sorting; the small arrays follow by DMA (large batches)
+// or through k_stage, a copy kernel that reads the pinned image in whole cache lines (small ones: no copy command, and none
+// of the ~9 us a copy command waits behind its predecessor); the host's sort contributes one 24-byte record per track, which
+// this kernel reads where it lies (pinned host memory for small batches).  It writes the sorted image the other kernels
+// read: an HBM-bound permutation, one 32-lane group per track.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "k_lsweep.h"
@@ -39,13 +40,26 @@ struct GatherArgs {
 
 constexpr int GATHER_THREADS = 256;
 
+// The small arrays of a small batch, pinned host image -> HBM in whole cache lines (a few thousand tracks: cheaper than a copy
+// command and the ~9 us it waits behind its predecessor, and 5x fewer PCIe requests than k_gather's scattered reads of them).
+__global__ __launch_bounds__(256) void k_stage(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(GATHER_THREADS) void k_gather(GatherArgs p) {
     __shared__ unsigned long long scol[GATHER_THREADS / 32][2];
     const int t = threadIdx.x, grp = t >> 5, v = t & 31;
     const int s = blockIdx.x * (GATHER_THREADS / 32) + grp;
     const bool live = s < p.F;
+    // (the records may sit in pinned host memory: lanes 0 - 2 of a group fetch one 8-byte word each, so that the two groups of
+    //  a wavefront make ONE request for their 48 contiguous bytes instead of 64 lanes asking for the same 24)
     GatherRec r{0, 0, 0, 0, 0};
-    if (live) r = p.rec[s];
+    {
+        long long w = 0;
+        if (live && v < 3) w = reinterpret_cast<const long long*>(p.rec + s)[v];
+        const long long w0 = __shfl(w, 0, 32), w1 = __shfl(w, 1, 32), w2 = __shfl(w, 2, 32);
+        r.f = (int)w0; r.a = (int)(w0 >> 32); r.M = (int)w1; r.o = (int)(w1 >> 32); r.blk = w2;
+    }
     const int f = r.f, a = r.a, M = r.M, o = r.o;
     int sl = 1 << 30;
     double hv = 0.0;

@@ -1978,12 +1978,12 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->hFeatCap = pin_bytes + pin_bytes / 2;
     }
     if (int rca = ensure(c, c->dFeatArena, feat_bytes)) return rca;
-    // small batches: k_gather reads everything but the observations from the pinned image (zero-copy: 5 PCIe reads per track,
-    // cheaper than two more copy commands up to a few thousand tracks); large ones: DMA, beside the host's sort (measured at
-    // 10000 tracks: zero-copy 620 us per call, DMA 578)
+    // small batches: the small arrays reach HBM through a copy KERNEL reading the pinned image (k_stage) and k_gather reads the
+    // sort's records from it (zero-copy) -- no copy command but the observations', none of the ~9 us each one waits behind its
+    // predecessor; large ones: DMA, beside the host's sort (measured at 10000 tracks: zero-copy 620 us per call, DMA 578)
     static const int zc_max = [] { const char* e = std::getenv("MSCKF_ZEROCOPY_MAX"); return e ? std::atoi(e) : 4096; }();
     const bool zc = F <= zc_max;
-    if (int rca = ensure(c, c->dRawArena, zc ? (size_t)sumM * 16 : pin_bytes)) return rca;
+    if (int rca = ensure(c, c->dRawArena, pin_bytes)) return rca;
     char* hb = static_cast<char*>(c->hFeat);
     char* draw = static_cast<char*>(c->dRawArena.p);
     const bool par = c->pool && F >= host_par_min();
@@ -2041,6 +2041,11 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         Mmax = std::max(Mmax_cls[0], std::max(Mmax_cls[1], Mmax_cls[2]));
     }
     if (!zc) HIPCHK(c, hipMemcpyAsync(draw + r_base, hb + r_base, raw_bytes - r_base, hipMemcpyHostToDevice, c->stream));
+    else {
+        const size_t n16 = (raw_bytes - r_base) / 16;           // (r_base and raw_bytes are multiples of 16)
+        hipLaunchKernelGGL(k_stage, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, c->stream,
+                           reinterpret_cast<const uint4*>(hb + r_base), reinterpret_cast<uint4*>(draw + r_base), n16);
+    }
     const double tv = now_us();
     if (c->n_chi2 <= 2 * Mmax) { (void)hipStreamSynchronize(c->stream); return MSCKF_ERR_ARG; }
     c->F = F; c->sumM = sumM; c->Mmax = Mmax;            // validated: commit the batch size
@@ -2108,11 +2113,10 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     if (c->oneshot) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     {
         GatherArgs g;
-        const char* src = zc ? hb : draw;
         g.uv_in = reinterpret_cast<const double*>(draw);
-        g.slot_in = reinterpret_cast<const int*>(src + r_slot); g.base_in = reinterpret_cast<const double*>(src + r_base);
-        g.m_in = reinterpret_cast<const double*>(src + r_m); g.rho_in = reinterpret_cast<const double*>(src + r_rho);
-        g.rec = reinterpret_cast<const GatherRec*>(src + raw_bytes);
+        g.slot_in = reinterpret_cast<const int*>(draw + r_slot); g.base_in = reinterpret_cast<const double*>(draw + r_base);
+        g.m_in = reinterpret_cast<const double*>(draw + r_m); g.rho_in = reinterpret_cast<const double*>(draw + r_rho);
+        g.rec = reinterpret_cast<const GatherRec*>((zc ? hb : draw) + raw_bytes);
         g.uv = ptr<double>(c->dObsUV); g.base = ptr<double>(c->dBase); g.m = ptr<double>(c->dMvec); g.rho = ptr<double>(c->dRho);
         g.slot = ptr<int>(c->dObsSlot); g.fmin = ptr<int>(c->dFmin); g.view = ptr<int>(c->dViewPtr); g.perm = ptr<int>(c->dPerm);
         g.blk = ptr<long long>(c->dBlkOff); g.info = ptr<FeatInfo>(c->dFeatInfo);
