@@ -271,11 +271,11 @@ def main():
                                         "device_pipeline": us_step,
                                         "host_sort_plan": head["host_prep_us"], "h2d": head["h2d_us"], "d2h": head["d2h_us"]},
     }
-    k5_names = ("k_lsweep<", "k_sweep<", "k_wsweep<", "k_root_gain<")
+    k5_names = ("k_lsweep<", "k_sweep<", "k_wsweep<", "k_root_gain<", "k_root_gain_m<")
     ex = pmc_executed_flops(k5_names)
     line["roofline"] = {
-        "kernel": "K5 QR compression: k_lsweep leaves + k_sweep group merges + the root sweep (%d launches per update; the root's "
-                  "launch, k_root_gain, also holds K6-K7, whose trailing part is not counted here)" % n_lv,
+        "kernel": "K5 QR compression: k_lsweep leaves + group merges + the root sweep (%d launches per update; the last merge "
+                  "level and the root share k_root_gain's launch, which also holds K6-K7, whose trailing part is not counted here)" % n_lv,
         "bound": "fp64_valu", "unit": "TFLOP/s",
         "achieved": costs["flops_B"] / (us_qr * 1e-6) / 1e12,
         "peak": FP64_PEAK_TFLOPS,
