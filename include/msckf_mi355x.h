@@ -26,10 +26,13 @@
  *     F == 0: dx = 0, P_out = P, mirrors the early returns MSCKF.py:584-585,
  *     :591-592), < 0 = error (see msckf_strerror).
  *   - one context per host thread; calls on a context are serialised.
- *   - msckf_create starts a few host worker threads per context (CPU work only, no HIP calls: the validation / gather
- *     loops and the covariance staging copies of msckf_update are split over them; pinned next to the creating
- *     thread).  Environment: MSCKF_HOST_THREADS (default 3, 0 = none), MSCKF_HOST_PAR_MIN (smallest batch that is
+ *   - msckf_create starts a few host worker threads per context (CPU work only, no HIP calls: the copies into the
+ *     pinned upload image, the validation loop and the covariance staging copies of msckf_update are split over them;
+ *     pinned next to the creating thread).  Environment: MSCKF_HOST_THREADS (default 3, 0 = none), MSCKF_HOST_PAR_MIN (smallest batch that is
  *     split, default 1024 features), MSCKF_HOST_SPIN_US (how long idle workers poll before they sleep, default 1000).
+ *   - waiting: msckf_update, msckf_get_result, msckf_get_covariance and msckf_sync return with the device drained of
+ *     everything their results depend on; msckf_set_features, msckf_set_poses, msckf_commit_covariance and msckf_run
+ *     leave their work in the context's stream (host arrays passed in are copied before the call returns).
  *   - tuning switches of the K5 plan (diagnostics; the defaults are the measured best): MSCKF_LEAF_TARGET (leaf workgroups
  *     aimed at per batch, default 240), MSCKF_LS_BIG_BATCH (from this many features on the 60-column leaves run twelve
  *     wavefronts, default 4000), MSCKF_LS_TALL (90-column leaves with 56-row blocks, default 1; 0 = 32-row blocks).
