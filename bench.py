@@ -178,7 +178,7 @@ def time_config(N, F, M, steps, warmup, dtype="f64", device=0, host_reps=10, rot
         "roofline_frac_pipeline_host_inclusive_canonical": costs["t_roof_s"] / host_s,
         "stages_us": {"feature_K1_K4": stages[0], "qr_K5": stages[1], "gain_K6_K7": stages[2]},
         "features": int(F), "accepted": int(res.accepted.sum()), "stacked_rows": int(one.stats.get("stacked_rows", 0)),
-        "k5_launches": int(one.stats.get("n_levels", 0)), "leaves": int(one.stats.get("n_leaves", 0)),
+        "k5_launches": int(one.stats.get("k5_launches", 0) or one.stats.get("n_levels", 0)), "leaves": int(one.stats.get("n_leaves", 0)),
         "host_prep_us": one.stats.get("us_host_prep"), "h2d_us": one.stats.get("us_h2d"), "d2h_us": one.stats.get("us_d2h"),
         # every fraction below prices the CANONICAL bytes / flops of SURVEY 8(d) (the reference's dense formulation) against the
         # measured time; the kernels execute far fewer flops than that (band QR, D - V Z gate), so a stage fraction can pass 1

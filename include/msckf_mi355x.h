@@ -102,9 +102,9 @@ typedef struct msckf_stats {
     int32_t n_rejected;             /* reference counter number_of_residuals_discarded_for_gasting_test, MSCKF.py:578 */
     int32_t stacked_rows;           /* m = sum of q_j over accepted features                */
     int32_t n_leaves;
-    int32_t n_levels;               /* K5 launches (tree levels, or leaves + group merges + root sweep) */
+    int32_t n_levels;               /* levels of the K5 plan (tree levels, or leaves + group merge levels + root sweep) */
     int32_t not_spd;                /* per-feature gate matrices that were not SPD          */
-    int32_t reserved;
+    int32_t k5_launches;            /* launches they took in the last run (a merge level streamed to the root rides in its launch) */
     float us_total;                 /* whole device pipeline                                */
     float us_feature;               /* K1-K3 kernel                                         */
     float us_qr;                    /* K5 tree                                              */

@@ -45,7 +45,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_features", C.c_int32), ("n_accepted", C.c_int32), ("n_rejected", C.c_int32),
                 ("stacked_rows", C.c_int32), ("n_leaves", C.c_int32), ("n_levels", C.c_int32),
-                ("not_spd", C.c_int32), ("reserved", C.c_int32),
+                ("not_spd", C.c_int32), ("k5_launches", C.c_int32),
                 ("us_total", C.c_float), ("us_feature", C.c_float), ("us_qr", C.c_float), ("us_gain", C.c_float),
                 ("us_host_prep", C.c_float), ("us_h2d", C.c_float), ("us_d2h", C.c_float), ("reserved2", C.c_float)]
 

@@ -2332,8 +2332,8 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
         st->n_rejected = std::max(0, c->F - counters[3] - n_acc - counters[2]);
         st->stacked_rows = counters[1]; st->not_spd = counters[2];
         st->n_leaves = c->n_leaves;
-        st->n_levels = (int)c->levels.size() + (c->band_plan ? (int)c->sweep_levels.size() + 1 : 0)
-                       - ((c->band_plan && c->gs_fused_last && c->sweep_mode == 0 && c->root_streamed) ? 1 : 0);   // (launches: a streamed merge level rides in the root's)
+        st->n_levels = (int)c->levels.size() + (c->band_plan ? (int)c->sweep_levels.size() + 1 : 0);
+        st->k5_launches = st->n_levels - ((c->band_plan && c->gs_fused_last && c->sweep_mode == 0 && c->root_streamed) ? 1 : 0);   // (a streamed merge level rides in the root's launch)
         st->us_total = c->us_total; st->us_feature = c->us_stage[0]; st->us_qr = c->us_stage[1];
         st->us_gain = c->us_stage[2];
         st->us_host_prep = c->us_host_prep; st->us_h2d = c->us_h2d; st->us_d2h = c->us_d2h;
