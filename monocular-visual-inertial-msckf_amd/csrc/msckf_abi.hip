@@ -390,6 +390,7 @@ struct msckf_ctx {
     int stream_level = -1;                // index of that level in sweep_levels
     std::vector<int> h_mflush;            // [n offsets | the nodes' flush tables]
     int mflush_at = 0;                    // where h_mflush sits in the uploaded h_root_flush
+    bool x_streamed = false; int x_root_n_gate = -1, x_mflush_at = 0;   // the same for rank 0's merge plan (run_merge_groups)
     int root_n_gate = -1;                 // step-0 requirements behind the root's flush + gate tables (sweep_gate_table), -1: no gate table
     Buf dMFlush, dMProg;                  // ... on the device; the merge nodes' progress words (64)
     bool stream_enabled = true;           // MSCKF_ROOT_STREAM=0: the level keeps its own launch
@@ -1457,8 +1458,11 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
 bool root_gain_ok(const msckf_ctx* c, int band) {
     return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 2 * SWEEP_NW;      // two tiles on each fold-slot wavefront
 }
+// A merge level that rides in the root's launch (k_gstream.h): its nodes, where their flush tables sit on the device
+// ([count offsets | tables]) and the root's step-0 requirement count behind its own tables (sweep_gate_table).
+struct MergeRide { int node_base, count, nf, n_gate; const int* flush; size_t lds; };    // lds: what its largest node asks for
 int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const int* flush_tab, const double* Tblk, int band,
-                         bool with_merges = false) {
+                         const MergeRide* ride = nullptr) {
     ++c->gs_epoch;
     sa.flush_tab = flush_tab;
     sa.progress = ptr<unsigned long long>(c->dGsProg);
@@ -1473,19 +1477,17 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
     SweepArgs ma{};
     int nm = 0;
     bool mid = false;
-    if (with_merges) {           // the plan's last merge level: workgroups behind the strips, streaming their rows to the root
-        const auto& lv = c->sweep_levels[c->stream_level];
-        nm = lv.second;
+    if (ride) {                  // a merge level: workgroups behind the strips, streaming their rows to the root
+        nm = ride->count;
         ma = sa;
-        ma.node_base = lv.first;
-        ma.flush_off = ptr<int>(c->dRootFlush) + c->mflush_at; ma.flush_tab = ptr<int>(c->dRootFlush) + c->mflush_at + nm;
+        ma.node_base = ride->node_base;
+        ma.flush_off = ride->flush; ma.flush_tab = ride->flush + nm;
         ma.progress = ptr<unsigned long long>(c->dMProg); ma.prog_stride = 1; ma.pub_shift = 3;
         ma.tstamp = nullptr;
-        sa.src_progress = ptr<unsigned long long>(c->dMProg); sa.n_prod = nm; sa.n_gate = c->root_n_gate;
-        lds = std::max(lds, sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps, c->root_n_gate));
-        mid = c->sweep_level_nf[c->stream_level] == SWEEP_NW_MID;
-        for (int i = lv.first; i < lv.first + nm; ++i)
-            lds = std::max(lds, sweep_lds_bytes_fl(c->snodes[i].wtot, mid ? SWEEP_NW_MID : SWEEP_NW, c->snodes[i].nsteps));
+        sa.src_progress = ptr<unsigned long long>(c->dMProg); sa.n_prod = nm; sa.n_gate = ride->n_gate;
+        lds = std::max(lds, sweep_lds_bytes_fl(wtot, SWEEP_NW, nsteps, ride->n_gate));
+        mid = ride->nf == SWEEP_NW_MID;
+        lds = std::max(lds, ride->lds);
     }
     if (mid) hipLaunchKernelGGL((k_root_gain_m<SWEEP_NW, SWEEP_NW_MID, 2>), dim3(1 + ga.ns + nm), dim3(64 * (SWEEP_NW_MID + 1)), lds, c->stream, sa, ga, ma);
     else hipLaunchKernelGGL((k_root_gain<SWEEP_NW, 2>), dim3(1 + ga.ns + nm), dim3(64 * (SWEEP_NW + 1)), lds, c->stream, sa, ga, ma);
@@ -1630,8 +1632,15 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         a.node_base = c->n_group_merges;
         // (one launch: the stage boundary K5 | K6-K7 is not observable; the events report the pair under K5 and only what
         //  trails the launch -- nothing -- under K6-K7)
+        MergeRide ride{};
+        if (streamed) {
+            const auto& lv = c->sweep_levels[c->stream_level];
+            ride = MergeRide{lv.first, lv.second, c->sweep_level_nf[c->stream_level], c->root_n_gate, ptr<int>(c->dRootFlush) + c->mflush_at, 0};
+            for (int i = lv.first; i < lv.first + lv.second; ++i)
+                ride.lds = std::max(ride.lds, sweep_lds_bytes_fl(c->snodes[i].wtot, ride.nf, c->snodes[i].nsteps));
+        }
         if ((rc = launch_root_and_gain(c, a, c->snodes.back().wtot, c->snodes.back().nsteps, ptr<int>(c->dRootFlush), root_block(c),
-                                       c->root_band, streamed)) != MSCKF_OK) return rc;
+                                       c->root_band, streamed ? &ride : nullptr)) != MSCKF_OK) return rc;
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
     } else {
         if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[2], c->stream));
@@ -2915,7 +2924,10 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     const int XW = xchg_w(xmode);
     const size_t rec = msckf_group_record_doubles(c);
     // workspace behind the local plan: records | merged group triangles | root block | zero words
-    const size_t o_rec = c->gather_off, o_mrg = o_rec + (size_t)n_rec * rec, o_root = o_mrg + (size_t)N * XCHG_SLOT;
+    // (60-column plans: merged triangles with rows of 64 doubles, streamable to the root inside its launch -- k_sweep.h)
+    const bool xs = xmode == 0 && c->stream_enabled;
+    const size_t MSLOT = xs ? (size_t)SWEEP_MAX_W * 64 : XCHG_SLOT;
+    const size_t o_rec = c->gather_off, o_mrg = o_rec + (size_t)n_rec * rec, o_root = o_mrg + (size_t)N * MSLOT;
     const size_t o_zero = o_root + (size_t)dc * (dc + 1), o_end = o_zero + 16;
     const size_t need = (o_end + 16) * 8;
     if (c->dRbuf.bytes < need) {          // grow, keeping the local plan's blocks
@@ -2966,7 +2978,7 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     if (!reuse) {
         c->x_snodes.clear(); c->x_sfolds.clear();
         const int fold_base = (int)c->sfolds.size();      // the tables sit behind the local plan's
-        struct Tri { long long src; int lo, w; };
+        struct Tri { long long src; int lo, w; int prod = 0, ld = 0; };
         std::vector<Tri> groups;
         std::vector<SweepFold>& fl = c->x_sfolds;
         for (int s0 = 0; s0 < N; ++s0) {
@@ -2983,11 +2995,14 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
             m.fold_end = fold_base + (int)fl.size();
             m.wtot = w;
             sweep_schedule(fl, b, (int)fl.size(), &m.nsteps);
-            m.out_off = (long long)(o_mrg + (size_t)s0 * XCHG_SLOT);
+            m.out_off = (long long)(o_mrg + (size_t)s0 * MSLOT);
+            m.ldo = xs ? 64 : 0;
             c->x_snodes.push_back(m);
-            groups.push_back({m.out_off, s0, w});
+            groups.push_back({m.out_off, s0, w, (int)c->x_snodes.size(), m.ldo});
         }
         c->x_n_merges = (int)c->x_snodes.size();
+        // the merge level rides in the root's launch and streams its rows to the root (as the local plan's last level does)
+        c->x_streamed = xs && c->x_n_merges >= 1 && c->x_n_merges <= 64 && groups.size() > 1 && root_gain_ok(c, XW);
         if (!groups.empty()) {
             SweepNode r{};
             r.fold_begin = fold_base + (int)fl.size();
@@ -2995,16 +3010,29 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
             int env = 0;
             for (const Tri& g : groups) {
                 env = std::max(env, 6 * g.lo + g.w);
-                SweepFold sf{}; sf.src_off = g.src; sf.off = 6 * g.lo; sf.w = g.w; sf.ew = env - 6 * g.lo;
+                SweepFold sf{}; sf.src_off = g.src; sf.off = 6 * g.lo; sf.w = g.w; sf.ew = env - 6 * g.lo; sf.ld = g.ld;
+                if (c->x_streamed) sf.prod = g.prod;
                 fl.push_back(sf);
             }
             r.fold_end = fold_base + (int)fl.size();
             r.wtot = dc;
-            sweep_schedule(fl, b, (int)fl.size(), &r.nsteps);
+            sweep_schedule(fl, b, (int)fl.size(), &r.nsteps, SWEEP_NW, !c->x_streamed);
             r.out_off = (long long)o_root;
             c->x_snodes.push_back(r);
             c->x_root_flush.clear();
             if (xmode == 0) sweep_flush_table(fl, b, (int)fl.size(), r.nsteps, r.wtot, 1 << 29, c->x_root_flush);
+            c->x_root_n_gate = -1;
+            if (c->x_streamed) {
+                c->x_root_n_gate = sweep_gate_table(fl, b, (int)fl.size(), r.nsteps, SWEEP_NW, c->x_root_flush);
+                c->x_mflush_at = (int)c->x_root_flush.size();
+                const int nm = c->x_n_merges;
+                c->x_root_flush.resize(c->x_root_flush.size() + nm, 0);
+                for (int i = 0; i < nm; ++i) {
+                    const SweepNode& m = c->x_snodes[i];
+                    c->x_root_flush[c->x_mflush_at + i] = (int)c->x_root_flush.size() - c->x_mflush_at - nm;
+                    sweep_flush_table(fl, m.fold_begin - fold_base, m.fold_end - fold_base, m.nsteps, m.wtot, 1 << 29, c->x_root_flush);
+                }
+            }
         }
         // tables: local plan first (its launches may follow this call), the merge plan behind it
         std::vector<SweepNode> all_n(c->snodes);
@@ -3089,15 +3117,23 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
     a.stamps = nullptr;
     a.zero = rb + c->x_zero_off;
     const dim3 block(64 * SWEEP_NW * SWEEP_WPF);
-    if (c->x_n_merges > 0) {
+    const bool fused = root_gain_ok(c, XW) && !c->x_root_flush.empty();
+    const bool ride_on = fused && c->x_streamed;
+    if (c->x_n_merges > 0 && !ride_on) {
         a.node_base = nb;
         hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF>), dim3(c->x_n_merges), block,
                            sweep_lds_bytes(SWEEP_MAX_W, SWEEP_NW, SWEEP_WPF), c->stream, a);
     }
     a.node_base = nb + c->x_n_merges;
     int rc;
-    if (root_gain_ok(c, XW) && !c->x_root_flush.empty()) {
-        rc = launch_root_and_gain(c, a, dc, c->x_snodes.back().nsteps, ptr<int>(c->dXRootFlush), rb + c->x_root_off, XW);
+    if (fused) {
+        MergeRide ride{};
+        if (ride_on) {
+            ride = MergeRide{nb, c->x_n_merges, SWEEP_NW, c->x_root_n_gate, ptr<int>(c->dXRootFlush) + c->x_mflush_at, 0};
+            for (int i = 0; i < c->x_n_merges; ++i)
+                ride.lds = std::max(ride.lds, sweep_lds_bytes_fl(c->x_snodes[i].wtot, SWEEP_NW, c->x_snodes[i].nsteps));
+        }
+        rc = launch_root_and_gain(c, a, dc, c->x_snodes.back().nsteps, ptr<int>(c->dXRootFlush), rb + c->x_root_off, XW, ride_on ? &ride : nullptr);
     } else {
         hipLaunchKernelGGL((k_sweep<SWEEP_NW, SWEEP_WPF, SWEEP_P2P>), dim3(1), block, sweep_lds_bytes(dc, SWEEP_NW, SWEEP_WPF), c->stream, a);
         HIPCHK(c, hipGetLastError());
