@@ -202,9 +202,16 @@ def i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+_c_char, _addressof = C.c_char, C.addressof
+
+
 def dptr(a):
-    # (the address straight from the array interface: `a.ctypes` builds a helper object per call, ~1 us x 17 arguments)
-    return a.__array_interface__["data"][0]
+    # (the address through the buffer protocol: 0.3 us; `a.__array_interface__` builds a dict per call, 0.9 us, `a.ctypes` a helper
+    #  object, 1 us -- times 17 arguments of the drop-in call.  Read-only and empty arrays do not export a writable buffer.)
+    try:
+        return _addressof(_c_char.from_buffer(a))
+    except (TypeError, ValueError):
+        return a.__array_interface__["data"][0]
 
 
 iptr = dptr

@@ -159,13 +159,14 @@ class UpdateEngine:
 
     @classmethod
     def _pack(cls, prob: UpdateProblem) -> dict:
+        # (C-contiguous float64 / int32 arrays whatever their shape: the library takes addresses)
         return dict(
-            P=_ffi.f64(prob.P), cam_R=_ffi.f64(prob.cam_R).reshape(-1), cam_t=_ffi.f64(prob.cam_t).reshape(-1),
-            cam_R0=_ffi.f64(prob.cam_R0).reshape(-1), cam_t0=_ffi.f64(prob.cam_t0).reshape(-1),
+            P=_ffi.f64(prob.P), cam_R=_ffi.f64(prob.cam_R), cam_t=_ffi.f64(prob.cam_t),
+            cam_R0=_ffi.f64(prob.cam_R0), cam_t0=_ffi.f64(prob.cam_t0),
             g=_ffi.f64(prob.gravity), Kinv=cls._kinv(prob.K),               # reference MSCKF.py:519
-            view_ptr=_ffi.i32(prob.view_ptr), obs_uv=_ffi.f64(prob.obs_uv).reshape(-1),
-            obs_slot=_ffi.i32(prob.obs_slot), idp_base=_ffi.f64(prob.idp_base).reshape(-1),
-            idp_m=_ffi.f64(prob.idp_m).reshape(-1), idp_rho=_ffi.f64(prob.idp_rho))
+            view_ptr=_ffi.i32(prob.view_ptr), obs_uv=_ffi.f64(prob.obs_uv),
+            obs_slot=_ffi.i32(prob.obs_slot), idp_base=_ffi.f64(prob.idp_base),
+            idp_m=_ffi.f64(prob.idp_m), idp_rho=_ffi.f64(prob.idp_rho))
 
     # -- resident path ------------------------------------------------------
     def set_state(self, prob: UpdateProblem):
