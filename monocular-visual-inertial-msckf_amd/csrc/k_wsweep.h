@@ -147,13 +147,8 @@ __device__ __forceinline__ void wsweep_body(const WSweepArgs& p) {
     int e_nx = 0, p_nx = 0;                                // table entries of the coming step (read one step ahead)
     const int* ptab = ftab + nsteps + 1;                   // rows to publish at the head of step ts (0: nothing), made by the host
     auto store_out = [&](double* q, double x) {
-#ifdef WS_PUB_PLAIN
-        if constexpr (false) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)q,
-                                              (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         if constexpr (PUB) __hip_atomic_store((__attribute__((address_space(1))) unsigned long long*)(unsigned long long*)q,
                                               (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
         else *q = x;
     };
     auto publish = [&](int rows) {
@@ -164,9 +159,7 @@ __device__ __forceinline__ void wsweep_body(const WSweepArgs& p) {
     // rows [lo, lo + n) are final at the head of macro step ts: out to HBM, ring slots cleared
     auto flush_rows = [&](int ts) {
         if constexpr (PUB) {
-#ifndef WS_PUB_NOWAIT
             if (pend & 1u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             pend >>= 1;
         }
         // (the table entries of step ts were requested during step ts - 1: a dependent LDS read at the head of every step

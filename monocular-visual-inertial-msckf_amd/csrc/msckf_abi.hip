@@ -110,16 +110,15 @@ double now_us() {
     return duration_cast<duration<double, std::micro>>(steady_clock::now().time_since_epoch()).count();
 }
 
-// Host-side helpers of the drop-in call: the validation and the gather of the tracks into the pinned upload image
-// are loops over F features (50 us of the 590 us call at the headline, 290 of 1040 at 10000 features) that split cleanly
-// over feature ranges.  A few persistent worker threads (created with the context, CPU work only -- they never make a
-// HIP call, whose first use costs a new thread ~100 ms) take chunks of a parallel_for next to the calling thread.  After a
-// run they keep polling for MSCKF_HOST_SPIN_US (default 1000) microseconds before they sleep on the condition variable, so
-// a filter calling at frame rate finds them awake (a condition-variable wake-up alone costs what the parallel loop saves
-// at the headline size).  MSCKF_HOST_THREADS=n sets the worker count (default 3, 0 = everything on the calling thread),
-// MSCKF_HOST_PAR_MIN the smallest batch that is split (default 1024 features).  Measured on the 2 x 64-core EPYC of the
-// GPU box (tools/host_path.py, rotating batches): 10000 features 1040 -> 918 us per call (validate 80 -> 23 us, gather
-// 203 -> 93 us); 2000 features 587 -> 567 us (validate 18 -> 7, gather 32 -> 20).
+// Host-side helpers of the drop-in call: the copies of the caller's arrays into the pinned upload image and the validation of
+// the tracks are loops over F features that split cleanly over feature ranges (rounds 2-3 also gathered the tracks into sorted
+// order here -- 29 us of the call at the headline, 155 at 10000 features; k_gather.h does that on the device now).  A few
+// persistent worker threads (created with the context, CPU work only -- they never make a HIP call, whose first use costs a
+// new thread ~100 ms) take chunks of a parallel_for next to the calling thread.  After a run they keep polling for
+// MSCKF_HOST_SPIN_US (default 1000) microseconds before they sleep on the condition variable, so a filter calling at frame
+// rate finds them awake (a condition-variable wake-up alone costs what the parallel loop saves at the headline size).
+// MSCKF_HOST_THREADS=n sets the worker count (default 3, 0 = everything on the calling thread; 7 measured no faster: the phase
+// is bound by the pinned image's memory traffic), MSCKF_HOST_PAR_MIN the smallest batch that is split (default 1024 features).
 class HostPool {
 public:
     explicit HostPool(int workers, int spin_us = 1000) : spin_us_(spin_us) {
@@ -394,6 +393,7 @@ struct msckf_ctx {
     int root_n_gate = -1;                 // step-0 requirements behind the root's flush + gate tables (sweep_gate_table), -1: no gate table
     Buf dMFlush, dMProg;                  // ... on the device; the merge nodes' progress words (64)
     bool stream_enabled = true;           // MSCKF_ROOT_STREAM=0: the level keeps its own launch
+    int n_cu = 256;                       // compute units of the device: workgroups that wait for each other inside one launch must all be resident
     bool feat_busy = false, pose_busy = false;   // hFeat / hPose may still be read by a copy or by k_gather
     bool main_busy = false;                      // the main stream holds work nobody has waited for
     bool run_pending = false;                    // ... a pipeline / merge among it (kernels that read the K5 plan and the workspace)
@@ -881,8 +881,10 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     c->root_streamed = false; c->stream_level = -1; c->h_mflush.clear();
     {
         const int last = (int)merge_levels.size() - 1;
+        // (every workgroup of that launch -- root, strips, merge nodes -- holds a CU of its own while it waits for the others:
+        //  at most half of the device, so that a partitioned GPU or a kernel on another stream cannot keep a producer out)
         if (c->stream_enabled && mode == 0 && !xchg && last >= 0 && c->sweep_level_nf[last] <= SWEEP_NW_MID && (int)merge_levels[last].size() <= 64 &&
-            group_tri.size() > 1) {
+            group_tri.size() > 1 && 2 * (2 + (dc + 15) / 16 + (int)merge_levels[last].size()) <= c->n_cu) {
             c->root_streamed = true; c->stream_level = last;
         }
     }
@@ -1456,7 +1458,8 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
 // The root sweep (k_sweep form) and K6-K7 in ONE launch (k_root_gain): workgroup 0 sweeps and publishes the rows of the
 // root block as they become final, workgroups 1.. are the strips of the update.  `sa` carries the tables and the node index.
 bool root_gain_ok(const msckf_ctx* c, int band) {
-    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 2 * SWEEP_NW;      // two tiles on each fold-slot wavefront
+    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 2 * SWEEP_NW &&    // two tiles on each fold-slot wavefront
+           2 * (2 + (c->dc + 15) / 16) <= c->n_cu;                                             // (the sweep and the strips wait for each other: all resident)
 }
 // A merge level that rides in the root's launch (k_gstream.h): its nodes, where their flush tables sit on the device
 // ([count offsets | tables]) and the root's step-0 requirement count behind its own tables (sweep_gate_table).
@@ -1702,6 +1705,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     hipDeviceProp_t prop{};
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { delete c; return MSCKF_ERR_NO_DEVICE; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MSCKF_ERR_NO_DEVICE; }
+    c->n_cu = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MSCKF_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { msckf_destroy(c); return MSCKF_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->stream_up, hipStreamNonBlocking) != hipSuccess) { msckf_destroy(c); return MSCKF_ERR_HIP; }
@@ -3002,7 +3006,8 @@ int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int devic
         }
         c->x_n_merges = (int)c->x_snodes.size();
         // the merge level rides in the root's launch and streams its rows to the root (as the local plan's last level does)
-        c->x_streamed = xs && c->x_n_merges >= 1 && c->x_n_merges <= 64 && groups.size() > 1 && root_gain_ok(c, XW);
+        c->x_streamed = xs && c->x_n_merges >= 1 && c->x_n_merges <= 64 && groups.size() > 1 && root_gain_ok(c, XW) &&
+                        2 * (2 + (dc + 15) / 16 + c->x_n_merges) <= c->n_cu;
         if (!groups.empty()) {
             SweepNode r{};
             r.fold_begin = fold_base + (int)fl.size();
