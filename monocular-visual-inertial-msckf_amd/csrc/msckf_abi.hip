@@ -2002,6 +2002,9 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const bool par = c->pool && F >= host_par_min();
     if (par) c->pool->copy(hb + r_uv, obs_uv, (size_t)sumM * 16); else std::memcpy(hb + r_uv, obs_uv, (size_t)sumM * 16);
     HIPCHK(c, hipMemcpyAsync(draw, hb + r_uv, (size_t)sumM * 16, hipMemcpyHostToDevice, c->stream));
+    // (the one-shot call's state went up on the side stream: the main stream learns of it HERE, behind a copy it has to wait for
+    //  anyway -- between k_gather and k_feature the cross-stream wait cost ~4 us of an otherwise back-to-back pair)
+    if (c->state_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_state, 0)); c->state_pending = false; }
     // validate + first/last slot of each track + sort key (feature ranges on the host pool; the lowest failing range decides
     // the code), and the range's share of the remaining arrays into the pinned image
     // key = (class, first slot, last slot); class 0: band tracks; 1: wide tracks of up to 15 views (k_feature<32>); 2: wide tracks
