@@ -219,3 +219,26 @@ def test_streamed_merges_against_their_own_launch(monkeypatch, N, F, M, kw):
             eng.run()
             r = eng.result()
             assert np.array_equal(r.dx, one.dx) and np.array_equal(r.P_new, one.P_new)
+
+
+@pytest.mark.parametrize("N,F,M", [
+    (5, 1, 3), (30, 2, 10), (30, 1023, 10), (30, 1024, 10),      # one track; either side of the host pool's size
+    (30, 4096, 10), (30, 4097, 10),                               # either side of the copy-kernel / DMA switch
+    (3, 40, 3), (30, 600, 30),                                    # a short window; tracks as long as the window allows
+])
+def test_upload_paths_at_their_boundaries(monkeypatch, N, F, M):
+    """Sizes where the host path changes its route (pool on / off, k_stage / DMA, one wavefront of k_gather half empty):
+    the one-shot call against the oracle (1e-8) and, bitwise, against the resident sequence."""
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(N, F, M, seed=100 + F, variable_tracks=M > 3, outlier_fraction=0.1 if F > 10 else 0.0, outlier_px=300.0)
+    prob, _ = _shuffled(prob, F)
+    ref = oracle.update(prob, dense_noise=False)
+    with _engine(monkeypatch) as eng:
+        one = eng.update_problem(prob)
+        eng.load(prob)
+        eng.run()
+        res = eng.result()
+    assert one.status == ref["status"] and np.array_equal(one.accepted, ref["accepted"])
+    assert rel_err(one.dx, ref["dx"]) < TOL and rel_err(one.P_new, ref["P_new"]) < TOL
+    assert np.array_equal(one.dx, res.dx) and np.array_equal(one.P_new, res.P_new) and np.array_equal(one.accepted, res.accepted)

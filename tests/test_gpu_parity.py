@@ -857,3 +857,24 @@ def test_config5_full_size_fp64():
         assert np.array_equal(res.accepted, ref["accepted"])
         assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
         assert np.array_equal(res.P_new, res.P_new.T)
+
+
+@pytest.mark.parametrize("M", [16, 20, 21, 22, 30, 31])
+def test_gate_statistic_of_long_tracks(M):
+    """gamma of every track against the oracle at 1e-9 for track lengths around k_feature<64>'s column-chunk boundaries
+    (reference MSCKF.py:561-568).  Tracks of exactly 21 and 31 views were split into chunks of 11 views = 66 columns on 64
+    lanes until round 4: the gate lost two columns of one view, gamma was off by a few per cent -- and by a factor of 50 for a
+    track whose gross outlier sat in that view, which the gate then accepted."""
+    from msckf_amd import synth
+    from msckf_amd.api import UpdateEngine
+    from oracle import msckf_oracle as oracle
+    N = max(M, 25)
+    prob = synth.make_problem(N, 160, M, seed=900 + M, outlier_fraction=0.3, outlier_px=300.0)
+    ref = oracle.update(prob, dense_noise=False)
+    with UpdateEngine(max_clones=31, max_features=256, max_track=31) as eng:
+        res = eng.update_problem(prob)
+        gam, _ = eng.debug_gate()
+    np.testing.assert_allclose(gam, ref["gamma"], rtol=1e-9, atol=1e-12)
+    assert 0 < int(ref["accepted"].sum()) < prob.F                       # both sides of the gate are populated
+    assert np.array_equal(res.accepted, ref["accepted"])
+    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
