@@ -859,17 +859,17 @@ def test_config5_full_size_fp64():
         assert np.array_equal(res.P_new, res.P_new.T)
 
 
-@pytest.mark.parametrize("M", [16, 20, 21, 22, 30, 31])
+@pytest.mark.parametrize("M", list(range(2, 32)))
 def test_gate_statistic_of_long_tracks(M):
-    """gamma of every track against the oracle at 1e-9 for track lengths around k_feature<64>'s column-chunk boundaries
-    (reference MSCKF.py:561-568).  Tracks of exactly 21 and 31 views were split into chunks of 11 views = 66 columns on 64
+    """gamma of every track against the oracle at 1e-9 for EVERY track length the engine takes (2 - 31 views: the three
+    instances of k_feature and all their column-chunk boundaries; reference MSCKF.py:561-568).  Tracks of exactly 21 and 31 views were split into chunks of 11 views = 66 columns on 64
     lanes until round 4: the gate lost two columns of one view, gamma was off by a few per cent -- and by a factor of 50 for a
     track whose gross outlier sat in that view, which the gate then accepted."""
     from msckf_amd import synth
     from msckf_amd.api import UpdateEngine
     from oracle import msckf_oracle as oracle
     N = max(M, 25)
-    prob = synth.make_problem(N, 160, M, seed=900 + M, outlier_fraction=0.3, outlier_px=300.0)
+    prob = synth.make_problem(N, 160, M, seed=900 + M, outlier_fraction=0.3, outlier_px=300.0, min_track=2)
     ref = oracle.update(prob, dense_noise=False)
     with UpdateEngine(max_clones=31, max_features=256, max_track=31) as eng:
         res = eng.update_problem(prob)
@@ -878,3 +878,19 @@ def test_gate_statistic_of_long_tracks(M):
     assert 0 < int(ref["accepted"].sum()) < prob.F                       # both sides of the gate are populated
     assert np.array_equal(res.accepted, ref["accepted"])
     assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+
+
+@pytest.mark.parametrize("N", list(range(1, 54)))
+def test_every_window_size(eng, N):
+    """One small batch per window size 1 - 53 against the oracle: every strip count of K6-K7, every length of its short first
+    row block (6 N mod 16), the sweep forms on either side of N = 37 and the wide-track rule on either side of N = 31."""
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    M = max(1, min(N, 2 + N % 9))
+    prob = synth.make_problem(N, 90, M, seed=1300 + N, variable_tracks=M > 2, outlier_fraction=0.15, outlier_px=300.0)
+    ref = oracle.update(prob, dense_noise=False)
+    res = eng.update_problem(prob)
+    assert res.status == ref["status"] and np.array_equal(res.accepted, ref["accepted"])
+    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
+    if res.status == 0:
+        assert np.array_equal(res.P_new, res.P_new.T)
