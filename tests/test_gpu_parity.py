@@ -894,3 +894,16 @@ def test_every_window_size(eng, N):
     assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
     if res.status == 0:
         assert np.array_equal(res.P_new, res.P_new.T)
+
+
+@pytest.mark.parametrize("F", [1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 63, 64, 65, 127, 128, 129, 239, 240, 241, 255, 256, 257, 383, 511, 513])
+def test_batch_sizes_around_the_plan_boundaries(eng, F):
+    """Batch sizes on either side of the leaf / row-block / wavefront counts of the K5 plan (features per row block, blocks per
+    round, leaves per group, the streamed merge level appearing and disappearing) against the oracle."""
+    from msckf_amd import synth
+    from oracle import msckf_oracle as oracle
+    prob = synth.make_problem(30, F, 10, seed=2100 + F, variable_tracks=(F % 2 == 1), outlier_fraction=0.1 if F > 8 else 0.0, outlier_px=300.0)
+    ref = oracle.update(prob, dense_noise=False)
+    res = eng.update_problem(prob)
+    assert res.status == ref["status"] and np.array_equal(res.accepted, ref["accepted"])
+    assert rel_err(res.dx, ref["dx"]) < TOL and rel_err(res.P_new, ref["P_new"]) < TOL
