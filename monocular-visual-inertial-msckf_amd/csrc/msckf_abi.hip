@@ -555,7 +555,11 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
         if (f >= F) break;
         int lo = fmin[f], hi = fmax[f];
         int rows = 0, e = f, last = f;
+        // (a batch with wide tracks is sorted class by class -- set_features -- and a leaf's rows must come sorted by their
+        //  first column: no leaf across a class boundary; the merge levels sort their rows themselves)
+        const int cut1 = c->Fw > 0 ? c->Fb : F, cut2 = c->Fw > 0 ? c->Fb + c->Fw1 : F;
         while (e < F && (e - f) < FOLD_MAX_SRC) {
+            if (e > f && (e == cut1 || e == cut2)) break;
             if (live(e)) {
                 const int r = 2 * (view_sorted[e + 1] - view_sorted[e]);
                 if (e > f && rows + r > leaf_rows) break;
@@ -969,7 +973,9 @@ void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
         for (int i = 0; i < c->Fb; ++i) mask[i] = valid ? ((*valid)[i] & 1) : 1;
         if (build_plan_band(c, fmin, fmax, view_sorted, &mask)) { c->band_plan = true; c->wide_active = true; return; }
     }
-    c->band_plan = build_plan_band(c, fmin, fmax, view_sorted, valid);
+    // (a batch with wide tracks is sorted class by class: with all of them in ONE plan the order is no longer that of the first
+    //  slots, which the band plan's groups and the root's fold order rely on -- the merge tree takes any order)
+    c->band_plan = (c->Fw > 0 && c->no_wide) ? false : build_plan_band(c, fmin, fmax, view_sorted, valid);
     if (!c->band_plan) {
         c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->h_root_flush.clear();
@@ -2204,27 +2210,33 @@ int msckf_run(msckf_ctx* c) {
     return rc;
 }
 
+// Every track of the current batch through ONE Householder plan (the wide ones included: the merge tree, as before the
+// information form existed): for blocks that leave this context, and when the wide tracks' Gram matrix does not factor.
+static int replan_no_wide(msckf_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    c->no_wide = true;
+    c->plan_valid = false;
+    plan_batch(c, c->h_fmin, c->h_fmax, c->h_view_sorted, nullptr);
+    c->plan_no_wide = true;
+    c->gather_off = c->rbuf_doubles;
+    const size_t need = (c->rbuf_doubles + 16) * 8;
+    if (c->dRbuf.bytes < need) {
+        if (c->dRbuf.p) HIPCHK(c, hipFree(c->dRbuf.p));
+        c->dRbuf.p = nullptr; c->dRbuf.bytes = 0;
+        HIPCHK(c, hipMalloc(&c->dRbuf.p, need + need / 2));
+        c->dRbuf.bytes = need + need / 2;
+    }
+    HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
+    return upload_plan(c);
+}
+
 int msckf_run_compress(msckf_ctx* c) {
     if (!c) return MSCKF_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->have_features && c->wide_active) {
         // the compressed block leaves this context (msckf_export_block): one plan for every track, the wide ones included
-        // (the merge tree, as before the information form existed)
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->no_wide = true;
-        c->plan_valid = false;
-        plan_batch(c, c->h_fmin, c->h_fmax, c->h_view_sorted, nullptr);
-        c->plan_no_wide = true;
-        c->gather_off = c->rbuf_doubles;
-        const size_t need = (c->rbuf_doubles + 16) * 8;
-        if (c->dRbuf.bytes < need) {
-            if (c->dRbuf.p) HIPCHK(c, hipFree(c->dRbuf.p));
-            c->dRbuf.p = nullptr; c->dRbuf.bytes = 0;
-            HIPCHK(c, hipMalloc(&c->dRbuf.p, need + need / 2));
-            c->dRbuf.bytes = need + need / 2;
-        }
-        HIPCHK(c, hipMemsetAsync(c->dRbuf.p, 0, need, c->stream));
-        if (int rcp = upload_plan(c)) return rcp;
+        if (int rcp = replan_no_wide(c)) return rcp;
     }
     return run_pipeline(c, false, nullptr);
 }
@@ -2316,6 +2328,14 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     if (!(c->ran_gain && n_acc > 0)) status[0] = status[1] = 0;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
+    if (rc == MSCKF_ERR_NOT_SPD && c->wide_active && !c->no_wide && status[1] != 0 && c->have_features) {
+        // The wide tracks' Gram matrix did not factor: with few rows (a small batch, or one the gate thinned out) its rank is far
+        // below 6N + 1 and the shift 1e-14 trace / n does not carry that many pivots through rounding.  Every track through the
+        // Householder plans instead (the update the reference computes exists: its S = T P T^T + sigma^2 I is SPD regardless).
+        if (int r2 = replan_no_wide(c)) return r2;
+        if (int r2 = run_pipeline(c, true, nullptr)) return r2;
+        return msckf_get_result(c, dx, P_out, accepted, st);
+    }
     if (rc == MSCKF_ERR_NOT_SPD && status[0] == 3) {       // the mirror of the status word in host memory was never written
         c->last_error = "K6-K7 did not report a status";
         rc = MSCKF_ERR_HIP;
@@ -2374,6 +2394,11 @@ int msckf_commit_covariance(msckf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
+    if (c->wide_active && !c->no_wide && status[1] != 0 && c->have_features) {      // (msckf_get_result's fallback, for callers that commit unseen)
+        if (int r2 = replan_no_wide(c)) return r2;
+        if (int r2 = run_pipeline(c, true, nullptr)) return r2;
+        return msckf_commit_covariance(c);
+    }
     if (status[0] == 2) return MSCKF_ERR_HIP;                                  // k_gain_stream timed out
     if (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0)) return MSCKF_ERR_NOT_SPD;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
