@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak with RAGGED tracks: every track keeps a random subset of the views of a full-window track (holes,
 any span, 2 - 31 views), random window sizes, outliers; the one-shot call against the oracle (1e-8, equal masks).
-usage: soak_holes.py [cases] [seed] [f64|f32]   (f32: fp32 stack + f32 matrix-core products, tolerance 1e-4 / gamma 1e-3)"""
+usage: soak_holes.py [cases] [seed] [f64|f32] [Fmin Fmax]   (f32: fp32 stack + f32 matrix-core products, tolerance 1e-4 / gamma 1e-3)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,9 +38,10 @@ def main():
     worst = 0.0
     dtype = sys.argv[3] if len(sys.argv) > 3 else "f64"
     tol, gtol = (1e-8, 1e-7) if dtype == "f64" else (1e-4, 1e-3)
-    with UpdateEngine(max_clones=53, max_features=2048, max_track=31, dtype=dtype) as eng:
+    Fmin, Fmax = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1, 400)
+    with UpdateEngine(max_clones=53, max_features=max(2048, Fmax), max_track=31, dtype=dtype) as eng:
         for c in range(cases):
-            N = int(rng.integers(2, 54)); F = int(rng.integers(1, 400))
+            N = int(rng.integers(2, 54)); F = int(rng.integers(Fmin, Fmax))
             lo = 2; hi = int(rng.integers(2, min(N, 31) + 1))
             prob = ragged(rng, N, F, lo, hi, float(rng.choice([0.0, 0.1, 0.4])))
             ref = oracle.update(prob, dense_noise=False)
