@@ -58,10 +58,13 @@ def main():
             if ok and res.status == 0:
                 e = max(np.linalg.norm(res.dx - ref["dx"]) / max(np.linalg.norm(ref["dx"]), 1e-300),
                         np.linalg.norm(res.P_new - ref["P_new"]) / np.linalg.norm(ref["P_new"]))
-            g = float(np.max(np.abs(gam - ref["gamma"]) / np.maximum(np.abs(ref["gamma"]), 1e-12)))
+            gr = np.abs(gam - ref["gamma"]) / np.maximum(np.abs(ref["gamma"]), 1e-12)
+            g = float(np.max(gr))
+            kg = int(np.argmax(gr))
             worst = max(worst, e)
             if not ok or e > tol or g > gtol:
-                print(f"case {c}: N={N} F={F} views<= {hi}: status {res.status}/{ref['status']} masks equal {np.array_equal(res.accepted, ref['accepted'])} err {e:.2e} gamma {g:.2e}", flush=True)
+                print(f"case {c}: N={N} F={F} views<= {hi}: status {res.status}/{ref['status']} masks equal {np.array_equal(res.accepted, ref['accepted'])} err {e:.2e} gamma {g:.2e}"
+                      f" (track {kg}: {int(prob.view_ptr[kg + 1] - prob.view_ptr[kg])} views, slots {prob.obs_slot[prob.view_ptr[kg]]}..{prob.obs_slot[prob.view_ptr[kg + 1] - 1]}, gamma {gam[kg]:.6e} / oracle {ref['gamma'][kg]:.6e})", flush=True)
     print(f"{cases} cases, worst dx / P+ error {worst:.2e}")
 
 
