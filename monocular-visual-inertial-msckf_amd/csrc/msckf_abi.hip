@@ -169,7 +169,12 @@ public:
         cv_.notify_all();
         int c;
         while ((c = next_.fetch_add(1, std::memory_order_relaxed)) < n) { fn(c); done_.fetch_add(1, std::memory_order_release); }
-        while (done_.load(std::memory_order_acquire) < n) cpu_relax();
+        // (the workers are pinned, the caller is not: when the scheduler has moved it onto a worker's CPU, a caller that only
+        //  spins here keeps that worker -- and the chunk it holds -- off the CPU for a whole timeslice: 8 ms calls, measured on
+        //  the 5th - 10th call of a fresh process.  After a short spin the wait gives the CPU away.)
+        for (int spins = 0; done_.load(std::memory_order_acquire) < n; ++spins) {
+            if (spins < 256) cpu_relax(); else sched_yield();
+        }
     }
 
 private:
@@ -183,7 +188,10 @@ private:
             for (int spins = 0;; ++spins) {
                 if (gen_.load(std::memory_order_acquire) != seen) { got = true; break; }
                 cpu_relax();
-                if ((spins & 63) == 63 && std::chrono::steady_clock::now() > t_end) break;
+                if ((spins & 63) == 63) {
+                    if (std::chrono::steady_clock::now() > t_end) break;
+                    sched_yield();                  // (a caller that has been moved onto this CPU must not wait for the poll to end)
+                }
             }
             const std::function<void(int)>* fn = nullptr;
             int n = 0;
@@ -1839,6 +1847,25 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         const char* es = std::getenv("MSCKF_HOST_SPIN_US");
         c->pool = new HostPool(nw, es ? std::max(0, std::atoi(es)) : 1000);
     }
+    {
+        // The runtime sets up a copy engine the first time a copy is handed to it -- 8 ms, measured -- and picks the engine by
+        // what is busy: the one-shot call's two uploads (state on stream_up, observations on the main stream) met a second
+        // engine the first time they overlapped, on the 4th to 18th call of a process, inside the timed region of a short
+        // benchmark.  Overlapping copies in both directions on all three streams now, where the time does not count.
+        const size_t dm = 15 + 6 * (size_t)c->maxN;
+        const size_t wb = std::min<size_t>(dm * dm * 8, c->res_cap);
+        for (int round = 0; round < 6 && wb > 0; ++round) {
+            (void)hipMemcpyAsync(c->dP.p, c->hP, wb, hipMemcpyHostToDevice, c->stream_up);
+            (void)hipMemcpyAsync(c->dResArena.p, c->hRes, wb, hipMemcpyHostToDevice, c->stream);
+            (void)hipMemcpyAsync(c->dPn.p, c->hP, wb, hipMemcpyHostToDevice, c->stream2);
+            if (round & 1) {
+                (void)hipMemcpyAsync(c->hRes, c->dResArena.p, wb, hipMemcpyDeviceToHost, c->stream);
+                (void)hipMemcpyAsync(c->hP, c->dP.p, wb, hipMemcpyDeviceToHost, c->stream_up);
+            }
+        }
+        (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream_up); (void)hipStreamSynchronize(c->stream2);
+        (void)hipGetLastError();
+    }
     *out = c;
     return MSCKF_OK;
 }
@@ -2475,6 +2502,18 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
     if (stats) stats->us_total = c->us_total;
     c->hp[10] += now_us() - tu0;
     ++c->hp_calls;
+    {   // MSCKF_HOSTPROF=2: the phases of every call that took more than 2 ms (first uses, allocations)
+        static const int lvl = [] { const char* e = std::getenv("MSCKF_HOSTPROF"); return e ? std::atoi(e) : 0; }();
+        if (lvl >= 2) {
+            static thread_local double prev[12] = {0};
+            if (c->hp[10] - prev[10] > 2000.0)
+                std::fprintf(stderr, "msckf_update call %ld took %.0f us: set_state %.0f | image + validate %.0f, sort %.0f, launch K1-K4 %.0f, plan %.0f, plan upload %.0f | "
+                             "K5-K7 launches %.0f | gate %.0f | wait %.0f, unpack %.0f\n", c->hp_calls - 1, c->hp[10] - prev[10], c->hp[0] - prev[0], c->hp[1] - prev[1],
+                             c->hp[2] - prev[2], c->hp[4] - prev[4], c->hp[5] - prev[5], c->hp[6] - prev[6], c->hp[7] - prev[7], c->hp[11] - prev[11], c->hp[8] - prev[8],
+                             c->hp[9] - prev[9]);
+            for (int i = 0; i < 12; ++i) prev[i] = c->hp[i];
+        }
+    }
     return rc;
 }
 
