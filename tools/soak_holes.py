@@ -39,7 +39,8 @@ def main():
     dtype = sys.argv[3] if len(sys.argv) > 3 else "f64"
     tol, gtol = (1e-8, 1e-7) if dtype == "f64" else (1e-4, 1e-3)
     Fmin, Fmax = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1, 400)
-    with UpdateEngine(max_clones=53, max_features=max(2048, Fmax), max_track=31, dtype=dtype) as eng:
+    # (SOAK_PLAN=band|tree: every track on the Householder plans / on the merge tree; the MSCKF_* switches select the fallbacks)
+    with UpdateEngine(max_clones=53, max_features=max(2048, Fmax), max_track=31, dtype=dtype, plan=os.environ.get("SOAK_PLAN", "auto")) as eng:
         for c in range(cases):
             N = int(rng.integers(2, 54)); F = int(rng.integers(Fmin, Fmax))
             lo = 2; hi = int(rng.integers(2, min(N, 31) + 1))
