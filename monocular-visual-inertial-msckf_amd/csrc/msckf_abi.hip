@@ -1452,7 +1452,7 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.f32_update = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
     if (c->wide_active) {
         a.T2 = ptr<double>(c->dGramU); a.ldt2 = dc + 1; a.nb2 = nb;
-        if (c->wide_on_stream2) a.t2_flag = ptr<unsigned long long>(c->dGsProg) + 16;
+        a.t2_flag = ptr<unsigned long long>(c->dGsProg) + 16;
     }
     a.stamps = nullptr;
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
@@ -1538,10 +1538,10 @@ int launch_gram_chain(msckf_ctx* c) {
     a.S = ptr<double>(c->dGramS); a.lds_ = n; a.L = ptr<double>(c->dGramL); a.U = ptr<double>(c->dGramU);
     a.invd = ptr<double>(c->dGramInvd); a.n = n; a.work = nullptr; a.status = ptr<int>(c->dStatus) + 1;
     a.diag_rel = 1e-14;
-    if (c->wide_on_stream2) {             // K6-K7 of THIS update (the next epoch) waits for the factor inside its launch
-        a.done_flag = ptr<unsigned long long>(c->dGsProg) + 16;
-        a.done_val = (unsigned long long)(c->gs_epoch + 1) << 32;
-    }
+    // K6-K7 of THIS update (the next epoch) takes the factor's rows by the count k_chol16 publishes -- inside its launch when the
+    // chain runs beside it on the second stream, and by the same protocol when it ran in front of it (MSCKF_WIDE_STREAM=0)
+    a.done_flag = ptr<unsigned long long>(c->dGsProg) + 16;
+    a.done_val = (unsigned long long)(c->gs_epoch + 1) << 32;
     hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * CHOL16_W), 0, st, a);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
@@ -2355,10 +2355,11 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     if (!(c->ran_gain && n_acc > 0)) status[0] = status[1] = 0;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
-    if (rc == MSCKF_ERR_NOT_SPD && c->wide_active && !c->no_wide && status[1] != 0 && c->have_features) {
-        // The wide tracks' Gram matrix did not factor: with few rows (a small batch, or one the gate thinned out) its rank is far
-        // below 6N + 1 and the shift 1e-14 trace / n does not carry that many pivots through rounding.  Every track through the
-        // Householder plans instead (the update the reference computes exists: its S = T P T^T + sigma^2 I is SPD regardless).
+    if (rc == MSCKF_ERR_NOT_SPD && c->wide_active && !c->no_wide && c->have_features) {
+        // The wide tracks' Gram matrix did not factor (status word 1), or the update met a non-positive pivot on its rows (word 0):
+        // with few rows (a small batch, or one the gate thinned out) its rank is far below 6N + 1 and the shift 1e-14 trace / n
+        // does not carry that many pivots through rounding.  Every track through the Householder plans instead (the update the
+        // reference computes exists: its S = T P T^T + sigma^2 I is SPD regardless).
         if (int r2 = replan_no_wide(c)) return r2;
         if (int r2 = run_pipeline(c, true, nullptr)) return r2;
         return msckf_get_result(c, dx, P_out, accepted, st);
@@ -2421,7 +2422,7 @@ int msckf_commit_covariance(msckf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
-    if (c->wide_active && !c->no_wide && status[1] != 0 && c->have_features) {      // (msckf_get_result's fallback, for callers that commit unseen)
+    if (c->wide_active && !c->no_wide && (status[1] != 0 || status[0] == 1) && c->have_features) {      // (msckf_get_result's fallback, for callers that commit unseen)
         if (int r2 = replan_no_wide(c)) return r2;
         if (int r2 = run_pipeline(c, true, nullptr)) return r2;
         return msckf_commit_covariance(c);
