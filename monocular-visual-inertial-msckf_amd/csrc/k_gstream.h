@@ -317,10 +317,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             }
             if (I + 1 == nb) t2_seen = true;
         }
-        // (the factor's buffer was zeroed by k_gram_reduce's workgroups on every XCD moments before k_chol16 wrote it: a copy of
-        //  such a line that still sits in this XCD's L2 must not serve the loads below -- measured: 1 update in 6000 differed with
-        //  the factor made in the same stream, 1 in ~280000 with it made beside this launch)
-        if (src2) asm volatile("buffer_inv sc1" ::: "memory");
+
         GS_STAMP(WV - 1, 0);                                      // rows of T seen
         if (p.tstamp && !src2 && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();
         __syncthreads();

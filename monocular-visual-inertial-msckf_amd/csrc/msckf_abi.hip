@@ -396,6 +396,7 @@ struct msckf_ctx {
     bool root_streamed = false;           // this plan's root folds name their producers (SweepFold::prod), first fold not adopted
     int stream_level = -1;                // index of that level in sweep_levels
     std::vector<int> h_mflush;            // [n offsets | the nodes' flush tables]
+    int gram_u_n = -1;                    // layout (6N + 1) for which dGramU's lower triangle was zeroed
     int mflush_at = 0;                    // where h_mflush sits in the uploaded h_root_flush
     bool x_streamed = false; int x_root_n_gate = -1, x_mflush_at = 0;   // the same for rank 0's merge plan (run_merge_groups)
     int root_n_gate = -1;                 // step-0 requirements behind the root's flush + gate tables (sweep_gate_table), -1: no gate table
@@ -1522,7 +1523,7 @@ int launch_gram_chain(msckf_ctx* c) {
     if (int rc = ensure(c, c->dGramPart, (size_t)G * npairs * 256 * 8)) return rc;
     const size_t nn = (size_t)(6 * c->maxN + 1) * (6 * c->maxN + 1) * 8;
     if (int rc = ensure(c, c->dGramS, nn)) return rc;
-    if (int rc = ensure(c, c->dGramU, nn)) return rc;
+    { const void* before = c->dGramU.p; if (int rc = ensure(c, c->dGramU, nn)) return rc; if (c->dGramU.p != before) c->gram_u_n = -1; }
     if (int rc = ensure(c, c->dGramL, nn)) return rc;
     if (int rc = ensure(c, c->dGramInvd, (size_t)(6 * c->maxN + 1) * 8)) return rc;
     GramArgs g{};
@@ -1531,8 +1532,17 @@ int launch_gram_chain(msckf_ctx* c) {
     g.rank = ptr<int>(c->dRank); g.accepted = ptr<unsigned char>(c->dAcc);
     g.f0 = c->Fb; g.nf = c->Fw; g.dc = dc; g.nt = nt; g.part = ptr<double>(c->dGramPart);
     hipLaunchKernelGGL(k_gram, dim3(G), dim3(64 * GRAM_WAVES), gram_lds_bytes(nt), st, g);
-    // (k_chol16 writes the factor's upper triangle only and N changes the layout of U: the reduction also zeroes U)
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS), ptr<double>(c->dGramU));
+    // k_chol16 writes the factor's upper triangle only; what lies below stays zero from ONE memset per window size (N changes
+    // the layout of U).  The reduction used to zero U in every update: its workgroups run on every XCD, the lines they zeroed
+    // stayed in those L2s, and K6-K7's workgroups there -- reading the factor's rows while k_chol16, beside this launch, was
+    // still writing them through -- were now and then served such a line instead of the row k_chol16 had published
+    // (tools/stress_repeat.py: results that differed from their batch's first, 1 call in 200 - 300000 depending on how much of
+    // the factor is taken while it is made).
+    if (c->gram_u_n != n) {
+        HIPCHK(c, hipMemsetAsync(c->dGramU.p, 0, nn, st));
+        c->gram_u_n = n;
+    }
+    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS), (double*)nullptr);
     HIPCHK(c, hipGetLastError());
     CholArgs a{};
     a.S = ptr<double>(c->dGramS); a.lds_ = n; a.L = ptr<double>(c->dGramL); a.U = ptr<double>(c->dGramU);

@@ -18,7 +18,9 @@ batches = []
 for k in range(24):
     N = int(rng.choice([8, 16, 20, 30, 30, 30, 40, 50]))
     F = int(rng.choice([200, 500, 2000, 2000, 4000, 6000]))
-    if os.environ.get("STRESS_ONLY") == "ragged":
+    if os.environ.get("STRESS_ONLY") == "short":         # short ragged tracks whose holes make them span > 10 slots (wide class)
+        batches.append(ragged(rng, 30, 1500, 2, int(rng.integers(3, 7)), 0.1))
+    elif os.environ.get("STRESS_ONLY") == "ragged":
         batches.append(ragged(rng, 30, 1500, 2, int(rng.integers(2, 31)), 0.1))
     elif os.environ.get("STRESS_ONLY") == "plain":
         batches.append(synth.make_problem(30, 2000, 10, seed=int(rng.integers(1 << 30)), outlier_fraction=0.1, outlier_px=300.0))
