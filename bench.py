@@ -69,15 +69,27 @@ def algorithmic_costs(N, F, M, s=8, lens=None):
                 bytes_A=bytes_inputs + bytes_stack, t_roof_s=t_A + t_B + t_C, t_A=t_A, t_B=t_B, t_C=t_C, rows=m)
 
 
+def headline_pmc_file():
+    """The committed PMC summary of the HEADLINE workload: profiles/rNN_pmc.json of the highest round (the other
+    workloads' files carry a tag behind the round: rNN_ns_pmc.json, rNN_cfg4_pmc.json, ...)."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")):
+        m = re.fullmatch(r"r(\d+)_pmc\.json", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def pmc_traffic(kernel_prefixes):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this
     same command; raw counters, see the note in profiles/*_summary.md).  None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files:
+    f = headline_pmc_file()
+    if not f:
         return None
-    d = json.load(open(files[-1]))
+    d = json.load(open(f))
     tot, calls = 0.0, 0
     for name, k in d["kernels"].items():
         if any(pfx in name for pfx in kernel_prefixes) and k.get("fetch_kb") is not None and k.get("write_kb") is not None:
@@ -89,11 +101,11 @@ def pmc_traffic(kernel_prefixes):
 def pmc_executed_flops(kernel_prefixes):
     """FP64 flops the kernels EXECUTE per launch, from the committed SQ pass of the same command (profiles/*_pmc.json):
     SQ_INSTS_VALU_FMA_F64 counts wavefront instructions, 64 lanes x 2 flop each.  None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files:
+    f = headline_pmc_file()
+    if not f:
         return None
-    d = json.load(open(files[-1]))
+    files = [f]
+    d = json.load(open(f))
     tot, calls = 0.0, 0
     for name, k in d["kernels"].items():
         v = k.get("SQ_INSTS_VALU_FMA_F64")
@@ -297,6 +309,7 @@ def main():
                                  "frac_canonical": costs["t_roof_s"] * 1e6 / us_step,
                                  "frac_host_inclusive_canonical": costs["t_roof_s"] / call_s,
                                  "hbm_gbs_algorithmic": costs["bytes"] / (us_step * 1e-6) / 1e9}
+    line["k5_launches"] = n_lv
     line["stages_us"] = dict(head["stages_us"], hip_event_ms_per_step=us_step * 1e-3)
     line["accepted"] = head["accepted"]
     line["plan"] = {"leaves": stats.get("n_leaves"), "levels": stats.get("n_levels"),
@@ -439,6 +452,8 @@ def main():
                    "per-feature stage is a single-threaded Python loop, QR / products use the BLAS "
                    f"thread pool ({cores} threads, {os.cpu_count()} logical CPUs); mode (ii) of BASELINE.md 3: oracle with "
                    "R_n = sigma^2 I analytic instead of the reference's dense sigma^2*eye(m) (9.2 GB at this size)")
+        line["cpu_baseline"]["sample_short"] = (f"{reps} full headline updates, median {t:.2f} s ({tot:.0f} s in all); oracle mode (ii): "
+                                                f"R_n = sigma^2 I analytic; Python per-feature loop + BLAS pool of {cores} threads")
         line["cpu_baseline"]["samples_s"] = list(getattr(cpu_baseline, "last_samples", []))
         # the same update with the BLAS pool limited to 1 / 8 / 64 threads (rounds 1-3 read 1.000 +/- 0.0005 updates/s on
         # three different boxes: the un-quantised samples and this sweep say what the host is doing)
@@ -478,7 +493,48 @@ def main():
                     "note": "reference-faithful mode (i) of BASELINE.md 3: dense R_o = sigma^2 eye(m), m = 34000"}
             except MemoryError as e:
                 line["cpu_baseline"]["mode_i_headline"] = {"error": repr(e)}
-    print(json.dumps(line), flush=True)
+    emit(line)
+
+
+def emit(detail):
+    """The ONE stdout line of the contract, kept under 4 KB (round 4's had grown to 20 KB and the driver's parser returned
+    null): the contract keys, `roofline`, `cpu_baseline`, `north_star_roofline`, parity.  Everything else -- the per-config
+    rows, stage times, thread sweeps, sample lists, f1 / f2 / f3 / f4 rows -- goes to bench_detail.json beside this file
+    and, pretty-printed, to stderr (before the stdout line)."""
+    try:
+        with open(os.path.join(ROOT, "bench_detail.json"), "w") as fh:
+            json.dump(detail, fh, indent=1)
+    except OSError as e:
+        print("bench_detail.json not written: %r" % (e,), file=sys.stderr)
+    print(json.dumps(detail, indent=1), file=sys.stderr, flush=True)
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "value_resident", "ms_per_step_resident", "accepted")
+    line = {k: detail[k] for k in keep if k in detail}
+    line["config"] = {"workload": detail["config"]["workload"],
+                      "value_definition": "complete drop-in call, host arrays in -> dx, P+, mask on the host (PCIe both ways), four "
+                                          "batches in rotation; value_resident: K1-K7 with inputs resident in HBM (HIP events)"}
+    r = detail["roofline"]
+    line["roofline"] = {"kernel": "K5 QR compression (k_lsweep + merge levels + root sweep), %d launches/update" % detail["k5_launches"],
+                        "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"], "frac": r["frac"],
+                        "frac_executed": r.get("frac_executed"), "traffic": r.get("traffic"),
+                        "flops_per_launch": r["flops_per_launch"], "avg_launch_us": r["avg_launch_us"],
+                        "flops_model": "canonical dense-QR flops of SURVEY 8(d); frac_executed: SQ_INSTS_VALU_FMA_F64 of the committed PMC pass"}
+    if "cpu_baseline" in detail:
+        cb = detail["cpu_baseline"]
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample_short"]}
+        line["parity_vs_cpu_baseline"] = detail.get("parity_vs_cpu_baseline")
+    if "north_star_roofline" in detail:
+        ns = detail["north_star_roofline"]
+        line["north_star_roofline"] = {"workload": ns["workload"], "frac": ns["frac"], "frac_host_inclusive": ns["frac_host_inclusive"],
+                                       "us": ns["us_per_update_resident"], "t_roof_us": ns["t_roof_us"]}
+    line["pipeline_roofline"] = {k: detail["pipeline_roofline"][k] for k in ("t_roof_us", "t_measured_us", "frac_canonical",
+                                                                            "frac_host_inclusive_canonical")}
+    line["stages_us"] = {k: detail["stages_us"][k] for k in ("feature_K1_K4", "qr_K5", "gain_K6_K7")}
+    line["detail"] = "bench_detail.json (also on stderr)"
+    out = json.dumps(line)
+    assert len(out) < 4096, len(out)
+    print(out, flush=True)
 
 
 def bench_sharded(args, world, rank, local_rank):
