@@ -624,6 +624,34 @@ def main():
     cases["edge_rank2_Hf"] = lambda: (coincident_clone_problem(14), None)                         # tracks with rank(H_f) = 2
     cases["edge_gate_threshold"] = lambda: (gate_threshold_problem(15), None)                     # gamma within 1e-4 of crit, both sides
     cases["edge_gate_threshold_tight"] = lambda: (gate_threshold_problem(16, rel=1e-7), None)     # ... within 1e-7: the reference decides the mask
+    # Round 5: long tracks, pinned to the reference itself (the reference's window is 30 clones, MSCKF.py:45; tracks grow a view
+    # per frame until lost, :404-412; both pruning callers hand update every feature of the removed clones, :669-678, :726-735).
+    # Until now the longest fixture track had 12 views: k_feature<32> / <64>, the split of long tracks and the dense
+    # remainder were compared with the oracle only.
+    cases["edge_long_tracks"] = lambda: (synth.make_problem(31, 64, 31, seed=24), None)           # every track spans the whole 31-clone window
+    cases["edge_mixed_spans"] = lambda: (synth.make_problem(30, 300, 30, seed=41, variable_tracks=True, min_track=2,
+                                                            outlier_fraction=0.10, outlier_px=400.0), None)
+    cases["edge_few_long_among_short"] = lambda: (synth.few_long_tracks_problem(30, 400, 10, 10, seed=42), None)
+
+    def long_recipe_b():
+        P, cam_R, cam_t, keys = realistic_state(30, 43)
+        return synth.make_problem(30, 160, 30, seed=43, P=P, poses=(cam_R, cam_t), variable_tracks=True, min_track=2), keys
+    cases["edge_long_tracks_B"] = long_recipe_b
+
+    def gauge_prior():
+        # metre-level COMMON-MODE variance of the clone (and IMU) positions: the stacked Jacobian's null space (global
+        # translation and yaw, rank 6N - 4) is where this prior is largest -- any shortcut that adds information there
+        # (a shifted normal-equation form) shows up in P+ at once
+        prob = synth.make_problem(30, 150, 30, seed=44, variable_tracks=True, min_track=2)
+        d = prob.d
+        U = np.zeros((d, 3))
+        U[12:15] = np.eye(3)
+        for i in range(prob.N):
+            U[18 + 6 * i:21 + 6 * i] = np.eye(3)
+        P = prob.P + 100.0 * (U @ U.T)                                                            # sigma = 10 m, fully correlated
+        return synth.UpdateProblem(**{**prob.__dict__, "P": P}), None
+    cases["edge_gauge_prior"] = gauge_prior
+    cases["edge_few_rows_long_tracks"] = lambda: (synth.make_problem(20, 5, 18, seed=45, variable_tracks=True, min_track=14), None)   # m << 6N
     if args.headline:
         cases["cfg3_A"] = lambda: (synth.make_problem(30, 2000, 10, seed=0), None)
 
