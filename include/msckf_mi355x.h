@@ -365,6 +365,15 @@ int msckf_debug_fold_stamps(msckf_ctx* ctx, long long* out, int32_t max_nodes);
 /* Average device time of the selection kernel (HIP events, `iters` re-launches of the last
  * msckf_run_select; the kernel is idempotent). */
 int msckf_debug_time_select(msckf_ctx* ctx, int32_t iters, float* us_per_launch);
+/* How the current batch's long tracks (more than 10 clone slots) were planned: out[0] long tracks that were split
+ * (two-level nullspace basis), out[1] their narrow blocks, out[2] rows their remainder blocks may hold,
+ * out[3] what K6-K7 does with those rows under the CURRENT plan: 0 nothing apart (no long track, or one plan for every
+ * block), 1 takes them as they are (dense second source), 2 takes the root of their own merge tree in a second launch;
+ * out[4] levels of that tree, out[5] entries of the sorted arrays (tracks + blocks), out[6] 1: band plan, out[7] sweep mode. */
+int msckf_debug_split(msckf_ctx* ctx, int32_t out[8]);
+/* Tests: remainder rows up to which K6-K7 takes them as they are (default 2048; < 0 restores it).  Applies to the
+ * batches loaded afterwards. */
+int msckf_debug_set_rem_direct_rows(msckf_ctx* ctx, int32_t rows);
 /* Raw device pointers (as integers) for zero-copy interop: which = 0 dx (dx[d] | P_out[d*d] are contiguous for the
  * CURRENT d = 15 + 6 N: the range is re-seated whenever N changes), 1 P_out, 2 root block [T | r_n], 3 the shard's
  * group record (msckf_set_group_exchange), 4 the prior covariance P, 5 the result range (status 64 B | dx | P_out |

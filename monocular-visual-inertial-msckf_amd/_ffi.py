@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 FLAG_TREE_PLAN = 1
-FLAG_BAND_ONLY = 2      # msckf_config.flags: always plan the K5 merge tree (no band pipeline)
+FLAG_BAND_ONLY = 2      # msckf_config.flags: long tracks are not split (one Householder plan for every track: 90-column tiles / merge tree)
 LIB_PATH = os.environ.get("MSCKF_LIB") or os.path.join(_HERE, "libmsckf_mi355x.so")   # MSCKF_LIB: A/B builds
 ABI_VERSION = 2
 DTYPE_F64, DTYPE_F32 = 0, 1
@@ -33,6 +33,7 @@ SYMBOLS = [
     "msckf_comm_unique_id", "msckf_comm_init", "msckf_comm_destroy", "msckf_comm_gather", "msckf_comm_broadcast",
     "msckf_comm_allreduce", "msckf_comm_buffer", "msckf_comm_put", "msckf_comm_get",
     "msckf_set_exchange_mask", "msckf_result_range_doubles", "msckf_get_shared_result", "msckf_set_exchange_span",
+    "msckf_debug_split", "msckf_debug_set_rem_direct_rows",
 ]
 
 
@@ -188,6 +189,10 @@ def load():
     lib.msckf_set_poses.restype = C.c_int
     lib.msckf_get_covariance.argtypes = [vp, _dp, _ip]
     lib.msckf_get_covariance.restype = C.c_int
+    lib.msckf_debug_split.argtypes = [vp, C.POINTER(C.c_int32)]
+    lib.msckf_debug_split.restype = C.c_int
+    lib.msckf_debug_set_rem_direct_rows.argtypes = [vp, C.c_int32]
+    lib.msckf_debug_set_rem_direct_rows.restype = C.c_int
     lib.msckf_debug_time_select.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.msckf_debug_time_select.restype = C.c_int
     _lib = lib

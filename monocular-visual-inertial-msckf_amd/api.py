@@ -567,6 +567,18 @@ class UpdateEngine:
         self._check(self._lib.msckf_debug_gate(self._h, _ffi.dptr(g), _ffi.iptr(q)), allow_noop=False)
         return g[:self._F], q[:self._F]
 
+    def debug_split(self) -> dict:
+        """How the loaded batch's long tracks were planned (`msckf_debug_split`)."""
+        out = (C.c_int32 * 8)()
+        self._check(self._lib.msckf_debug_split(self._h, out), allow_noop=False)
+        names = ("long_tracks", "narrow_blocks", "remainder_rows_cap", "remainder_mode", "remainder_tree_levels", "entries",
+                 "band_plan", "sweep_mode")
+        return dict(zip(names, [int(x) for x in out]))
+
+    def set_rem_direct_rows(self, rows: int = -1):
+        """Tests: remainder rows up to which K6-K7 takes them without a QR of their own (< 0: the default)."""
+        self._check(self._lib.msckf_debug_set_rem_direct_rows(self._h, int(rows)), allow_noop=False)
+
     def debug_compressed(self):
         dc = 6 * self._N
         T = np.zeros((dc, dc))

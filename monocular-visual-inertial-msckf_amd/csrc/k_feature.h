@@ -23,6 +23,28 @@
 
 namespace msckf {
 
+// ---- long tracks: a two-level nullspace basis (round 5) -----------------------------------------------------------------
+// delta x and P+ do not depend on WHICH orthonormal basis of null(H_f^T) projects a track (reference MSCKF.py:554-559 takes
+// scipy's).  A track that spans more than SPLIT_GSLOTS clone slots is cut into groups of views, each within
+// SPLIT_GSLOTS slots, and Q is built in two levels, Q = Q_1 Q_2:
+//   level 1: Q_1 = blockdiag(Q_1g), Q_1g^T H_f,g = [R_g; 0] -- three Householder reflectors over group g's rows alone.
+//            Rows 3.. of Q_1g^T [H_x,g | r_g] are projected measurements that touch ONLY the group's clone slots: an
+//            ordinary track of <= 10 views to the 60-column band pipeline (its "narrow block", q_g = 2 M_g - 3 rows);
+//   level 2: the 3 carry rows of every group ([R_g | their rows of Q_1g^T H_x | r]) are stacked and reduced by three
+//            more (column-pivoted) reflectors: the rows that remain, 3 (groups - 1) of them, touch every slot of the track
+//            -- the "remainder block", a few rows per long track instead of 2 M - 3.
+// A 30-view track becomes 3 x 17 narrow rows + 6 remainder rows; the gate (K3) is taken over all of them together and does
+// not depend on the basis either, so it runs on the one-level basis as before.
+constexpr int SPLIT_MAXG = 6;            // groups per long track
+constexpr int SPLIT_GSLOTS = 10;         // clone slots a group may span
+struct __attribute__((aligned(8))) SplitRec {
+    int child[SPLIT_MAXG];               // block index (K5 order) of group g's narrow block; -1: a one-view group has none
+    int wide;                            // block index of the remainder block
+    unsigned char gv[SPLIT_MAXG + 1];    // group g = views [gv[g], gv[g + 1]) of the track (views in slot order)
+    unsigned char ng;                    // groups (>= 2)
+    int row0;                            // first row of the track's 3 ng rows in the dense remainder matrix (k_rem_scatter)
+};
+
 struct FeatureArgs {
     int F;                       // features in this launch
     int f0;                      // ... sorted features [f0, f0 + F): workgroup b takes feature f0 + b
@@ -52,6 +74,7 @@ struct FeatureArgs {
     double* gamma;               // [F]
     long long* stamps;           // optional diagnostics (8 per feature), may be null
     long long zero_idx;          // index (scalars) of the 8 zero words behind the last block (k_lsweep loads them for absent entries)
+    const SplitRec* split;       // k_feature<64, true>: one record per feature of the launch (long tracks)
     int* rank_h;                 // optional mirrors of rank / accepted in pinned host memory (the one-shot call: the gate results
     unsigned char* acc_h;        //   are on the host when the stream has drained, without a copy command behind K7)
 };
@@ -77,7 +100,17 @@ __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
         const int stage = R2 * (6 * feature_chunk_views(M) + 1), elim = (R2 + 1) * (R2 + 3);   // one chunk of E | the elimination's tile (reuses it)
         return head + (stage > elim ? stage : elim) + 3 * R2 + 8;               // + E Z^T (behind both)
     }
-    return head + R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2) + 8;
+    const int stage = R2 * (6 * feature_chunk_views(M) + 1) + (R2 + 2), elim = (R2 + 1) * (R2 + 3);   // (the elimination's tile takes the staging area's place)
+    return head + (stage > elim ? stage : elim) + 8;
+}
+
+// ... of the split form (k_feature<64, true>): the chunked layout with a 61-column staging tile (a group has up to 10 views) +
+// V1, V2 rows, Z1, Z2, the view -> group map and the carry list
+__host__ __device__ inline int feature_split_lds_doubles(int M) {
+    const int R2 = 2 * M, C6 = 6 * M;
+    const int head = (M + 2) / 2 + R2 * 6 + R2 * 3 + 3 * C6;
+    const int cv = feature_chunk_views(M), ld = 6 * (cv > SPLIT_GSLOTS ? cv : SPLIT_GSLOTS) + 1;
+    return head + R2 * ld + (R2 + 2) + 8 + 6 * R2 + 6 * C6 + (M + 3 * SPLIT_MAXG + 4) / 2 + 2;
 }
 
 // The workgroup IS one wavefront (64 threads): its LDS instructions execute in program order, so a phase boundary needs no
@@ -129,14 +162,63 @@ template <int LK> __device__ __forceinline__ void elim_self(double (&b)[4], doub
                  "v_fmac_f64_dpp %3, %3, %[wb] " MSCKF_FD
                  : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : [wb] "v"(wB), [lk] "i"(LK));
 }
+// ... and of a row slot whose source is ANOTHER register set: d_j += (lane LK of a_j's row) * w  (k_feature<64>: four row slots)
+template <int LK> __device__ __forceinline__ void elim_from(double (&d)[1], const double (&a)[1], double w) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %[w] " MSCKF_FD : "+v"(d[0]) : "v"(a[0]), [w] "v"(w), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_from(double (&d)[2], const double (&a)[2], double w) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %[w] " MSCKF_FD "v_fmac_f64_dpp %1, %3, %[w] " MSCKF_FD
+                 : "+v"(d[0]), "+v"(d[1]) : "v"(a[0]), "v"(a[1]), [w] "v"(w), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_from(double (&d)[3], const double (&a)[3], double w) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %[w] " MSCKF_FD "v_fmac_f64_dpp %1, %4, %[w] " MSCKF_FD "v_fmac_f64_dpp %2, %5, %[w] " MSCKF_FD
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), [w] "v"(w), [lk] "i"(LK));
+}
+template <int LK> __device__ __forceinline__ void elim_from(double (&d)[4], const double (&a)[4], double w) {
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %4, %[w] " MSCKF_FD "v_fmac_f64_dpp %1, %5, %[w] " MSCKF_FD "v_fmac_f64_dpp %2, %6, %[w] " MSCKF_FD
+                 "v_fmac_f64_dpp %3, %7, %[w] " MSCKF_FD
+                 : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), [w] "v"(w), [lk] "i"(LK));
+}
 #undef MSCKF_FD
+// column quads [J0, J0 + NJ) of a 16-quad row slot, four per statement
+template <int LK, int J0, int NJ>
+__device__ __forceinline__ void elim_from16(double (&d)[16], const double (&a)[16], double w) {
+    if constexpr (NJ > 0) {
+        constexpr int N1 = NJ < 4 ? NJ : 4;
+        double dd[N1], aa[N1];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) { dd[i] = d[J0 + i]; aa[i] = a[J0 + i]; }
+        elim_from<LK>(dd, aa, w);
+#pragma unroll
+        for (int i = 0; i < N1; ++i) d[J0 + i] = dd[i];
+        elim_from16<LK, J0 + N1, NJ - N1>(d, a, w);
+    }
+}
+template <int LK, int J0, int NJ>
+__device__ __forceinline__ void elim_self16(double (&d)[16], double w) {
+    if constexpr (NJ > 0) {
+        constexpr int N1 = NJ < 4 ? NJ : 4;
+        double dd[N1];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) dd[i] = d[J0 + i];
+        elim_self<LK>(dd, w);
+#pragma unroll
+        for (int i = 0; i < N1; ++i) d[J0 + i] = dd[i];
+        elim_self16<LK, J0 + N1, NJ - N1>(d, w);
+    }
+}
+template <int K, int KEND, typename Fn>
+__device__ __forceinline__ void feature_static_for(Fn&& fn) {
+    if constexpr (K < KEND) { fn(FTag<K>{}); feature_static_for<K + 1, KEND>(fn); }
+}
 // RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
-template <int RMAX>
+template <int RMAX, bool SPLIT = false>
 __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs p) {      // (<24>: <= 168 registers, the LDS footprint allows 12 wavefronts per CU; <32>: 219 registers, 8 per CU -- bounded to 168 it spills and is slower)
     // CHUNKED: the gate works on column chunks (tracks of 16+ views, k_feature<64>).  Tracks of up to 15 views keep all 6M
     // columns of E in LDS: 27 KB at 15 views -- five wavefronts per CU instead of the chunked form's nine, and still the
     // faster one since the all-columns form was rebuilt in round 3 (per block at 15 views: 61 us chunked).
     constexpr bool CHUNKED = RMAX > 32;
+    static_assert(!SPLIT || CHUNKED, "the split form is an instance of the chunked kernel");
     constexpr bool ONE_CHUNK = RMAX <= 24;        // k_feature<24>: tracks of up to 10 views, all 60 columns in one chunk
     constexpr int MAXVK = ONE_CHUNK ? 10 : (RMAX - 2) / 2;   // longest track of this instance
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -167,6 +249,11 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         if (lane == 0) {
             p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3;
             if (p.acc_h) { p.rank_h[f] = 0; p.acc_h[f] = 3; }
+            if constexpr (SPLIT) {
+                const SplitRec& sr = p.split[blockIdx.x];
+                for (int g = 0; g < sr.ng; ++g) if (sr.child[g] >= 0) { p.rank[sr.child[g]] = 3; p.accepted[sr.child[g]] = 3; }
+                p.rank[sr.wide] = 0; p.accepted[sr.wide] = 3;
+            }
         }
         return;
     }
@@ -328,6 +415,7 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
     if (p.stamps) tq[2] = wall_clock64();
     const int q = R2 - rank;
     double srow[RMAX];
+    int n_wide_rows = 0;                   // SPLIT: rows of the track's remainder block
     if constexpr (!CHUNKED) {
     // Tracks of up to 15 views (k_feature<24>: 11, <32>: 15).  K4 and the gate run over column chunks of whole views, at most
     // 60 columns = one per lane (one chunk up to 10 views, two from 11 on): sE holds the chunk's columns of H_o (K4 staging),
@@ -559,9 +647,205 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
     if (p.stamps) tq[5] = wall_clock64();
     } else {
     const int CV = feature_chunk_views(M);   // views per column chunk
-    const int ldE = 6 * CV + 1;
+    const int ldE = 6 * ((SPLIT && CV < SPLIT_GSLOTS) ? SPLIT_GSLOTS : CV) + 1;
     double* sE = sZ + 3 * C6;              // [R2][ldE] one column chunk of H_o (K4 staging) / of E = H_o P_sub (gate)
     double* sRo = sE + R2 * ldE;           // [R2]      r_o
+    if constexpr (SPLIT) {
+        // ---------------- K2 + K4 of a long track: two-level basis, G narrow blocks + one remainder block ----------------
+        double* sU = sRo + (R2 + 2);           // [R2][3] level-1 reflectors (V1 rows)
+        double* sW = sU + 3 * R2;              // [R2][3] level-2 reflectors (V2 rows, zero outside the carry rows)
+        double* sZ1 = sW + 3 * R2;             // [3][C6] T1_g^T V1_g^T D, group g's columns
+        double* sZ2 = sZ1 + 3 * C6;            // [3][C6] T2^T V2^T H1
+        int* sGrp = reinterpret_cast<int*>(sZ2 + 3 * C6);      // [M] group of a view | [3 SPLIT_MAXG] the carry rows in order
+        int* sCarry = sGrp + M;
+        const SplitRec sr = p.split[blockIdx.x];
+        const int ng = sr.ng;
+        int grp = 0, g0v = 0;
+        for (int g = 0; g < ng; ++g)
+            if (view >= sr.gv[g] && view < sr.gv[g + 1]) { grp = g; g0v = sr.gv[g]; }
+        const bool inr = lane < R2;
+        const int lr = lane - 2 * g0v;         // row within the group
+        if (inr && (lane & 1) == 0) sGrp[view] = grp;
+        int ncarry = 0;
+        for (int g = 0; g < ng; ++g) {
+            const int rows = min(3, 2 * (sr.gv[g + 1] - sr.gv[g]));
+            for (int i = 0; i < rows; ++i) { if (lane == 0) sCarry[ncarry] = 2 * sr.gv[g] + i; ++ncarry; }
+        }
+        // sums over the rows of ONE group, every lane receiving its own group's (ng <= 6 whole-wave sums)
+        auto gsum = [&](double x) -> double {
+            double mine = 0.0;
+            for (int g = 0; g < ng; ++g) {
+                const double sg = wave_sum(grp == g ? x : 0.0);
+                if (grp == g) mine = sg;
+            }
+            return mine;
+        };
+        // level 1: three reflectors per group, no pivoting (any triangularisation of H_f,g serves)
+        double hh[3] = {inr ? h0 : 0.0, inr ? h1 : 0.0, inr ? h2 : 0.0};
+        double uu[3] = {0.0, 0.0, 0.0}, ub[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool act = inr && lr >= k;
+            const double ck = hh[k];
+            const double n0 = gsum(act ? ck * ck : 0.0);
+            double xk = 0.0;                                    // the pivot row's entry, per group
+            for (int g = 0; g < ng; ++g) {
+                const double xg = readlane_d(ck, min(2 * sr.gv[g] + k, 63));
+                if (grp == g) xk = xg;
+            }
+            const bool live = n0 > 0.0;                         // (a one-view group has no rows left at k = 2; a zero column: identity)
+            const double ry = fast_rsqrt(live ? n0 : 1.0);
+            const double nrm = n0 * ry;
+            const double alpha = (xk > 0.0) ? -nrm : nrm;
+            const double vk = (act && live) ? ((lr == k) ? (xk - alpha) : ck) : 0.0;
+            const double beta = live ? ry * fast_rcp(nrm + fabs(xk)) : 0.0;
+#pragma unroll
+            for (int j = k + 1; j < 3; ++j) {
+                const double dj = gsum(vk * hh[j]);
+                hh[j] -= beta * dj * vk;
+            }
+            if (act && live) hh[k] = (lr == k) ? alpha : 0.0;
+            uu[k] = vk; ub[k] = beta;
+        }
+        // T1 of the group (compact WY, as above) and the level-1 residual r1 = r - V1 T1^T V1^T r
+        const double g01 = gsum(uu[0] * uu[1]), g02 = gsum(uu[0] * uu[2]), g12 = gsum(uu[1] * uu[2]);
+        const double A00 = ub[0], A11 = ub[1], A22 = ub[2];
+        const double A01 = -ub[1] * A00 * g01;
+        const double A02 = -ub[2] * (A00 * g02 + A01 * g12);
+        const double A12 = -ub[2] * A11 * g12;
+        const double q0 = gsum(uu[0] * res), q1 = gsum(uu[1] * res), q2 = gsum(uu[2] * res);
+        const double r1 = res - (uu[0] * (A00 * q0) + uu[1] * (A01 * q0 + A11 * q1) + uu[2] * (A02 * q0 + A12 * q1 + A22 * q2));
+        {   // Z1 = T1^T (V1^T D): the two rows of a view sit in one group
+            const double av[6] = {a0, a1, a2, a3, a4, a5};
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double w0 = uu[0] * av[a], w1 = uu[1] * av[a], w2 = uu[2] * av[a];
+                w0 += dpp_move<0xB1>(w0);
+                w1 += dpp_move<0xB1>(w1);
+                w2 += dpp_move<0xB1>(w2);
+                if (inr && (lane & 1) == 0) {
+                    const int c = 6 * view + a;
+                    sZ1[c] = A00 * w0;
+                    sZ1[C6 + c] = A01 * w0 + A11 * w1;
+                    sZ1[2 * C6 + c] = A02 * w0 + A12 * w1 + A22 * w2;
+                }
+            }
+        }
+        // level 2: the carry rows (the first three rows of every group: [R_g | ...]) reduced by column-pivoted reflectors, as
+        // many as the one-level factorisation found the rank to be (the same |R_kk| up to rounding: the column norms of what
+        // is left are invariant under Q_1)
+        const bool isc = inr && lr < 3;
+        double ww[3] = {0.0, 0.0, 0.0}, wb[3] = {0.0, 0.0, 0.0};
+        {
+            double c0 = isc ? hh[0] : 0.0, c1 = isc ? hh[1] : 0.0, c2 = isc ? hh[2] : 0.0;
+            int L2[3] = {0, 0, 0};
+            { int n = 0; for (int g = 0; g < ng && n < 3; ++g) { const int rows = min(3, 2 * (sr.gv[g + 1] - sr.gv[g])); for (int i = 0; i < rows && n < 3; ++i) L2[n++] = 2 * sr.gv[g] + i; } }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k >= rank) break;
+                const bool act = isc && lane >= L2[k];
+                double n0 = wave_sum(act ? c0 * c0 : 0.0);
+                double n1 = (k < 2) ? wave_sum(act ? c1 * c1 : 0.0) : -1.0;
+                double n2 = (k < 1) ? wave_sum(act ? c2 * c2 : 0.0) : -1.0;
+                if (n1 > n0 && n1 >= n2) { double t_ = c0; c0 = c1; c1 = t_; n0 = n1; }
+                else if (n2 > n0 && n2 > n1) { double t_ = c0; c0 = c2; c2 = t_; n0 = n2; }
+                if (!(n0 > 0.0)) break;
+                const double ry = fast_rsqrt(n0);
+                const double nrm = n0 * ry;
+                const double xk = readlane_d(c0, L2[k]);
+                const double alpha = (xk > 0.0) ? -nrm : nrm;
+                const double vk = act ? ((lane == L2[k]) ? (xk - alpha) : c0) : 0.0;
+                const double beta = ry * fast_rcp(nrm + fabs(xk));
+                if (k < 2) { const double d1 = wave_sum(vk * (act ? c1 : 0.0)); if (act) c1 -= beta * d1 * vk; }
+                if (k < 1) { const double d2 = wave_sum(vk * (act ? c2 : 0.0)); if (act) c2 -= beta * d2 * vk; }
+                ww[k] = vk; wb[k] = beta;
+                c0 = c1; c1 = c2; c2 = 0.0;
+            }
+        }
+        const double e01 = wave_sum(ww[0] * ww[1]), e02 = wave_sum(ww[0] * ww[2]), e12 = wave_sum(ww[1] * ww[2]);
+        const double B00 = wb[0], B11 = wb[1], B22 = wb[2];
+        const double B01 = -wb[1] * B00 * e01;
+        const double B02 = -wb[2] * (B00 * e02 + B01 * e12);
+        const double B12 = -wb[2] * B11 * e12;
+        const double s0 = wave_sum(ww[0] * r1), s1 = wave_sum(ww[1] * r1), s2 = wave_sum(ww[2] * r1);
+        const double r2 = r1 - (ww[0] * (B00 * s0) + ww[1] * (B01 * s0 + B11 * s1) + ww[2] * (B02 * s0 + B12 * s1 + B22 * s2));
+        if (inr) {
+            sU[lane * 3 + 0] = uu[0]; sU[lane * 3 + 1] = uu[1]; sU[lane * 3 + 2] = uu[2];
+            sW[lane * 3 + 0] = ww[0]; sW[lane * 3 + 1] = ww[1]; sW[lane * 3 + 2] = ww[2];
+        }
+        wave_sync();
+        // Z2 = T2^T (V2^T H1), lanes over the columns: column c of view v meets the (up to three) carry rows of v's group only
+        for (int c = lane; c < C6; c += 64) {
+            const int v = c / 6, a = c - 6 * v, g = sGrp[v];
+            const int L0 = 2 * sr.gv[g], rows = min(3, 2 * (sr.gv[g + 1] - sr.gv[g]));
+            const double z0 = sZ1[c], z1 = sZ1[C6 + c], z2 = sZ1[2 * C6 + c];
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+            for (int i = 0; i < rows; ++i) {
+                const int L = L0 + i;
+                double hx = -(sU[L * 3 + 0] * z0 + sU[L * 3 + 1] * z1 + sU[L * 3 + 2] * z2);
+                if ((L >> 1) == v) hx += sA[L * 6 + a];
+                t0 += sW[L * 3 + 0] * hx; t1 += sW[L * 3 + 1] * hx; t2 += sW[L * 3 + 2] * hx;
+            }
+            sZ2[c] = B00 * t0;
+            sZ2[C6 + c] = B01 * t0 + B11 * t1;
+            sZ2[2 * C6 + c] = B02 * t0 + B12 * t1 + B22 * t2;
+        }
+        wave_sync();
+        // K4: one group of columns at a time through the staging tile (lanes over rows), then out as contiguous row segments:
+        // group g's narrow block (its rows 3.., its columns + r1) and the remainder block's columns of the group (the carry
+        // rows behind the `rank` pivot rows, + r2 with the last group)
+        n_wide_rows = ncarry - rank;
+        const int ldw = C6 + 1;
+        const long long wide_off = p.blk_off[sr.wide];
+        for (int g = 0; g < ng; ++g) {
+            const int gv0 = sr.gv[g], nvg = sr.gv[g + 1] - gv0;
+            const int c0g = 6 * gv0, cw = 6 * nvg;
+            const bool lastg = g == ng - 1;
+            if (inr) {
+                const double av[6] = {a0, a1, a2, a3, a4, a5};
+                double* erow = sE + lane * ldE;
+                const bool mine = grp == g;
+                for (int vw = gv0; vw < gv0 + nvg; ++vw) {
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        const int c = 6 * vw + a;
+                        double x = 0.0;
+                        if (mine) {
+                            x = -(uu[0] * sZ1[c] + uu[1] * sZ1[C6 + c] + uu[2] * sZ1[2 * C6 + c]);
+                            if (vw == view) x += av[a];
+                        }
+                        if (isc) x -= ww[0] * sZ2[c] + ww[1] * sZ2[C6 + c] + ww[2] * sZ2[2 * C6 + c];
+                        erow[c - c0g] = x;
+                    }
+                }
+                erow[cw] = isc ? r2 : r1;
+            }
+            wave_sync();
+            if (sr.child[g] >= 0) {                       // narrow block: rows 2 gv0 + 3 .. of the tile, cw + 1 columns, contiguous
+                const int qg = 2 * nvg - 3, cwp = cw + 1, nel = qg * cwp;
+                const long long boff = p.blk_off[sr.child[g]];
+                const float inv_cwp = 1.0f / (float)cwp;
+                for (int e = lane; e < nel; e += 64) {
+                    const int L = (int)(((float)e + 0.5f) * inv_cwp), cc = e - L * cwp;
+                    const double x = sE[(2 * gv0 + 3 + L) * ldE + cc];
+                    if (p.stack_f32) static_cast<float*>(p.stack)[boff + e] = (float)x;
+                    else static_cast<double*>(p.stack)[boff + e] = x;
+                }
+            }
+            {                                             // remainder block: the carry rows behind the pivot rows
+                const int cwp = cw + (lastg ? 1 : 0), nel = n_wide_rows * cwp;
+                const float inv_cwp = 1.0f / (float)cwp;
+                for (int e = lane; e < nel; e += 64) {
+                    const int L = (int)(((float)e + 0.5f) * inv_cwp), cc = e - L * cwp;
+                    const double x = sE[sCarry[rank + L] * ldE + cc];
+                    const long long dst = wide_off + (long long)L * ldw + c0g + cc;
+                    if (p.stack_f32) static_cast<float*>(p.stack)[dst] = (float)x;
+                    else static_cast<double*>(p.stack)[dst] = x;
+                }
+            }
+            wave_sync();
+        }
+    }
     // ---------------- K4 + K3, one column chunk (whole views, <= 64 columns) at a time -------------------
     // K4: the chunk's columns of H_o = D - V Z (and r_o with the last chunk) are staged in sE and leave as
     //     contiguous row segments of the stack block (row-major q x (6M+1), the q projected rows only).
@@ -578,7 +862,8 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         const int c0 = 6 * vc0, cw = 6 * nv;
         const bool last = vc0 + nv >= M;
         const int cwp = cw + (last ? 1 : 0);            // + the rhs column
-        // ---- K4 ----
+        // ---- K4 ---- (the split form has written its blocks above)
+        if constexpr (!SPLIT) {
         if (lane < R2) {
             const double av[6] = {a0, a1, a2, a3, a4, a5};
             double* erow = sE + lane * ldE;
@@ -606,24 +891,21 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             }
         }
         wave_sync();                                 // sE is rewritten by the gate's first pass
+        }
         // ---- K3 pass 1, lanes over the chunk's columns c of P_sub: E = D P_sub (block rows) - V (Z P_sub) ----
         if (lane < cw) {
             const int c = c0 + lane;
             const int colg = 15 + 6 * sSlot[c / 6] + (c % 6);
             double zp0 = 0, zp1 = 0, zp2 = 0;
-            double pv[6], pn[6];
-            {
-                const double* prow = p.P + (size_t)(15 + 6 * sSlot[0]) * p.ldp + colg;
+            // the column of P_sub this lane walks is requested FOUR views ahead (an L2 read is ~0.6 us, a view's 30 FMAs ~0.1:
+            // with one view of lookahead the pass was one load latency per view -- 30 of them per chunk of a 30-view track)
+            double pb[4][6];
+            auto fetchv = [&](double (&dst)[6], int vw) {
+                const double* prow = p.P + (size_t)(15 + 6 * sSlot[vw]) * p.ldp + colg;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) pv[a] = prow[(size_t)a * p.ldp];
-            }
-            for (int vw = 0; vw < M; ++vw) {
-                // prefetch the next 6 rows of this P_sub column while the current ones are consumed
-                if (vw + 1 < M) {
-                    const double* prow = p.P + (size_t)(15 + 6 * sSlot[vw + 1]) * p.ldp + colg;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) pn[a] = prow[(size_t)a * p.ldp];
-                }
+                for (int a = 0; a < 6; ++a) dst[a] = prow[(size_t)a * p.ldp];
+            };
+            auto usev = [&](const double (&pv)[6], int vw) {
                 double e0 = 0, e1 = 0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
@@ -636,8 +918,18 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
                 }
                 sE[(2 * vw) * ldE + lane] = e0;
                 sE[(2 * vw + 1) * ldE + lane] = e1;
+            };
 #pragma unroll
-                for (int a = 0; a < 6; ++a) pv[a] = pn[a];
+            for (int i = 0; i < 4; ++i)
+                if (i < M) fetchv(pb[i], i);
+            for (int vw = 0; vw < M; vw += 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (vw + i < M) {
+                        usev(pb[i], vw + i);
+                        if (vw + i + 4 < M) fetchv(pb[i], vw + i + 4);
+                    }
+                }
             }
             // E -= V ZP  (same column, all rows)
             for (int L = 0; L < R2; ++L) {
@@ -780,23 +1072,64 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         for (int j = 0; j < RMAX; ++j)
             if (j == R2) gam = -((j < 16) ? readlane_d(ea[j >> 2], 16 * (j & 3) + (j & 15)) : readlane_d(eb[j >> 2], 16 * (j & 3) + (j & 15)));
     } else {
+        // RMAX = 64 (tracks of 16 - 31 views): the same all-lane form with FOUR row slots -- lane (g, l) holds rows l + 16 s,
+        // s = 0 .. 3, of the columns j = 4 jj + g.  (Rounds 1-4 kept one matrix row per lane and moved every pivot-row entry
+        // by v_readlane: 64 of the 190 us of a 30-view track.)
+        double* sT = sZ + 3 * C6;
+        const int ldT = R2 + 3;
+        wave_sync();
+        if (lane <= R2) {
 #pragma unroll
-    for (int k = 0; k < RMAX - 1; ++k) {
-        if (k >= rank && k < R2 && !bad) {
-            const double piv = readlane_d(srow[k], k);
-            if (!(piv > 0.0)) {
-                bad = 1;
-            } else {
-                const double l = (lane > k) ? srow[k] * fast_rcp(piv) : 0.0;
+            for (int j = 0; j < RMAX; ++j)
+                if (j <= R2) sT[lane * ldT + j] = srow[j];
+        }
+        wave_sync();
+        const int g = lane >> 4, l15 = lane & 15;
+        double e[4][16];
 #pragma unroll
-                for (int j = k + 1; j < RMAX; ++j)
-                    if (j <= R2) srow[j] = fma(-l, readlane_d(srow[j], k), srow[j]);
+        for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = 4 * jj + g, row = l15 + 16 * sl;
+                e[sl][jj] = (j <= R2 && row <= R2) ? sT[row * ldT + j] : 0.0;
             }
         }
-    }
+        auto bperm_d = [&](double x, int src4) {
+            const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(x));
+            const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(x));
+            return __hiloint2double(hi, lo);
+        };
+        auto pivot4 = [&](auto tagk) {
+            constexpr int k = decltype(tagk)::value;
+            constexpr int sk = k >> 4, lk = k & 15, gk = k & 3, jk = k >> 2;
+            if (k >= rank && k < R2 && !bad) {
+                const double piv = readlane_d(e[sk][jk], 16 * gk + lk);
+                if (!(piv > 0.0)) {
+                    bad = 1;
+                } else {
+                    const double rp = fast_rcp(piv);
+                    const int src4 = (16 * gk + l15) * 4;                  // the lane of group gk with my rows
+                    double w[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < RMAX; ++j)
-        if (j == R2) gam = -readlane_d(srow[j], R2);
+                    for (int sl = sk; sl < 4; ++sl) {
+                        const double m = bperm_d(e[sl][jk], src4);
+                        w[sl] = (l15 + 16 * sl > k) ? -(m * rp) : 0.0;
+                    }
+                    // the slots below the pivot's first (their source, the pivot row in slot sk, is still untouched), then slot sk itself
+                    if constexpr (sk < 3) elim_from16<lk, jk, 16 - jk>(e[3], e[sk], w[3]);
+                    if constexpr (sk < 2) elim_from16<lk, jk, 16 - jk>(e[2], e[sk], w[2]);
+                    if constexpr (sk < 1) elim_from16<lk, jk, 16 - jk>(e[1], e[sk], w[1]);
+                    elim_self16<lk, jk, 16 - jk>(e[sk], w[sk]);
+                }
+            }
+        };
+        feature_static_for<0, RMAX - 2>(pivot4);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj)
+                if (sl == (R2 >> 4) && jj == (R2 >> 2)) gam = -readlane_d(e[sl][jj], 16 * (R2 & 3) + (R2 & 15));
+        }
     }
     if (p.stamps) tq[6] = wall_clock64();
     bool ok = (q >= 1) && (bad == 0) && (q < p.n_chi2);
@@ -809,7 +1142,61 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         // were 50 us of this kernel; the host sums the per-feature results instead.)
         p.accepted[f] = ok ? 1 : (bad ? 2 : 0);
         if (p.acc_h) { p.rank_h[f] = rank; p.acc_h[f] = ok ? 1 : (bad ? 2 : 0); }
+        if constexpr (SPLIT) {
+            // the blocks inherit the track's gate result; their `rank` is what K5's row count 2 M - rank needs
+            const SplitRec& sr = p.split[blockIdx.x];
+            const unsigned char code = ok ? 1 : (bad ? 2 : 0);
+            for (int g = 0; g < sr.ng; ++g) if (sr.child[g] >= 0) { p.rank[sr.child[g]] = 3; p.accepted[sr.child[g]] = code; }
+            p.rank[sr.wide] = R2 - n_wide_rows; p.accepted[sr.wide] = code;
+        }
         if (p.stamps) { tq[7] = wall_clock64(); for (int i = 0; i < 8; ++i) p.stamps[8 * f + i] = tq[i]; }
+    }
+}
+
+// The remainder blocks of a batch with few enough long tracks (up to 16 GS_MAX_NB2 rows: a merge tree over them would take longer) as ONE dense
+// row-major matrix [rows][6N + 1] = [H | r], zero where a track has no view, zero rows for rejected tracks and up to the next
+// multiple of 16: the sequential block update (k_gstream.h) takes them 16 at a time as its second source of rows, in front
+// of the band root's -- inside the root sweep's launch, while the sweep is on its first columns.
+//   reference MSCKF.py:581-588 (rows of the stack), :604-614 (the update they enter)
+struct RemScatterArgs {
+    const SplitRec* split;       // [n_tracks]
+    int n_tracks;                // long tracks; workgroup n_tracks zeroes the padding rows
+    int rows_cap, rows_pad;      // sum of 3 ng | rounded up to 16
+    int dc, N;
+    const int* view_ptr; const int* obs_slot;
+    const long long* blk_off; const void* stack; int stack_f32;
+    const int* rank; const unsigned char* accepted;
+    double* out;                 // [rows_pad][dc + 1]
+};
+__global__ __launch_bounds__(256) void k_rem_scatter(RemScatterArgs p) {
+    __shared__ int s_view[256];                       // clone slot -> view of the track (-1: none)
+    const int t = threadIdx.x, ld = p.dc + 1;
+    if ((int)blockIdx.x == p.n_tracks) {
+        for (int e = t; e < (p.rows_pad - p.rows_cap) * ld; e += 256) p.out[(size_t)p.rows_cap * ld + e] = 0.0;
+        return;
+    }
+    const SplitRec sr = p.split[blockIdx.x];
+    const int f = sr.wide, v0 = p.view_ptr[f], M = p.view_ptr[f + 1] - v0, cap = 3 * sr.ng;
+    const int q = (p.accepted[f] == 1) ? 2 * M - p.rank[f] : 0;
+    for (int i = t; i < p.N; i += 256) s_view[i] = -1;
+    __syncthreads();
+    if (t < M) s_view[p.obs_slot[v0 + t]] = t;
+    __syncthreads();
+    const long long boff = p.blk_off[f];
+    const int ldb = 6 * M + 1;
+    for (int e = t; e < cap * ld; e += 256) {
+        const int row = e / ld, col = e - row * ld;
+        double x = 0.0;
+        if (row < q) {
+            int src = -1;
+            if (col == p.dc) src = 6 * M;
+            else { const int sl = col / 6, v = s_view[sl]; if (v >= 0) src = 6 * v + (col - 6 * sl); }
+            if (src >= 0) {
+                const long long at = boff + (long long)row * ldb + src;
+                x = p.stack_f32 ? (double)static_cast<const float*>(p.stack)[at] : static_cast<const double*>(p.stack)[at];
+            }
+        }
+        p.out[(size_t)(sr.row0 + row) * ld + col] = x;
     }
 }
 

@@ -57,27 +57,29 @@ __device__ __forceinline__ void gs_std(double* p, double v) { gs_st(p, (unsigned
 constexpr int GS_WAVES = 16;                 // wavefronts per workgroup: tile wavefronts 0 .., wavefront 15 also eliminates
 constexpr int GS_PUB_WAVE = 14;              // publishes the strip's Y tile
 constexpr int GS_MAX_NS = 32;                // strips (two tiles per wavefront)
+constexpr int GS_MAX_NB2 = 128;              // row blocks of the second source (dense remainder rows of split long tracks)
 constexpr int GS_XS = 17;                    // X tiles in LDS: [column][row] with columns 17 doubles apart (a stride of 16 put a
 constexpr int GS_XT = 16 * GS_XS;            //  wavefront's store on four bank pairs: 1.2 us per row block for thirteen tiles)
 constexpr long long GS_TIMEOUT_TICKS = 50000000LL;   // 0.5 s of the 100 MHz wall clock
 
 struct GStreamArgs {
     const double* P; int ldp;                // prior covariance, d x d
+    const double* dx0;                       // null, or the dx a previous update on OTHER rows of the same batch left: the dx row starts
+                                             // from it (P is then that update's P+; split long tracks, launch_gain_chain)
     const double* T; int ldt;                // root block [T | r_n]: dc rows x (dc + 1), row-major, zero below the diagonal
     const unsigned long long* progress;      // (epoch << 32) | rows of T that are final; null: all rows are (standalone)
     unsigned epoch;
     double* ex;                              // exchange tiles [nb][ns][256]
-    unsigned long long* exflag;              // [nb][ns]: (epoch, row block + 1) in the upper 32 bits
+    unsigned long long* exflag;              // [row blocks of both sources][ns]: epoch << 32 | row block + 1
     double* dx; double* Pout; int ldo;
     double* dx_h; double* Pout_h; int* status_h;     // optional mirrors in pinned host memory (same layout; the one-shot call)
     int* status;                             // [0]: 0 ok, 1 a pivot was not a positive normal number, 2 timeout
     double sigma2;
     int d, dc, nb, ns, ncb;                  // nb row blocks of T, ns = nb + 1 strips, ncb column blocks per row block
-    // A second, COMPLETE source of rows taken first (while the sweep that publishes T is still on its first rows): the
-    // square root of the wide tracks' Gram matrix (k_gram.h).  nb2 = 0: none.  Its rows are dense right of the diagonal.
+    // A second, COMPLETE source of rows, taken FIRST (while the sweep that publishes T is still on its first columns): the
+    // remainder blocks of split long tracks as a dense row-major matrix [16 nb2][ldt2] (k_rem_scatter; complete when the
+    // launch starts -- its producer is ordered in front of the launch by the stream or an event).  nb2 = 0: none.
     const double* T2; int ldt2; int nb2;
-    const unsigned long long* t2_flag;       // null: T2 is complete when the launch starts and is taken FIRST; else it is another
-                                             // stream's work, taken LAST, as the word (epoch << 32) | rows says its rows are final
     int nb1;                                 // row blocks of T to take (nb, or 0 when there is no band root at all)
     int f32_update;                          // msckf_config.dtype = f32: the rank-16 products X_I[s] X_I[r]^T of the P-update on the
                                              // f32 matrix cores (fp32 operands and sums of 16 terms; P itself stays fp64)
@@ -248,16 +250,20 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
     // ([0] bad pivot, [1] timeout; an LDS pointer by type: a volatile generic one compiles to flat accesses that wait for vmcnt)
     typedef __attribute__((address_space(3))) int gs_lds_int;
     volatile gs_lds_int* sCtl = (volatile gs_lds_int*)(gs_lds_int*)(int*)(smem + 576);
-    double* sPartY = smem + 592;                         // [ncb][256]
-    double* sPartA = sPartY + (size_t)ncb * 256;         // [ncb][256]
-    double* sX = sPartA + (size_t)ncb * 256;             // [ns][GS_XT], operand order [column][row], column stride GS_XS
+    // (a block of the dense second source meets all nb strips, one of T only ncb: the partial tiles are laid out for the larger
+    //  count -- round 4 laid them out for ncb alone, and the second source's partials past ncb ran into sPartA / sX while other
+    //  wavefronts were using those: the "rare nondeterminism" of batches with wide tracks)
+    const int ncbl = (p.nb2 > 0 && nb > ncb) ? nb : ncb;
+    double* sPartY = smem + 592;                         // [ncbl][256]
+    double* sPartA = sPartY + (size_t)ncbl * 256;        // [ncbl][256]
+    double* sX = sPartA + (size_t)ncbl * 256;            // [ns][GS_XT], operand order [column][row], column stride GS_XS
     const unsigned sw_addr = lds_addr(sW);
     auto g0 = [&](int s) { return s == 0 ? 0 : 15 + 16 * (s - 1); };
     auto nrows = [&](int s) { return s == 0 ? 15 : min(16, d - (15 + 16 * (s - 1))); };
     const int gr = g0(r), nr = nrows(r);
     const int rem0 = dc - 16 * (nb - 1);                 // rows of the first block of T (1 .. 16)
-    // flag values: (epoch, row block + 1) in the upper 32 bits; never 0 (the flags are zeroed once), never the value a
-    // previous launch left in the same place (the epoch differs)
+    // flag values: epoch << 32 | row block + 1; never 0 (the flags are zeroed once), never the value a previous launch left
+    // in the same place (the epoch differs)
 
     // tiles P(s, r), s = wv + 16 q, symmetrised as they are loaded (the reference symmetrises its result, MSCKF.py:614)
     double Pt[TPW][4];
@@ -272,6 +278,12 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             const size_t row = ok ? gsr + m : 0, col = ok ? gr + cc : 0;
             const double x1 = p.P[row * p.ldp + col], x2 = p.P[col * p.ldp + row];
             Pt[q][i] = ok ? 0.5 * (x1 + x2) : 0.0;
+            if (p.dx0) {
+                // the dx row (row 15 of strip 0) holds -dx; its mirror image, column 15 of the tiles P(s, 0), is what strip 0's
+                // workgroup forms the row's share of Y from
+                if (s == 0 && m == 15 && cc < nr) Pt[q][i] = -p.dx0[gr + cc];
+                if (r == 0 && cc == 15 && s < ns && m < ms) Pt[q][i] = -p.dx0[gsr + m];
+            }
         }
     }
     if (t < 32) { sRi[t] = 0.0; sW[(t >> 4) * 272 + (t & 15) * 17 + 16] = __longlong_as_double(CHOL16_UNSET); }
@@ -281,22 +293,18 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
     const long long t_start = wall_clock64();
     bool failed = false;
     const int nb2 = p.nb2;
-    // which source first: the complete one (T2) while the sweep is on its first rows -- unless T2 is still being made by
-    // another stream's kernels (t2_flag): then the sweep's rows first and T2 behind them.  A FIXED order per launch
-    // configuration: an order that followed the factor's arrival (tried: strip 0 handing "ready" to every strip in its
-    // exchange flag, block by block) made the result depend on timing in its last bits.
-    const bool t2_first = !(nb2 > 0 && p.t2_flag);
-    bool t2_seen = !(nb2 > 0 && p.t2_flag) || t2_first;                   // the factor's rows may be read
     const int nb1 = p.nb1;
     for (int J = 0; J < nb2 + nb1; ++J) {
-        const bool src2 = t2_first ? (J < nb2) : (J >= nb1);
-        const int I = t2_first ? (src2 ? J : J - nb2) : (src2 ? J - nb1 : J);
+        const bool src2 = J < nb2;
+        const int I = src2 ? J : J - nb2;
         const double* Tsrc = src2 ? p.T2 : p.T;
         const int ldts = src2 ? p.ldt2 : p.ldt;
         const int ncbs = src2 ? nb : ncb;
-        const int row0 = (I == 0) ? 0 : rem0 + 16 * (I - 1), nrw = (I == 0) ? rem0 : 16;   // rows [row0, row0 + nrw) of T
+        // rows [row0, row0 + nrw) of the source: T's first block is the short one; the second source is a DENSE row matrix in
+        // blocks of 16 (the remainder blocks of split long tracks, k_rem_scatter: its rows meet every strip)
+        const int row0 = src2 ? 16 * I : ((I == 0) ? 0 : rem0 + 16 * (I - 1)), nrw = src2 ? 16 : ((I == 0) ? rem0 : 16);
         const int need = row0 + nrw;
-        const unsigned long long tag = (unsigned long long)((p.epoch << 6) | (unsigned)(J + 1)) << 32;
+        const unsigned long long tag = ((unsigned long long)p.epoch << 32) | (unsigned)(J + 1);
         // ---- A: row block I of T is final -------------------------------------------------------------------
         if (!src2 && p.progress && wv == WV - 1) {
             for (;;) {
@@ -306,23 +314,11 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
                 __builtin_amdgcn_s_sleep(8);
             }
         }
-        if (src2 && !t2_seen) {                                             // (uniform) the factor is another stream's work:
-            if (wv == WV - 1) {                                             // k_chol16 publishes its rows 16 at a time
-                for (;;) {
-                    const unsigned long long v = gs_ld(p.t2_flag);
-                    if ((v >> 32) == p.epoch && (int)(v & 0xffffffffu) >= min(need, 16 * nb)) break;
-                    if (wall_clock64() - t_start > GS_TIMEOUT_TICKS) { if (lane == 0) sCtl[1] = 1; break; }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            if (I + 1 == nb) t2_seen = true;
-        }
-
         GS_STAMP(WV - 1, 0);                                      // rows of T seen
         if (p.tstamp && !src2 && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();
         __syncthreads();
         if (sCtl[1]) { failed = true; break; }
-        const int s_lo = 1 + (row0 >> 4), s_hi = min(s_lo + ncbs - 1, ns - 1);   // strips that hold T_I's columns
+        const int s_lo = src2 ? 1 : 1 + (row0 >> 4), s_hi = min(s_lo + ncbs - 1, ns - 1);   // strips that hold T_I's columns
         // ---- B: partials of Y_I[r] = sum_s P(r, s) T_{I,s}^T ------------------------------------------------
         double Tt[TPW][4];
 #pragma unroll

@@ -26,7 +26,6 @@
 #include "k_fold.h"
 #include "k_gain.h"
 #include "k_gstream.h"
-#include "k_gram.h"
 #include "k_select.h"
 #include "k_sweep.h"
 #include "k_wsweep.h"
@@ -331,7 +330,7 @@ struct msckf_ctx {
     // (a pageable hipMemcpyAsync costs ~9 us apiece; the 15 + 6 of them were 270 us of the host-inclusive call)
     Buf dPoseArena, dFeatArena, dRawArena, dResArena, dGateArena;     // dRawArena: the tracks in the caller's order (k_gather.h)
     void *hPose = nullptr, *hFeat = nullptr, *hRes = nullptr, *hGate = nullptr, *hP = nullptr;   // pinned staging
-    size_t hFeatCap = 0, res_dx_off = 0, res_p_off = 0;
+    size_t hFeatCap = 0, hGateCap = 0, res_dx_off = 0, res_p_off = 0;
     size_t res_mask_off = 0, res_mask_cap = 0, res_cap = 0;   // gate bytes of the whole (sharded) batch behind P_out; arena bytes
     // sharded update: the gate results ride with the exchange (msckf_set_exchange_mask)
     std::vector<int> x_bounds;            // [n_shards + 1] shard r holds features [b[r], b[r+1]) of the whole batch; empty = off
@@ -353,14 +352,32 @@ struct msckf_ctx {
     int root_band = 0;                    // widest row of the root block in columns (the local plan's / the merge plan's)
     bool gs_stamp = false;                // msckf_run_timed: k_root_gain notes when its sweep ends and when its update ends
     bool gs_fused_last = false;           // the last pipeline ran k_root_gain (stage events cannot split it)
-    // tracks that span more than WIDE_SPAN clone slots go through the information form (k_gram.h): they are sorted behind the
-    // band tracks ([0, Fb) band, [Fb, F) wide), compressed to the square root of their Gram matrix and taken by K6-K7 as a
-    // second source of rows
+    // tracks that span more than WIDE_SPAN clone slots are sorted behind the others ([0, Fb) short, [Fb, F) long) and split
     int Fb = 0, Fw = 0, Fw1 = 0, Mmax_band = 0, Mmax_wide = 0, Mmax_w1 = 0;   // (Fw1 of the Fw wide tracks have <= 15 views)
+    // Round 5: a long track (more than WIDE_SPAN clone slots) is SPLIT (k_feature.h, two-level nullspace basis): the sorted
+    // arrays hold its blocks behind the F tracks -- [F, F + nNarrow) the narrow blocks of its view groups (ordinary <= 10-slot
+    // tracks to every K5 kernel, sorted by (first slot, last slot) among themselves), [F + nNarrow, Fs) one remainder block per
+    // long track (3 (groups - 1) rows that touch every slot of the track).  The long tracks themselves, [Fb, F), are entries
+    // of K1-K3 only (gate, mask, counters): no K5 plan names them.
+    int Fs = 0, nNarrow = 0;              // entries of the sorted arrays; narrow blocks
+    int sumMs = 0;                        // views of all entries
+    bool split_on = false;                // this batch's long tracks were split (Fw > 0: k_feature<64, true> writes their blocks)
+    std::vector<SplitRec> h_split;        // per long track, in sorted order
+    std::vector<int> h_parent;            // [Fs - F] sorted index of the long track a block belongs to
+    Buf dSplit, dRem;
+    int rem_cap = 0;                      // rows the remainder blocks may hold in all (3 per view group)
+    int rem_direct_max = 16 * GS_MAX_NB2; // (msckf_debug_set_rem_direct_rows)
+    bool rem_direct = false;              // ... few enough (16 GS_MAX_NB2): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
+    // ... the remainder blocks' own QR: a merge tree beside the band pipeline (second stream), its root the second source of
+    // rows for K6-K7 -- applied by a k_gain_stream launch of its own behind the first one, ordered by an event
+    std::vector<FoldNode> rnodes;
+    std::vector<std::pair<int, int>> rlevels;
+    int rroot = -1; size_t rroot_off = 0;
+    Buf dRNodes;
+    hipEvent_t ev_rem = nullptr;
     bool wide_active = false;             // the current plan keeps the wide tracks out of the band pipeline / tree
     bool no_wide = false;                 // the batch was re-planned with every track in one plan (msckf_run_compress: the
                                           // exported block must hold the wide tracks' rows too)
-    Buf dGramPart, dGramS, dGramU, dGramL, dGramInvd;
     hipStream_t stream2 = nullptr;        // the wide tracks' chain (k_feature, k_gram, k_gram_reduce, k_chol16) runs beside the band pipeline
     hipEvent_t ev_fork = nullptr, ev_wfeat = nullptr;   // uploads done -> stream2 may start; the wide tracks' K4 blocks are written
     bool wide_on_stream2 = false;         // this batch's wide k_feature went to stream2 (ev_wfeat pending)
@@ -396,7 +413,6 @@ struct msckf_ctx {
     bool root_streamed = false;           // this plan's root folds name their producers (SweepFold::prod), first fold not adopted
     int stream_level = -1;                // index of that level in sweep_levels
     std::vector<int> h_mflush;            // [n offsets | the nodes' flush tables]
-    int gram_u_n = -1;                    // layout (6N + 1) for which dGramU's lower triangle was zeroed
     int mflush_at = 0;                    // where h_mflush sits in the uploaded h_root_flush
     bool x_streamed = false; int x_root_n_gate = -1, x_mflush_at = 0;   // the same for rank 0's merge plan (run_merge_groups)
     int root_n_gate = -1;                 // step-0 requirements behind the root's flush + gate tables (sweep_gate_table), -1: no gate table
@@ -526,85 +542,95 @@ void invalidate_batch(msckf_ctx* c) {
     c->F = 0;
 }
 
-// Tracks of more than WIDE_SPAN clone slots take the information form where it applies (6N + 1 <= 192 columns: windows of up
-// to 31 clones): the 60-column band pipeline then never sees a track it would need the 90-column tiles for (whose root
-// sweep is 2.5 times as long) and the batch's widest track no longer decides the plan of all the others.
-constexpr int WIDE_SPAN = 10;
-bool wide_ok(const msckf_ctx* c, int N) {
-    if (!c->gs_enabled || c->cfg.dtype != MSCKF_DTYPE_F64 || (c->cfg.flags & (MSCKF_FLAG_TREE_PLAN | MSCKF_FLAG_BAND_ONLY)) || c->xchg) return false;
-    // OFF unless MSCKF_WIDE_GRAM=1 (round 5): the stack has an exact null space (global translation + yaw, rank 6N - 4) and the
-    // form's error enters the gauge directions LINEARLY in the rounding of G (and through the eps shift), not quadratically as
-    // with Householder rows -- with metre-level common-mode prior variance it is not a 1e-8 method.
-    static const bool on = [] { const char* e = std::getenv("MSCKF_WIDE_GRAM"); return e && std::atoi(e) == 1; }();
-    return on && N > WIDE_SPAN && 6 * N + 1 <= 16 * GRAM_MAX_NT;
+// Tracks that span more than WIDE_SPAN clone slots are SPLIT (k_feature.h: two-level nullspace basis) wherever a batch is
+// planned for this context alone: their narrow blocks are ordinary tracks of the 60-column band pipeline, their remainder
+// blocks a small dense QR beside it.  Any window size, both dtypes.  Not with the group exchange of a sharded update (its
+// record layout is the band pipeline's; such a batch keeps one plan for every track) nor where a plan is forced.
+constexpr int WIDE_SPAN = SPLIT_GSLOTS;
+// the sequential block update (k_gstream.h) on DENSE rows at this window size: strips and LDS
+bool gstream_ok_dc(const msckf_ctx* c, int dc) {
+    if (!c->gs_enabled || dc < 1) return false;
+    const int nb = (dc + 15) / 16, ns = nb + 1;
+    return ns <= GS_MAX_NS && gstream_lds_doubles(ns, nb) * 8 <= (size_t)(LDS_MAX_BYTES - 1024);
 }
+bool split_ok(const msckf_ctx* c, int N) {
+    if ((c->cfg.flags & (MSCKF_FLAG_TREE_PLAN | MSCKF_FLAG_BAND_ONLY)) || c->xchg) return false;
+    static const bool off = [] { const char* e = std::getenv("MSCKF_SPLIT"); return e && std::atoi(e) == 0; }();
+    return !off && N > WIDE_SPAN && gstream_ok_dc(c, 6 * N);
+}
+struct Run { int b, e; };                 // entries [b, e) of the sorted arrays
 
 // ---- QR tree plan ---------------------------------------------------------
 // Leaves: consecutive sorted features whose stacked-row bound stays under
 // leaf_rows.  Merge levels: consecutive nodes, up to `arity` children as long
 // as the rows to fold fit one LDS batch of the parent window, else two.
-void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
-                const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
-    const int F = c->F, N = c->N;
+void build_tree(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
+                const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid, const std::vector<Run>& runs,
+                size_t off0, std::vector<FoldNode>& nodes, std::vector<std::pair<int, int>>& levels, int& root, size_t& root_off,
+                size_t& off_end, int& n_leaves) {
+    const int N = c->N;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 160;
     const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 6;
-    c->nodes.clear();
-    c->levels.clear();
-    size_t off = 0;
+    const int rem0 = c->split_on ? c->F + c->nNarrow : (1 << 30);        // remainder blocks: entries [rem0, Fs)
+    nodes.clear();
+    levels.clear();
+    size_t off = off0;
     auto push = [&](int kind, int b, int e, int lo, int hi) {
         FoldNode n{};
         n.kind = kind; n.src_begin = b; n.src_end = e; n.win_lo = lo; n.w = 6 * (hi - lo + 1); n.pad = 0;
         n.out_off = (long long)off;
         off += (size_t)n.w * (n.w + 1);
-        c->nodes.push_back(n);
+        nodes.push_back(n);
     };
     // leaves (with `valid`, the features k_select masked out carry no rows: they neither count
     // towards a leaf nor widen its window, and stretches without a valid feature get no leaf)
     auto live = [&](int i) { return !valid || ((*valid)[i] & 1); };
-    int f = 0;
-    while (f < F) {
-        while (f < F && !live(f)) ++f;
-        if (f >= F) break;
-        int lo = fmin[f], hi = fmax[f];
-        int rows = 0, e = f, last = f;
-        // (a batch with wide tracks is sorted class by class -- set_features -- and a leaf's rows must come sorted by their
-        //  first column: no leaf across a class boundary; the merge levels sort their rows themselves)
-        const int cut1 = c->Fw > 0 ? c->Fb : F, cut2 = c->Fw > 0 ? c->Fb + c->Fw1 : F;
-        while (e < F && (e - f) < FOLD_MAX_SRC) {
-            if (e > f && (e == cut1 || e == cut2)) break;
-            if (live(e)) {
-                const int r = 2 * (view_sorted[e + 1] - view_sorted[e]);
-                if (e > f && rows + r > leaf_rows) break;
-                rows += r;
-                lo = std::min(lo, fmin[e]);
-                hi = std::max(hi, fmax[e]);
-                last = e;
+    // (a leaf's rows must come sorted by their first column and every run is sorted on its own: no leaf across a run
+    //  boundary; the merge levels sort their rows themselves)
+    for (const Run& run : runs) {
+        int f = run.b;
+        const int F = run.e;
+        while (f < F) {
+            while (f < F && !live(f)) ++f;
+            if (f >= F) break;
+            int lo = fmin[f], hi = fmax[f];
+            int rows = 0, e = f, last = f;
+            while (e < F && (e - f) < FOLD_MAX_SRC) {
+                if (live(e)) {
+                    // (rows of the entry at most: 2 per view; a remainder block holds 3 per view group)
+                    const int r = e >= rem0 ? 3 * (int)c->h_split[c->h_parent[e - c->F] - c->Fb].ng : 2 * (view_sorted[e + 1] - view_sorted[e]);
+                    if (e > f && rows + r > leaf_rows) break;
+                    rows += r;
+                    lo = std::min(lo, fmin[e]);
+                    hi = std::max(hi, fmax[e]);
+                    last = e;
+                }
+                ++e;
             }
-            ++e;
+            push(0, f, last + 1, lo, hi);
+            f = last + 1;
         }
-        push(0, f, last + 1, lo, hi);
-        f = last + 1;
     }
-    c->n_leaves = (int)c->nodes.size();
-    if (c->n_leaves > 0) c->levels.push_back({0, c->n_leaves});
+    n_leaves = (int)nodes.size();
+    if (n_leaves > 0) levels.push_back({0, n_leaves});
     // merge levels
-    int lvl_base = 0, lvl_cnt = c->n_leaves;
-    while (lvl_cnt > 1 || (lvl_cnt == 1 && (c->nodes[lvl_base].win_lo != 0 || c->nodes[lvl_base].w != 6 * N))) {
-        const int nb = (int)c->nodes.size();
+    int lvl_base = 0, lvl_cnt = n_leaves;
+    while (lvl_cnt > 1 || (lvl_cnt == 1 && (nodes[lvl_base].win_lo != 0 || nodes[lvl_base].w != 6 * N))) {
+        const int nb = (int)nodes.size();
         const int end = lvl_base + lvl_cnt;
         struct Grp { int b, e, lo, hi; };
         std::vector<Grp> grps;
         int i = lvl_base;
         while (i < end) {
-            int lo = c->nodes[i].win_lo, hi = lo + c->nodes[i].w / 6 - 1;
+            int lo = nodes[i].win_lo, hi = lo + nodes[i].w / 6 - 1;
             int e = i + 1;
             int fold_rows = 0;
             while (e < end && (e - i) < arity) {
-                const int lo2 = std::min(lo, c->nodes[e].win_lo);
-                const int hi2 = std::max(hi, c->nodes[e].win_lo + c->nodes[e].w / 6 - 1);
+                const int lo2 = std::min(lo, nodes[e].win_lo);
+                const int hi2 = std::max(hi, nodes[e].win_lo + nodes[e].w / 6 - 1);
                 const int cap = fold_bmax(6 * (hi2 - lo2 + 1));
-                if ((e - i) >= 2 && fold_rows + c->nodes[e].w > cap) break;   // keep one register batch per node
-                fold_rows += c->nodes[e].w;
+                if ((e - i) >= 2 && fold_rows + nodes[e].w > cap) break;   // keep one register batch per node
+                fold_rows += nodes[e].w;
                 lo = lo2; hi = hi2;
                 ++e;
             }
@@ -614,12 +640,12 @@ void build_plan(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
         if (grps.size() == 1) { grps[0].lo = 0; grps[0].hi = N - 1; }   // the root spans every clone
         for (const Grp& g : grps) push(1, g.b, g.e, g.lo, g.hi);
         lvl_base = nb;
-        lvl_cnt = (int)c->nodes.size() - nb;
-        c->levels.push_back({lvl_base, lvl_cnt});
+        lvl_cnt = (int)nodes.size() - nb;
+        levels.push_back({lvl_base, lvl_cnt});
     }
-    c->root = c->nodes.empty() ? -1 : (int)c->nodes.size() - 1;
-    c->root_off = c->nodes.empty() ? 0 : (size_t)c->nodes.back().out_off;
-    c->rbuf_doubles = off;
+    root = nodes.empty() ? -1 : (int)nodes.size() - 1;
+    root_off = nodes.empty() ? 0 : (size_t)nodes.back().out_off;
+    off_end = off;
 }
 
 // ---- band plan ----------------------------------------------------------------
@@ -752,12 +778,15 @@ void sweep_publish_table(std::vector<int>& tab, size_t off, int nsteps, int wtot
 }
 
 bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
-                     const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
-    const int F = c->F, N = c->N, dc = 6 * N;
+                     const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid, const std::vector<Run>& runs) {
+    const int N = c->N, dc = 6 * N;
     auto live = [&](int i) { return !valid || ((*valid)[i] & 1); };
-    int max_span = 0;
-    for (int f = 0; f < F; ++f)
-        if (live(f)) max_span = std::max(max_span, fmax[f] - fmin[f] + 1);
+    int max_span = 0, mm_live = 0, F = 0;                 // F: entries of the runs (they size the leaves)
+    for (const Run& run : runs) {
+        F += run.e - run.b;
+        for (int f = run.b; f < run.e; ++f)
+            if (live(f)) { max_span = std::max(max_span, fmax[f] - fmin[f] + 1); mm_live = std::max(mm_live, view_sorted[f + 1] - view_sorted[f]); }
+    }
     if (c->xchg && c->xchg_span > 0) {
         if (max_span > c->xchg_span) return false;                        // the caller's figure does not cover this shard: root blocks
         max_span = c->xchg_span;                                          // every shard plans with the mode of the whole batch
@@ -781,7 +810,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         //  wavefronts of two: 142 against 116 us at 10000 features)
         c->leaf_tall = wide_leaf && tall_mode != 0;
         const int rb = wide_leaf ? (c->leaf_tall ? LSweepGeom<6, LS_RS6T>::RB : LSweepGeom<6, LS_RS6>::RB) : LSweepGeom<4, LS_RS4>::RB;
-        const int mm = (c->Fw > 0 && !c->no_wide) ? c->Mmax_band : c->Mmax;      // longest track the leaves will see
+        const int mm = std::max(mm_live, 1);                                     // longest track the leaves will see
         const int fpb = std::max(1, std::min(LS_FB, rb / std::max(2 * mm - 3, 1)));
         c->leaf_nf = (F >= big_batch && !c->leaf_tall) ? 12 : 8;
         const int unit = c->leaf_nf * fpb;
@@ -804,13 +833,22 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     const int merge_ld = (c->stream_enabled && mode == 0 && !xchg) ? 64 : 0;      // merge outputs with whole cache lines per row (streamable, k_sweep.h)
     std::vector<Tri> group_tri;                                           // one triangle per group, by first slot
     std::vector<std::vector<SweepNode>> merge_levels;                     // [level] -> nodes of every group at that depth
-    int f = 0;
-    while (f < F) {
-        while (f < F && !live(f)) ++f;
-        if (f >= F) break;
-        const int s = fmin[f];
+    // every run is sorted by (first slot, last slot) on its own (the tracks; the narrow blocks of split long tracks): the
+    // groups are walked over all runs together, a leaf takes entries of ONE run
+    std::vector<int> cur(runs.size());
+    for (size_t r = 0; r < runs.size(); ++r) cur[r] = runs[r].b;
+    for (;;) {
+        int s = 1 << 30;
+        for (size_t r = 0; r < runs.size(); ++r) {
+            while (cur[r] < runs[r].e && !live(cur[r])) ++cur[r];
+            if (cur[r] < runs[r].e) s = std::min(s, fmin[cur[r]]);
+        }
+        if (s == (1 << 30)) break;
         // leaves of this group
         std::vector<Tri> leaves;
+        for (size_t r = 0; r < runs.size(); ++r) {
+        int& f = cur[r];
+        const int F = runs[r].e;
         while (f < F && (!live(f) || fmin[f] == s)) {
             if (!live(f)) { ++f; continue; }
             int hi = fmax[f], rows = 0, e = f, last = f, nlive = 0;
@@ -833,6 +871,7 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
             if (n.w + 1 > 64) c->leaf_wide = true; else c->leaf_narrow = true;
             leaves.push_back({n.out_off, s, n.w});
             f = last + 1;
+        }
         }
         // merge levels of this group: one k_sweep node folds up to 2 * SWEEP_NW triangles (two rounds of the
         // fold slots); larger groups first reduce chunks of SWEEP_NW triangles in parallel workgroups
@@ -974,34 +1013,60 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
     return true;
 }
 
-// plan for the current batch: band pipeline when it qualifies, else the tree
+// plan for the current batch: band pipeline when it qualifies, else the tree.  `valid_in` (k_select): one byte per TRACK.
 void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
-                const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid = nullptr) {
+                const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid_in = nullptr) {
     c->xchg_planned = false;
     c->wide_active = false;
-    if (c->Fw > 0 && !c->no_wide) {
-        // band plan over the band tracks only ([0, Fb) of the sorted order; with k_select: those of them that are valid)
-        std::vector<unsigned char> mask(c->F, 0);
-        for (int i = 0; i < c->Fb; ++i) mask[i] = valid ? ((*valid)[i] & 1) : 1;
-        if (build_plan_band(c, fmin, fmax, view_sorted, &mask)) { c->band_plan = true; c->wide_active = true; return; }
+    c->rnodes.clear(); c->rlevels.clear(); c->rroot = -1; c->rroot_off = 0;
+    const int F = c->F, Fs = c->Fs;
+    // a block is as valid as the track it was split off
+    std::vector<unsigned char> vfull;
+    const std::vector<unsigned char>* valid = valid_in;
+    if (valid_in && Fs > F) {
+        vfull.assign(valid_in->begin(), valid_in->begin() + F);
+        vfull.resize(Fs);
+        for (int i = F; i < Fs; ++i) vfull[i] = (*valid_in)[c->h_parent[i - F]];
+        valid = &vfull;
     }
-    // (a batch with wide tracks is sorted class by class: with all of them in ONE plan the order is no longer that of the first
-    //  slots, which the band plan's groups and the root's fold order rely on -- the merge tree takes any order)
-    c->band_plan = (c->Fw > 0 && c->no_wide) ? false : build_plan_band(c, fmin, fmax, view_sorted, valid);
-    if (!c->band_plan) {
+    auto tree_only = [&](const std::vector<Run>& runs) {
+        c->band_plan = false;
         c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->h_root_flush.clear();
-        build_plan(c, fmin, fmax, view_sorted, valid);
+        size_t off_end = 0;
+        build_tree(c, fmin, fmax, view_sorted, valid, runs, 0, c->nodes, c->levels, c->root, c->root_off, off_end, c->n_leaves);
+        c->rbuf_doubles = off_end;
         c->root_band = c->dc;                                             // a dense triangle
+    };
+    if (c->split_on) {
+        // (three runs, each sorted by first slot on its own: a leaf's rows must come sorted by their first column)
+        const std::vector<Run> band_runs{{0, c->Fb}, {F, F + c->nNarrow}}, all_runs{{0, c->Fb}, {F, F + c->nNarrow}, {F + c->nNarrow, Fs}};
+        if (!c->no_wide && build_plan_band(c, fmin, fmax, view_sorted, valid, band_runs)) {
+            c->band_plan = true; c->wide_active = true;
+            // the remainder blocks: taken by K6-K7 as they are when they are few (rem_direct), else a merge tree of their own
+            // behind the band plan's workspace
+            if (c->rem_direct) return;
+            size_t off_end = 0; int nl = 0;
+            build_tree(c, fmin, fmax, view_sorted, valid, {{F + c->nNarrow, Fs}}, c->rbuf_doubles, c->rnodes, c->rlevels, c->rroot,
+                       c->rroot_off, off_end, nl);
+            c->rbuf_doubles = off_end;
+            return;
+        }
+        tree_only(all_runs);           // (blocks that leave the context, MSCKF_FLAG-forced plans: ONE root block)
+        return;
     }
+    const std::vector<Run> runs{{0, F}};
+    c->band_plan = build_plan_band(c, fmin, fmax, view_sorted, valid, runs);
+    if (!c->band_plan) tree_only(runs);
 }
 
 int upload_plan(msckf_ctx* c);
 
 int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& levels,
-                       const std::vector<FoldNode>& all_nodes) {
+                       const std::vector<FoldNode>& all_nodes, hipStream_t st = nullptr, const FoldNode* dnodes = nullptr) {
+    if (!st) st = c->stream;
     FoldArgs a{};
-    a.nodes = ptr<FoldNode>(c->dNodes);
+    a.nodes = dnodes ? dnodes : ptr<FoldNode>(c->dNodes);
     a.lds_doubles = FOLD_LDS_BYTES / 8;
     a.view_ptr = ptr<int>(c->dViewPtr);
     a.obs_slot = ptr<int>(c->dObsSlot);
@@ -1032,7 +1097,7 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
             const bool small = leaf && leaf_rows_max <= FOLD_RL * FOLD_RPT_LEAF;
             const int cls = fold_class(maxw);
 #define FOLD_LAUNCH(RPT, CPT) \
-    hipLaunchKernelGGL((k_fold<FOLD_T, FOLD_RL, RPT, CPT>), grid, block, FOLD_LDS_BYTES, c->stream, a)
+    hipLaunchKernelGGL((k_fold<FOLD_T, FOLD_RL, RPT, CPT>), grid, block, FOLD_LDS_BYTES, st, a)
             if (cls == 1) {
                 if (small) FOLD_LAUNCH(FOLD_RPT_LEAF, FOLD_CPT1);
                 else FOLD_LAUNCH(FOLD_RPT_BIG, FOLD_CPT1);
@@ -1045,8 +1110,8 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
 #undef FOLD_LAUNCH
         } else {                                // wide windows: R streamed through HBM
             const dim3 block(FOLDG_T);
-            if (maxw + 1 <= 6 * 32) hipLaunchKernelGGL((k_fold_g<FOLDG_T, 12, 6>), grid, block, FOLD_LDS_BYTES, c->stream, a);
-            else hipLaunchKernelGGL((k_fold_g<FOLDG_T, 6, 10>), grid, block, FOLD_LDS_BYTES, c->stream, a);
+            if (maxw + 1 <= 6 * 32) hipLaunchKernelGGL((k_fold_g<FOLDG_T, 12, 6>), grid, block, FOLD_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((k_fold_g<FOLDG_T, 6, 10>), grid, block, FOLD_LDS_BYTES, st, a);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -1163,7 +1228,9 @@ int upload_plan(msckf_ctx* c) {
     auto room = [&](size_t bytes) { const size_t o = need; need += (std::max<size_t>(bytes, 64) + 255) & ~(size_t)255; return o; };
     const size_t b_nodes = c->nodes.size() * sizeof(FoldNode), b_sn = c->snodes.size() * sizeof(SweepNode), b_sf = c->sfolds.size() * sizeof(SweepFold);
     const size_t b_rf = c->h_root_flush.size() * 4, b_fl = c->h_flush.size() * 4, b_fo = c->h_flush_off.size() * 4;
+    const size_t b_rn = c->rnodes.size() * sizeof(FoldNode);
     const size_t o_nodes = room(b_nodes), o_sn = room(b_sn), o_sf = room(b_sf), o_rf = room(b_rf), o_fl = room(b_fl), o_fo = room(b_fo);
+    const size_t o_rn = room(b_rn);
     if (c->plan_staged) { HIPCHK(c, hipEventSynchronize(c->ev_plan_up)); c->plan_staged = false; }
     if (c->hPlanCap < need) {
         if (c->hPlan) HIPCHK(c, hipHostFree(c->hPlan));
@@ -1172,7 +1239,7 @@ int upload_plan(msckf_ctx* c) {
         c->hPlanCap = 2 * need + 4096;
     }
     // (buffers of their own from a merge plan that outgrew the arena: released before they become views again)
-    for (Buf* bb : {&c->dNodes, &c->dSweepNodes, &c->dSweepFolds, &c->dRootFlush, &c->dFlush, &c->dFlushOff})
+    for (Buf* bb : {&c->dNodes, &c->dSweepNodes, &c->dSweepFolds, &c->dRootFlush, &c->dFlush, &c->dFlushOff, &c->dRNodes})
         if (bb->p && !bb->view) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(bb->p)); bb->p = nullptr; bb->bytes = 0; }
     if (c->dPlanArena.bytes < need) {
         HIPCHK(c, hipStreamSynchronize(c->stream));        // (kernels of an earlier run may still read the old arena)
@@ -1185,6 +1252,7 @@ int upload_plan(msckf_ctx* c) {
     if (b_rf) std::memcpy(hp + o_rf, c->h_root_flush.data(), b_rf);
     if (b_fl) std::memcpy(hp + o_fl, c->h_flush.data(), b_fl);
     if (b_fo) std::memcpy(hp + o_fo, c->h_flush_off.data(), b_fo);
+    if (b_rn) std::memcpy(hp + o_rn, c->rnodes.data(), b_rn);
     HIPCHK(c, hipMemcpyAsync(c->dPlanArena.p, hp, need, hipMemcpyHostToDevice, ps));
     set_view(c->dNodes, c->dPlanArena.p, o_nodes, std::max<size_t>(b_nodes, 64));
     set_view(c->dSweepNodes, c->dPlanArena.p, o_sn, std::max<size_t>(b_sn, 64));
@@ -1192,6 +1260,7 @@ int upload_plan(msckf_ctx* c) {
     set_view(c->dRootFlush, c->dPlanArena.p, o_rf, std::max<size_t>(b_rf, 64));
     set_view(c->dFlush, c->dPlanArena.p, o_fl, std::max<size_t>(b_fl, 64));
     set_view(c->dFlushOff, c->dPlanArena.p, o_fo, std::max<size_t>(b_fo, 64));
+    set_view(c->dRNodes, c->dPlanArena.p, o_rn, std::max<size_t>(b_rn, 64));
     c->x_plan_valid = false;               // the sweep tables are rewritten: a cached merge plan behind them is gone
     if (c->xchg_planned)                   // (behind the workspace memset of set_features / replan, same stream)
         HIPCHK(c, hipMemcpyAsync(c->dRbuf.p, c->h_xflags.data(), c->h_xflags.size() * 8, hipMemcpyHostToDevice, ps));
@@ -1218,13 +1287,13 @@ int launch_feature(msckf_ctx* c) {
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
     a.zero_idx = c->stack_elems;
     c->gate_direct = c->want_direct && c->Fw == 0 && !c->use_select;
-    if (c->gate_direct) { a.rank_h = static_cast<int*>(c->hGate); a.acc_h = static_cast<unsigned char*>(c->hGate) + (size_t)c->F * 4; }
-    // one launch per class of tracks: the band tracks [0, Fb) and, where they are kept apart (wide_active), the wide ones
-    // [Fb, F), each with the instance its own longest track asks for
+    if (c->gate_direct) { a.rank_h = static_cast<int*>(c->hGate); a.acc_h = static_cast<unsigned char*>(c->hGate) + (size_t)c->Fs * 4; }
+    // one launch per class of tracks: the short tracks [0, Fb) and the long ones [Fb, F), which are split (k_feature<64, true>
+    // writes their narrow and remainder blocks)
     hipStream_t st = c->stream;
     auto go = [&](int f0, int nf, int mmax) {
         if (nf <= 0) return;
-        a.f0 = f0; a.F = nf;
+        a.f0 = f0; a.F = nf; a.split = nullptr;
         const bool chunked = 2 * mmax + 1 > 32;                // k_feature<64>: column chunks, S in registers
         int lds_d = 0;                   // (the footprint is not monotone in the track length: whole-view chunks)
         for (int m = 1; m <= mmax; ++m) lds_d = std::max(lds_d, feature_lds_doubles(m, chunked));
@@ -1233,22 +1302,36 @@ int launch_feature(msckf_ctx* c) {
         else if (2 * mmax + 1 <= 32) hipLaunchKernelGGL(k_feature<32>, dim3(nf), dim3(64), lds, st, a);
         else hipLaunchKernelGGL(k_feature<64>, dim3(nf), dim3(64), lds, st, a);
     };
+    auto go_split = [&](int f0, int nf, int mmax) {
+        if (nf <= 0) return;
+        a.f0 = f0; a.F = nf; a.split = ptr<SplitRec>(c->dSplit);
+        int lds_d = 0;
+        for (int m = 2; m <= mmax; ++m) lds_d = std::max(lds_d, feature_split_lds_doubles(m));
+        hipLaunchKernelGGL((k_feature<64, true>), dim3(nf), dim3(64), (size_t)lds_d * 8, st, a);
+        if (c->rem_direct) {             // few remainder rows: one dense matrix for K6-K7, no QR of their own
+            RemScatterArgs r{};
+            r.split = ptr<SplitRec>(c->dSplit); r.n_tracks = nf; r.rows_cap = c->rem_cap; r.rows_pad = (c->rem_cap + 15) & ~15;
+            r.dc = c->dc; r.N = c->N;
+            r.view_ptr = a.view_ptr; r.obs_slot = a.obs_slot; r.blk_off = a.blk_off; r.stack = a.stack; r.stack_f32 = a.stack_f32;
+            r.rank = a.rank; r.accepted = a.accepted; r.out = ptr<double>(c->dRem);
+            hipLaunchKernelGGL(k_rem_scatter, dim3(nf + 1), dim3(256), 0, st, r);
+        }
+    };
     c->wide_on_stream2 = false;
-    if (c->Fw > 0) {
-        // the wide tracks' kernel is ONE wavefront's latency per track (~6 us per view: 180 us at 30 views) however few they
-        // are: it and the chain behind it (k_gram, k_chol16) run on the second stream beside the band pipeline
-        if (!c->no_wide && c->wide_concurrent) {
+    if (c->split_on && c->Fw > 0) {
+        // a long track's kernel is ONE wavefront's latency per track (~6 us per view: 190 us at 30 views) however few they are: it
+        // runs on the second stream beside the short tracks' launch; the leaves wait for both (ev_wfeat, run_pipeline)
+        if (c->wide_concurrent) {
             HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             st = c->stream2;
-            go(c->Fb + c->Fw1, c->Fw - c->Fw1, c->Mmax_wide);        // (the long ones first: theirs is the longer wavefront)
-            go(c->Fb, c->Fw1, c->Mmax_w1);
+            go_split(c->Fb, c->Fw, c->Mmax_wide);
             HIPCHK(c, hipEventRecord(c->ev_wfeat, c->stream2));
             c->wide_on_stream2 = true;
             st = c->stream;
             go(0, c->Fb, c->Mmax_band);
         } else {
-            go(0, c->Fb, c->Mmax_band); go(c->Fb, c->Fw1, c->Mmax_w1); go(c->Fb + c->Fw1, c->Fw - c->Fw1, c->Mmax_wide);
+            go(0, c->Fb, c->Mmax_band); go_split(c->Fb, c->Fw, c->Mmax_wide);
         }
     } else go(0, c->F, c->Mmax);
     HIPCHK(c, hipGetLastError());
@@ -1430,7 +1513,7 @@ bool gstream_ok(const msckf_ctx* c, int band) {
     if (!c->gs_enabled || c->dc < 1) return false;
     const int nb = (c->dc + 15) / 16, ns = nb + 1;
     if (ns > GS_MAX_NS) return false;
-    const int ncb = c->wide_active ? nb : gstream_ncb(c->dc, band);      // (the wide tracks' rows are dense)
+    const int ncb = c->wide_active ? nb : gstream_ncb(c->dc, band);      // (the remainder blocks' root is dense)
     return gstream_lds_doubles(ns, ncb) * 8 <= (size_t)(LDS_MAX_BYTES - 1024);
 }
 // Tblk: the root block [T | r_n]; band: its widest row in columns
@@ -1454,10 +1537,7 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.nb1 = Tblk ? nb : 0;
     a.f32_update = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
-    if (c->wide_active) {
-        a.T2 = ptr<double>(c->dGramU); a.ldt2 = dc + 1; a.nb2 = nb;
-        a.t2_flag = ptr<unsigned long long>(c->dGsProg) + 16;
-    }
+    if (c->wide_active && c->rem_direct) { a.T2 = ptr<double>(c->dRem); a.ldt2 = dc + 1; a.nb2 = (c->rem_cap + 15) / 16; }
     a.stamps = nullptr;
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
 }
@@ -1471,6 +1551,25 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
     else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     c->gain_blocked = false;
+    return MSCKF_OK;
+}
+// K6-K7 on a SECOND source of rows -- the root of the remainder blocks' tree (split long tracks) -- behind the update on the
+// first: the rows of both sources are measurements with independent sigma^2 noise, so the update on all of them is the
+// update on the second against the covariance the first left (P = P_out, in place: a strip's workgroup stores its column
+// strip after the last exchange, which every workgroup takes part in only after it has loaded its tiles), with the dx row
+// carried on.  Its status goes to word 1.
+int launch_gain_chain(msckf_ctx* c, const double* Tblk) {
+    ++c->gs_epoch;
+    GStreamArgs a;
+    fill_gstream_args(c, a, Tblk, c->dc, false);
+    a.P = ptr<double>(c->dPout); a.ldp = c->d; a.dx0 = ptr<double>(c->dDx);
+    a.T2 = nullptr; a.nb2 = 0;
+    a.status = ptr<int>(c->dStatus) + 1;
+    a.status_h = nullptr; a.dx_h = nullptr; a.Pout_h = nullptr; a.tstamp = nullptr;
+    const size_t lds = gstream_lds_doubles(a.ns, a.ncb) * 8;
+    if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
+    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
 // The root sweep (k_sweep form) and K6-K7 in ONE launch (k_root_gain): workgroup 0 sweeps and publishes the rows of the
@@ -1517,49 +1616,6 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
     return MSCKF_OK;
 }
 
-// The wide tracks [Fb, F): Gram matrix of their K4 blocks on the matrix cores, summed, factored (k_gram.h).  The rows of the
-// factor ([T2 | r2], 6N x (6N + 1) of the (6N + 1)^2 matrix U) are K6-K7's second source.
-int launch_gram_chain(msckf_ctx* c) {
-    const int dc = c->dc, n = dc + 1, nt = (n + 15) / 16, npairs = nt * (nt + 1) / 2;
-    hipStream_t st = c->wide_on_stream2 ? c->stream2 : c->stream;
-    const int G = std::max(1, std::min(c->Fw, 128));
-    if (int rc = ensure(c, c->dGramPart, (size_t)G * npairs * 256 * 8)) return rc;
-    const size_t nn = (size_t)(6 * c->maxN + 1) * (6 * c->maxN + 1) * 8;
-    if (int rc = ensure(c, c->dGramS, nn)) return rc;
-    { const void* before = c->dGramU.p; if (int rc = ensure(c, c->dGramU, nn)) return rc; if (c->dGramU.p != before) c->gram_u_n = -1; }
-    if (int rc = ensure(c, c->dGramL, nn)) return rc;
-    if (int rc = ensure(c, c->dGramInvd, (size_t)(6 * c->maxN + 1) * 8)) return rc;
-    GramArgs g{};
-    g.view_ptr = ptr<int>(c->dViewPtr); g.obs_slot = ptr<int>(c->dObsSlot);
-    g.blk_off = ptr<long long>(c->dBlkOff); g.stack = ptr<double>(c->dStack);
-    g.rank = ptr<int>(c->dRank); g.accepted = ptr<unsigned char>(c->dAcc);
-    g.f0 = c->Fb; g.nf = c->Fw; g.dc = dc; g.nt = nt; g.part = ptr<double>(c->dGramPart);
-    hipLaunchKernelGGL(k_gram, dim3(G), dim3(64 * GRAM_WAVES), gram_lds_bytes(nt), st, g);
-    // k_chol16 writes the factor's upper triangle only; what lies below stays zero from ONE memset per window size (N changes
-    // the layout of U).  The reduction used to zero U in every update: its workgroups run on every XCD, the lines they zeroed
-    // stayed in those L2s, and K6-K7's workgroups there -- reading the factor's rows while k_chol16, beside this launch, was
-    // still writing them through -- were now and then served such a line instead of the row k_chol16 had published
-    // (tools/stress_repeat.py: results that differed from their batch's first, 1 call in 200 - 300000 depending on how much of
-    // the factor is taken while it is made).
-    if (c->gram_u_n != n) {
-        HIPCHK(c, hipMemsetAsync(c->dGramU.p, 0, nn, st));
-        c->gram_u_n = n;
-    }
-    hipLaunchKernelGGL(k_gram_reduce, dim3(npairs), dim3(256), 0, st, ptr<double>(c->dGramPart), G, nt, n, ptr<double>(c->dGramS), (double*)nullptr);
-    HIPCHK(c, hipGetLastError());
-    CholArgs a{};
-    a.S = ptr<double>(c->dGramS); a.lds_ = n; a.L = ptr<double>(c->dGramL); a.U = ptr<double>(c->dGramU);
-    a.invd = ptr<double>(c->dGramInvd); a.n = n; a.work = nullptr; a.status = ptr<int>(c->dStatus) + 1;
-    a.diag_rel = 1e-14;
-    // K6-K7 of THIS update (the next epoch) takes the factor's rows by the count k_chol16 publishes -- inside its launch when the
-    // chain runs beside it on the second stream, and by the same protocol when it ran in front of it (MSCKF_WIDE_STREAM=0)
-    a.done_flag = ptr<unsigned long long>(c->dGsProg) + 16;
-    a.done_val = (unsigned long long)(c->gs_epoch + 1) << 32;
-    hipLaunchKernelGGL(k_chol16, dim3(1), dim3(64 * CHOL16_W), 0, st, a);
-    HIPCHK(c, hipGetLastError());
-    return MSCKF_OK;
-}
-
 // ... and for the ring-buffered root sweeps (k_wsweep form, sweep modes 1 and 2): k_root_gain_w
 bool root_gain_w_ok(const msckf_ctx* c, int band) {
     return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 3 * (SWEEP_NW - 1);
@@ -1597,13 +1653,13 @@ int launch_root_and_gain_w(msckf_ctx* c, int node, int nsteps, int rc_log2, cons
 int gate_counts(msckf_ctx* c, int out[4], std::vector<unsigned char>* acc_sorted, bool copied = false) {
     out[0] = out[1] = out[2] = out[3] = 0;
     if (c->F == 0) return MSCKF_OK;
-    const size_t F = c->F;
+    const size_t F = c->F, Fs = c->Fs;          // (the blocks of split long tracks sit behind the F tracks: not counted)
     if (!copied) {
-        HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, F * 5, hipMemcpyDeviceToHost, c->stream));   // rank | accepted
+        HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, Fs * 5, hipMemcpyDeviceToHost, c->stream));   // rank | accepted
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     const int* rk = static_cast<const int*>(c->hGate);
-    const unsigned char* acc = static_cast<const unsigned char*>(c->hGate) + F * 4;
+    const unsigned char* acc = static_cast<const unsigned char*>(c->hGate) + Fs * 4;
     for (int s = 0; s < c->F; ++s) {
         if (acc[s] == 1) { out[0]++; out[1] += 2 * (c->h_view_sorted[s + 1] - c->h_view_sorted[s]) - rk[s]; }
         else if (acc[s] == 2) out[2]++;
@@ -1623,16 +1679,26 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (!c->feature_launched && (rc = launch_feature(c)) != MSCKF_OK) return rc;
     c->feature_launched = false;
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
+    // split long tracks: their remainder blocks' tree follows k_feature<64, true> on the second stream, beside the band
+    // pipeline; the leaves below read the narrow blocks that kernel wrote
+    const bool chain = c->F > 0 && c->wide_active && c->rroot >= 0;
+    if (chain) {
+        hipStream_t rs = c->wide_on_stream2 ? c->stream2 : c->stream;
+        // (the tree reads the plan's tables and writes the workspace: behind their upload / memset, which the main stream is
+        //  behind by now -- ev_plan, set_features)
+        if (c->wide_on_stream2) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+        if ((rc = launch_fold_levels(c, c->rlevels, c->rnodes, rs, ptr<FoldNode>(c->dRNodes))) != MSCKF_OK) return rc;
+        if (c->wide_on_stream2) HIPCHK(c, hipEventRecord(c->ev_rem, c->stream2));
+    }
+    if (c->F > 0 && c->wide_on_stream2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wfeat, 0));
     if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c)) != MSCKF_OK) return rc;
     if (c->F > 0 && !c->band_plan && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
-    if (c->F > 0 && c->wide_on_stream2 && !c->wide_active)               // (one plan for every track after all: its leaves read the wide blocks)
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wfeat, 0));
-    if (c->F > 0 && c->wide_active && (rc = launch_gram_chain(c)) != MSCKF_OK) return rc;
     // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront and the update's strips in ONE launch
-    const bool have_rows = c->root >= 0 || c->wide_active;
+    const bool direct = c->F > 0 && c->wide_active && c->rem_direct;      // (the dense remainder rows: K6-K7's second source, taken first)
+    const bool have_rows = c->root >= 0 || chain || direct;
     const bool gs = with_gain && c->F > 0 && have_rows && gstream_ok(c, c->root_band);
-    if (c->wide_active && !gs) { c->last_error = "wide tracks need the streamed K6-K7"; return MSCKF_ERR_STATE; }
+    if (chain && with_gain && !gs) { c->last_error = "split long tracks need the streamed K6-K7"; return MSCKF_ERR_STATE; }
     const bool beside = gs && c->band_plan && c->root >= 0 &&
                         (c->sweep_mode == 0 ? (!c->h_root_flush.empty() && root_gain_ok(c, c->root_band)) : root_gain_w_ok(c, c->root_band));
     const bool streamed = beside && c->sweep_mode == 0 && c->root_streamed;     // the last merge level rides in the root's launch
@@ -1679,6 +1745,10 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
             else rc = launch_gain(c, root_block(c));
             if (rc != MSCKF_OK) return rc;
         }
+    }
+    if (chain && with_gain) {              // the remainder blocks' rows: a second update behind the first
+        if (c->wide_on_stream2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rem, 0));
+        if ((rc = launch_gain_chain(c, ptr<double>(c->dRbuf) + c->rroot_off)) != MSCKF_OK) return rc;
     }
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[3], c->stream));
     c->ran = true;
@@ -1751,6 +1821,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     for (auto& e : c->ev) CK(hipEventCreate(&e), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_wfeat, hipEventDisableTiming), "hipEventCreate");
+    CK(hipEventCreateWithFlags(&c->ev_rem, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_plan_up, hipEventDisableTiming), "hipEventCreate");
     CK(hipEventCreateWithFlags(&c->ev_state, hipEventDisableTiming), "hipEventCreate");
@@ -1784,7 +1855,6 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_sweep<SWEEP_NW_BIG, 1>), FOLD_LDS_BYTES, "k_sweep<12> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain<SWEEP_NW, 2>), LDS_MAX_BYTES - 1024, "k_root_gain LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_m<SWEEP_NW, SWEEP_NW_MID, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_m LDS attribute");
-    lds_attr(reinterpret_cast<const void*>(&k_gram), LDS_MAX_BYTES - 1024, "k_gram LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 3>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 6, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
@@ -1828,7 +1898,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         seat_result_views(c);
         bool ok = hipHostMalloc(&c->hPose, (size_t)24 * N * 8) == hipSuccess &&
                   hipHostMalloc(&c->hRes, c->res_cap) == hipSuccess &&
-                  hipHostMalloc(&c->hGate, (size_t)5 * std::max(c->maxF, 1)) == hipSuccess &&
+                  hipHostMalloc(&c->hGate, (c->hGateCap = (size_t)5 * std::max(c->maxF, 1))) == hipSuccess &&
                   hipHostMalloc(&c->hP, (size_t)d * d * 8) == hipSuccess;
         if (!ok) rc = MSCKF_ERR_HIP;
     }
@@ -1840,8 +1910,9 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     E(c->dCholWork, (size_t)dc * (dc + 1) / 2 * 8);
     {   // k_gain_stream: exchange tiles and (epoch-tagged, hence zeroed once) flags, the root sweep's progress word
         const size_t nbm = (size_t)(dc + 15) / 16, nsm = nbm + 1;
-        E(c->dGsEx, 2 * nbm * nsm * 256 * 8);          // (two sources of row blocks: the band root and the wide tracks' factor)
-        E(c->dGsFlag, (2 * nbm * nsm + 8) * 8, true);
+        E(c->dGsEx, (nbm + GS_MAX_NB2) * nsm * 256 * 8);      // (two sources of row blocks: the band root and the remainder rows of split long tracks)
+        E(c->dRem, 16 * (size_t)GS_MAX_NB2 * (dc + 1) * 8);   // the dense remainder rows (k_rem_scatter)
+        E(c->dGsFlag, ((nbm + GS_MAX_NB2) * nsm + 8) * 8, true);
         E(c->dMProg, 512, true);                       // (progress words of the merge workgroups inside k_root_gain's launch)
         E(c->dGsProg, 512, true);                      // (progress word at 0, k_root_gain's time stamps on a line of their own at byte 256)
     }
@@ -1906,13 +1977,14 @@ void msckf_destroy(msckf_ctx* c) {
                   &c->dLineBase, &c->dLineDir, &c->dLineConf, &c->dLostFor, &c->dTrackedFor, &c->dSelFlags, &c->dWorld,
                   &c->dFlush, &c->dFlushOff, &c->dFeatInfo, &c->dCommBuf, &c->dAssocUV, &c->dAssocRes,
                   &c->dGsEx, &c->dGsFlag, &c->dGsProg, &c->dMProg, &c->dMFlush, &c->dRootFlush, &c->dXRootFlush,
-                  &c->dGramPart, &c->dGramS, &c->dGramU, &c->dGramL, &c->dGramInvd};
+                  &c->dSplit, &c->dRem};
     for (Buf* b : all) if (b->p && !b->view) (void)hipFree(b->p);
     for (Buf* b : {&c->dPoseArena, &c->dFeatArena, &c->dRawArena, &c->dResArena, &c->dGateArena, &c->dPlanArena}) if (b->p) (void)hipFree(b->p);
     for (void* h : {c->hPose, c->hFeat, c->hRes, c->hGate, c->hP}) if (h) (void)hipHostFree(h);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_wfeat) (void)hipEventDestroy(c->ev_wfeat);
+    if (c->ev_rem) (void)hipEventDestroy(c->ev_rem);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
     if (c->ev_plan_up) (void)hipEventDestroy(c->ev_plan_up);
@@ -1985,6 +2057,8 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->sumM = 0; c->Mmax = 0; c->nodes.clear(); c->levels.clear(); c->snodes.clear(); c->sfolds.clear(); c->sweep_levels.clear(); c->n_group_merges = 0;
         c->band_plan = false; c->root = -1; c->perm.clear();
         c->Fb = c->Fw = c->Fw1 = 0; c->wide_active = false;
+        c->Fs = 0; c->nNarrow = 0; c->sumMs = 0; c->split_on = false; c->rem_cap = 0; c->rem_direct = false; c->h_split.clear(); c->h_parent.clear();
+        c->rnodes.clear(); c->rlevels.clear(); c->rroot = -1;
         c->plan_valid = false;
         c->xchg_planned = false;
         if (c->xchg) {
@@ -2022,21 +2096,16 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const size_t r_uv = 0, r_base = r_uv + (size_t)sumM * 16, r_m = r_base + (size_t)F * 24, r_rho = r_m + (size_t)F * 24;
     const size_t r_slot = r_rho + (size_t)F * 8;
     const size_t raw_bytes = (r_slot + (size_t)sumM * 4 + 15) & ~(size_t)15;
-    // sorted image (what the kernels read), written by k_gather
-    const size_t o_uv = 0, o_base = o_uv + (size_t)sumM * 16, o_m = o_base + (size_t)F * 24, o_rho = o_m + (size_t)F * 24;
-    const size_t o_blk = o_rho + (size_t)F * 8, o_view = o_blk + (size_t)F * 8;
-    const size_t o_perm = o_view + (((size_t)(F + 1) * 4 + 7) & ~(size_t)7);                  // sorted position -> input index
-    const size_t o_slot = (o_perm + (size_t)F * 4 + 7) & ~(size_t)7, o_fmin = o_slot + (((size_t)sumM * 4 + 7) & ~(size_t)7);
-    const size_t o_info = (o_fmin + (size_t)F * 4 + 15) & ~(size_t)15;                    // FeatInfo records (16-byte aligned)
-    const size_t feat_bytes = o_info + (size_t)F * sizeof(FeatInfo);
-    const size_t pin_bytes = raw_bytes + (size_t)F * sizeof(GatherRec);                   // the sort's records behind the arrays
+    // the sort's records behind the arrays: one per entry of the sorted arrays (the tracks and, for long tracks that are split,
+    // their blocks: at most 7 per track of 11+ views, i.e. fewer than sumM) and one SplitRec per long track
+    const size_t rec_cap = (size_t)F + (size_t)sumM * 7 / 11 + 8;
+    const size_t pin_bytes = raw_bytes + rec_cap * sizeof(GatherRec) + ((size_t)sumM / 11 + 1) * sizeof(SplitRec);
     if (c->hFeatCap < pin_bytes) {
         if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
         c->hFeat = nullptr; c->hFeatCap = 0;
         HIPCHK(c, hipHostMalloc(&c->hFeat, pin_bytes + pin_bytes / 2));
         c->hFeatCap = pin_bytes + pin_bytes / 2;
     }
-    if (int rca = ensure(c, c->dFeatArena, feat_bytes)) return rca;
     // small batches: the small arrays reach HBM through a copy KERNEL reading the pinned image (k_stage) and k_gather reads the
     // sort's records from it (zero-copy) -- no copy command but the observations', none of the ~9 us each one waits behind its
     // predecessor; large ones: DMA, beside the host's sort (measured at 10000 tracks: zero-copy 620 us per call, DMA 578)
@@ -2053,16 +2122,17 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     if (c->state_pending) { HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_state, 0)); c->state_pending = false; }
     // validate + first/last slot of each track + sort key (feature ranges on the host pool; the lowest failing range decides
     // the code), and the range's share of the remaining arrays into the pinned image
-    // key = (class, first slot, last slot); class 0: band tracks; 1: wide tracks of up to 15 views (k_feature<32>); 2: wide tracks
-    // of 16+ views (k_feature<64>) -- wide = wider than the band pipeline takes, where the information form is available (k_gram.h)
-    const bool wide = wide_ok(c, N);
+    // key = (class, first slot, last slot); class 0: tracks of up to WIDE_SPAN clone slots (and long ones that cannot be split:
+    // views out of slot order, more than SPLIT_MAXG groups, more views than k_feature<64> holds); class 2: long tracks, split
+    const bool split = split_ok(c, N);
     const size_t NN = (size_t)N * N;
     std::vector<int> key_in(F);
     std::vector<unsigned char> M_in(F);
     int Mmax = 0, Mmax_cls[3] = {0, 0, 0};
+    int n_mid = 0, n_long = 0;               // tracks of 11 - 15 slots / of more (any class)
     {
         const int nch = par ? std::min(4 * (c->pool->workers() + 1), (F + 255) / 256) : 1;
-        std::vector<int> ch_err(nch, MSCKF_OK), ch_mmax(3 * nch, 0);
+        std::vector<int> ch_err(nch, MSCKF_OK), ch_mmax(5 * nch, 0);
         const int maxM = c->maxM;
         auto validate = [&](int ch) {
             const int f0 = (int)((long long)F * ch / nch), f1 = (int)((long long)F * (ch + 1) / nch);
@@ -2071,15 +2141,17 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             std::memcpy(hb + r_base + (size_t)f0 * 24, idp_base + (size_t)f0 * 3, (size_t)(f1 - f0) * 24);
             std::memcpy(hb + r_m + (size_t)f0 * 24, idp_m + (size_t)f0 * 3, (size_t)(f1 - f0) * 24);
             std::memcpy(hb + r_rho + (size_t)f0 * 8, idp_rho + f0, (size_t)(f1 - f0) * 8);
-            int mm[3] = {0, 0, 0};
+            int mm[3] = {0, 0, 0}, nmid = 0, nlong = 0;
             for (int f = f0; f < f1; ++f) {
                 const int a = view_ptr[f], b = view_ptr[f + 1], M = b - a;
                 if (M < 1 || M > maxM) { ch_err[ch] = MSCKF_ERR_ARG; return; }
                 int lo = N, hi = -1;
+                bool ordered = true;
                 unsigned long long seen = 0;    // N <= 64 fast path; general check below
                 for (int i = a; i < b; ++i) {
                     const int sl = obs_slot[i];
                     if (sl < 0 || sl >= N) { ch_err[ch] = MSCKF_ERR_ARG; return; }
+                    if (sl < hi) ordered = false;
                     lo = std::min(lo, sl); hi = std::max(hi, sl);
                     if (N <= 64) {
                         if (seen & (1ull << sl)) { ch_err[ch] = MSCKF_ERR_DUP_SLOT; return; }
@@ -2088,19 +2160,29 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
                         for (int k = a; k < i; ++k) if (obs_slot[k] == sl) { ch_err[ch] = MSCKF_ERR_DUP_SLOT; return; }
                     }
                 }
-                const int cls = (wide && hi - lo + 1 > WIDE_SPAN) ? (M > 15 ? 2 : 1) : 0;
+                const int span = hi - lo + 1;
+                if (span > 15) ++nlong; else if (span > WIDE_SPAN) ++nmid;
+                const int cls = (split && span > WIDE_SPAN && ordered && M <= 31 && (span + SPLIT_GSLOTS - 1) / SPLIT_GSLOTS <= SPLIT_MAXG) ? 2 : 0;
                 key_in[f] = (int)(cls * NN + (size_t)lo * N + hi);
                 M_in[f] = (unsigned char)M;
                 mm[cls] = std::max(mm[cls], M);
             }
-            for (int k = 0; k < 3; ++k) ch_mmax[3 * ch + k] = mm[k];
+            for (int k = 0; k < 3; ++k) ch_mmax[5 * ch + k] = mm[k];
+            ch_mmax[5 * ch + 3] = nmid; ch_mmax[5 * ch + 4] = nlong;
         };
         if (nch > 1) c->pool->run(nch, validate); else validate(0);
         for (int ch = 0; ch < nch; ++ch) {
             if (ch_err[ch] != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); return ch_err[ch]; }      // (the pinned image is in flight)
-            for (int k = 0; k < 3; ++k) Mmax_cls[k] = std::max(Mmax_cls[k], ch_mmax[3 * ch + k]);
+            for (int k = 0; k < 3; ++k) Mmax_cls[k] = std::max(Mmax_cls[k], ch_mmax[5 * ch + k]);
+            n_mid += ch_mmax[5 * ch + 3]; n_long += ch_mmax[5 * ch + 4];
         }
         Mmax = std::max(Mmax_cls[0], std::max(Mmax_cls[1], Mmax_cls[2]));
+    }
+    // A batch MOST of whose tracks span 11 - 15 slots and none more (BASELINE configs[4]: every track 15 views) keeps the
+    // 90-column band pipeline for all of them: split, each would leave 3 remainder rows to the dense tree
+    if (Mmax_cls[2] > 0 && n_long == 0 && 2 * n_mid > F) {
+        for (int f = 0; f < F; ++f) key_in[f] = (int)((size_t)key_in[f] % NN);
+        Mmax_cls[0] = Mmax; Mmax_cls[2] = 0;
     }
     if (!zc) HIPCHK(c, hipMemcpyAsync(draw + r_base, hb + r_base, raw_bytes - r_base, hipMemcpyHostToDevice, c->stream));
     else {
@@ -2111,10 +2193,12 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const double tv = now_us();
     if (c->n_chi2 <= 2 * Mmax) { (void)hipStreamSynchronize(c->stream); return MSCKF_ERR_ARG; }
     c->F = F; c->sumM = sumM; c->Mmax = Mmax;            // validated: commit the batch size
-    // counting sort by the key: stable, O(F + N^2); the band tracks first, the wide ones behind them
+    // counting sort by the key: stable, O(F + N^2); the short tracks first, the long ones behind them
     c->perm.resize(F);
-    std::vector<int> h_view(F + 1), h_fmin(F), h_fmax(F);
+    std::vector<int> h_view, h_fmin(F), h_fmax(F);
     long long blk = 0;
+    int Fs = F, sumMs = sumM;
+    GatherRec* rec = reinterpret_cast<GatherRec*>(hb + raw_bytes);
     {
         std::vector<int> cnt(3 * NN + 1, 0);
         for (int f = 0; f < F; ++f) cnt[key_in[f] + 1]++;
@@ -2128,50 +2212,133 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             pos += n;
         }
         for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
-        c->Fb = cnt[NN];                                                  // band tracks: sorted positions [0, Fb)
-        c->Fw1 = cnt[2 * NN] - c->Fb;                                     // wide, <= 15 views: [Fb, Fb + Fw1)
-        c->Fw = F - c->Fb;                                                // all wide tracks: [Fb, F)
+        c->Fb = cnt[NN];                                                  // short tracks: sorted positions [0, Fb)
+        c->Fw1 = 0;
+        c->Fw = F - c->Fb;                                                // long tracks, split: [Fb, F)
         int* perm = c->perm.data();
         for (int f = 0; f < F; ++f) perm[cnt[key_in[f]]++] = f;
-        c->Mmax_band = Mmax_cls[0]; c->Mmax_w1 = Mmax_cls[1]; c->Mmax_wide = Mmax_cls[2];
+        c->Mmax_band = Mmax_cls[0]; c->Mmax_w1 = 0; c->Mmax_wide = Mmax_cls[2];
+        c->split_on = c->Fw > 0;
+        // ---- the blocks of the long tracks (k_feature.h): view groups of at most SPLIT_GSLOTS slots -> narrow blocks, one
+        //      remainder block per track
+        c->h_split.clear(); c->h_parent.clear();
+        struct Blk { int parent, f, a, M, lo, hi, pi, g; };
+        std::vector<Blk> narrow, wide;
+        int rem_cap = 0;
+        if (c->split_on) {
+            c->h_split.resize(c->Fw);
+            for (int sidx = c->Fb; sidx < F; ++sidx) {
+                const int f = perm[sidx], a = view_ptr[f], M = M_in[f], lo = h_fmin[sidx], hi = h_fmax[sidx];
+                const int span = hi - lo + 1, ng0 = (span + SPLIT_GSLOTS - 1) / SPLIT_GSLOTS, pi = sidx - c->Fb;
+                SplitRec sr{};
+                for (int g = 0; g < SPLIT_MAXG; ++g) sr.child[g] = -1;
+                int ng = 0, v = 0;
+                for (int g0 = 0; g0 < ng0; ++g0) {
+                    const int bnd = lo + (int)(((long long)(g0 + 1) * span) / ng0);       // slots [.., bnd): at most ceil(span / ng0) <= 10 of them
+                    const int v0 = v;
+                    while (v < M && obs_slot[a + v] < bnd) ++v;
+                    if (v == v0) continue;                                 // no view in this stretch of slots
+                    sr.gv[ng] = (unsigned char)v0;
+                    if (v - v0 >= 2) narrow.push_back({sidx, f, a + v0, v - v0, obs_slot[a + v0], obs_slot[a + v - 1], pi, ng});
+                    ++ng;
+                }
+                sr.gv[ng] = (unsigned char)M; sr.ng = (unsigned char)ng;
+                sr.row0 = rem_cap; rem_cap += 3 * ng;
+                c->h_split[pi] = sr;
+                wide.push_back({sidx, f, a, M, lo, hi, pi, -1});
+            }
+            // the narrow blocks among themselves by (first slot, last slot): the band plan walks them as a second run
+            std::vector<int> cn(NN + 1, 0);
+            for (const Blk& b : narrow) cn[(size_t)b.lo * N + b.hi + 1]++;
+            for (size_t i = 1; i < cn.size(); ++i) cn[i] += cn[i - 1];
+            std::vector<Blk> sorted(narrow.size());
+            for (const Blk& b : narrow) sorted[cn[(size_t)b.lo * N + b.hi]++] = b;
+            narrow.swap(sorted);
+        }
+        c->nNarrow = (int)narrow.size();
+        c->rem_cap = rem_cap;
+        // (K6-K7 takes 16 dense rows in ~5 us; a merge tree over them is a leaf of ~100 us and ~170 us per level: the tree pays
+        //  beyond some 2000 rows)
+        c->rem_direct = c->split_on && rem_cap <= c->rem_direct_max;
+        Fs = F + (int)narrow.size() + (int)wide.size();
+        h_view.resize(Fs + 1); h_fmin.resize(Fs); h_fmax.resize(Fs);
+        c->h_parent.resize(Fs - F);
         // the sorted CSR offsets and the offsets of the K4 blocks: a prefix over the sorted order; k_gather's records
-        GatherRec* rec = reinterpret_cast<GatherRec*>(hb + raw_bytes);
         int pos = 0;
         for (int sidx = 0; sidx < F; ++sidx) {
             const int f = perm[sidx], M = M_in[f];
             h_view[sidx] = pos;
-            rec[sidx] = GatherRec{f, view_ptr[f], M, pos, blk};
-            blk += (long long)(6 * M + 1) * (2 * M);
+            const bool parent = c->split_on && sidx >= c->Fb;              // (a split track has no block of its own)
+            rec[sidx] = GatherRec{f, view_ptr[f], M, pos, parent ? 0 : blk};
+            if (!parent) blk += (long long)(6 * M + 1) * (2 * M);
             pos += M;
         }
-        h_view[F] = pos;
+        int e = F;
+        for (const Blk& b : narrow) {
+            h_view[e] = pos; h_fmin[e] = b.lo; h_fmax[e] = b.hi; c->h_parent[e - F] = b.parent;
+            rec[e] = GatherRec{b.f, b.a, b.M, pos, blk};
+            c->h_split[b.pi].child[b.g] = e;
+            blk += (long long)(6 * b.M + 1) * (2 * b.M);
+            pos += b.M; ++e;
+        }
+        for (const Blk& b : wide) {
+            h_view[e] = pos; h_fmin[e] = b.lo; h_fmax[e] = b.hi; c->h_parent[e - F] = b.parent;
+            rec[e] = GatherRec{b.f, b.a, b.M, pos, blk};
+            c->h_split[b.pi].wide = e;
+            blk += (long long)(6 * b.M + 1) * (3 * SPLIT_MAXG);
+            pos += b.M; ++e;
+        }
+        h_view[Fs] = pos;
+        sumMs = pos;
     }
+    c->Fs = Fs; c->sumMs = sumMs;
+    const size_t split_off = raw_bytes + (((size_t)Fs * sizeof(GatherRec) + 15) & ~(size_t)15);
+    if (c->split_on) std::memcpy(hb + split_off, c->h_split.data(), c->h_split.size() * sizeof(SplitRec));
     c->h_view_sorted = h_view;
     c->h_view_in.assign(view_ptr, view_ptr + F + 1);
     c->h_fmin = h_fmin; c->h_fmax = h_fmax;
     const double ts = now_us(), t1 = ts;
 
-    set_view(c->dObsUV, c->dFeatArena.p, o_uv, (size_t)sumM * 16);
-    set_view(c->dBase, c->dFeatArena.p, o_base, (size_t)F * 24);
-    set_view(c->dMvec, c->dFeatArena.p, o_m, (size_t)F * 24);
-    set_view(c->dRho, c->dFeatArena.p, o_rho, (size_t)F * 8);
-    set_view(c->dBlkOff, c->dFeatArena.p, o_blk, (size_t)F * 8);
-    set_view(c->dViewPtr, c->dFeatArena.p, o_view, (size_t)(F + 1) * 4);
-    set_view(c->dObsSlot, c->dFeatArena.p, o_slot, (size_t)sumM * 4);
-    set_view(c->dFmin, c->dFeatArena.p, o_fmin, (size_t)F * 4);
-    set_view(c->dFeatInfo, c->dFeatArena.p, o_info, (size_t)F * sizeof(FeatInfo));
-    set_view(c->dPerm, c->dFeatArena.p, o_perm, (size_t)F * 4);
-    // gate results: rank[F] (int) then accepted[F] (byte), contiguous so they come back in one copy
-    set_view(c->dRank, c->dGateArena.p, 0, (size_t)F * 4);
-    set_view(c->dAcc, c->dGateArena.p, (size_t)F * 4, (size_t)F);
+    // sorted image (what the kernels read), written by k_gather: Fs entries, sumMs views
+    const size_t o_uv = 0, o_base = o_uv + (size_t)sumMs * 16, o_m = o_base + (size_t)Fs * 24, o_rho = o_m + (size_t)Fs * 24;
+    const size_t o_blk = o_rho + (size_t)Fs * 8, o_view = o_blk + (size_t)Fs * 8;
+    const size_t o_perm = o_view + (((size_t)(Fs + 1) * 4 + 7) & ~(size_t)7);                  // sorted position -> input index
+    const size_t o_slot = (o_perm + (size_t)Fs * 4 + 7) & ~(size_t)7, o_fmin = o_slot + (((size_t)sumMs * 4 + 7) & ~(size_t)7);
+    const size_t o_info = (o_fmin + (size_t)Fs * 4 + 15) & ~(size_t)15;                   // FeatInfo records (16-byte aligned)
+    const size_t feat_bytes = o_info + (size_t)Fs * sizeof(FeatInfo);
+    if (c->dFeatArena.bytes < feat_bytes && c->run_pending) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->run_pending = false; }
+    if (int rca = ensure(c, c->dFeatArena, feat_bytes)) return rca;
+    set_view(c->dObsUV, c->dFeatArena.p, o_uv, (size_t)sumMs * 16);
+    set_view(c->dBase, c->dFeatArena.p, o_base, (size_t)Fs * 24);
+    set_view(c->dMvec, c->dFeatArena.p, o_m, (size_t)Fs * 24);
+    set_view(c->dRho, c->dFeatArena.p, o_rho, (size_t)Fs * 8);
+    set_view(c->dBlkOff, c->dFeatArena.p, o_blk, (size_t)Fs * 8);
+    set_view(c->dViewPtr, c->dFeatArena.p, o_view, (size_t)(Fs + 1) * 4);
+    set_view(c->dObsSlot, c->dFeatArena.p, o_slot, (size_t)sumMs * 4);
+    set_view(c->dFmin, c->dFeatArena.p, o_fmin, (size_t)Fs * 4);
+    set_view(c->dFeatInfo, c->dFeatArena.p, o_info, (size_t)Fs * sizeof(FeatInfo));
+    set_view(c->dPerm, c->dFeatArena.p, o_perm, (size_t)Fs * 4);
+    // gate results: rank[Fs] (int) then accepted[Fs] (byte), contiguous so they come back in one copy
+    if ((size_t)5 * Fs > c->dGateArena.bytes || (size_t)5 * Fs > c->hGateCap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (int rcg = ensure(c, c->dGateArena, (size_t)8 * Fs)) return rcg;
+        if (c->hGate) HIPCHK(c, hipHostFree(c->hGate));
+        c->hGate = nullptr; c->hGateCap = 0;
+        HIPCHK(c, hipHostMalloc(&c->hGate, (size_t)8 * Fs));
+        c->hGateCap = (size_t)8 * Fs;
+    }
+    set_view(c->dRank, c->dGateArena.p, 0, (size_t)Fs * 4);
+    set_view(c->dAcc, c->dGateArena.p, (size_t)Fs * 4, (size_t)Fs);
     int rc = MSCKF_OK;
     auto E = [&](Buf& b, size_t bytes, bool z = false) { if (rc == MSCKF_OK) rc = ensure(c, b, bytes, z); };
     const size_t stack_es = c->cfg.dtype == MSCKF_DTYPE_F32 ? 4 : 8;
     E(c->dStack, ((size_t)blk + 8) * stack_es); E(c->dGamma, (size_t)F * 8);
+    if (c->split_on) E(c->dSplit, c->h_split.size() * sizeof(SplitRec));
     c->stack_elems = blk;
     if (rc != MSCKF_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
     // the permutation on the device; in the one-shot call K1-K4 starts behind it while the host plans K5
-    if (!zc) HIPCHK(c, hipMemcpyAsync(draw + raw_bytes, hb + raw_bytes, (size_t)F * sizeof(GatherRec), hipMemcpyHostToDevice, c->stream));
+    if (!zc) HIPCHK(c, hipMemcpyAsync(draw + raw_bytes, hb + raw_bytes, (size_t)Fs * sizeof(GatherRec), hipMemcpyHostToDevice, c->stream));
+    if (c->split_on) HIPCHK(c, hipMemcpyAsync(c->dSplit.p, hb + split_off, c->h_split.size() * sizeof(SplitRec), hipMemcpyHostToDevice, c->stream));
     if (c->oneshot) HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     {
         GatherArgs g;
@@ -2182,8 +2349,8 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         g.uv = ptr<double>(c->dObsUV); g.base = ptr<double>(c->dBase); g.m = ptr<double>(c->dMvec); g.rho = ptr<double>(c->dRho);
         g.slot = ptr<int>(c->dObsSlot); g.fmin = ptr<int>(c->dFmin); g.view = ptr<int>(c->dViewPtr); g.perm = ptr<int>(c->dPerm);
         g.blk = ptr<long long>(c->dBlkOff); g.info = ptr<FeatInfo>(c->dFeatInfo);
-        g.F = F; g.sumM = sumM;
-        hipLaunchKernelGGL(k_gather, dim3((F + GATHER_THREADS / 32 - 1) / (GATHER_THREADS / 32)), dim3(GATHER_THREADS), 0, c->stream, g);
+        g.F = Fs; g.sumM = sumMs;
+        hipLaunchKernelGGL(k_gather, dim3((Fs + GATHER_THREADS / 32 - 1) / (GATHER_THREADS / 32)), dim3(GATHER_THREADS), 0, c->stream, g);
         HIPCHK(c, hipGetLastError());
     }
     // (k_lsweep's zero words behind the stack are written by k_feature itself: one launch less in front of it)
@@ -2348,7 +2515,7 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     const double t0 = now_us();
     const size_t d = c->d;
     // gate results and (when the gain stage ran) status | dx | P_out: two copies behind the pipeline, one sync
-    if (c->F > 0 && !c->gate_direct) HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, (size_t)c->F * 5, hipMemcpyDeviceToHost, c->stream));
+    if (c->F > 0 && !c->gate_direct) HIPCHK(c, hipMemcpyAsync(c->hGate, c->dGateArena.p, (size_t)c->Fs * 5, hipMemcpyDeviceToHost, c->stream));
     const bool direct = c->res_direct && c->direct_serial == c->run_serial;     // (a merge behind the update wrote the HBM arena only)
     if (c->ran_gain && !direct) {
         const size_t bytes = P_out ? c->res_p_off + d * d * 8 : c->res_dx_off + d * 8;
@@ -2368,20 +2535,11 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
     if (!(c->ran_gain && n_acc > 0)) status[0] = status[1] = 0;
     int rc = (n_acc == 0) ? MSCKF_NOOP : MSCKF_OK;
     if (rc == MSCKF_OK && c->ran_gain && (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0))) rc = MSCKF_ERR_NOT_SPD;
-    if (rc == MSCKF_ERR_NOT_SPD && c->wide_active && !c->no_wide && c->have_features) {
-        // The wide tracks' Gram matrix did not factor (status word 1), or the update met a non-positive pivot on its rows (word 0):
-        // with few rows (a small batch, or one the gate thinned out) its rank is far below 6N + 1 and the shift 1e-14 trace / n
-        // does not carry that many pivots through rounding.  Every track through the Householder plans instead (the update the
-        // reference computes exists: its S = T P T^T + sigma^2 I is SPD regardless).
-        if (int r2 = replan_no_wide(c)) return r2;
-        if (int r2 = run_pipeline(c, true, nullptr)) return r2;
-        return msckf_get_result(c, dx, P_out, accepted, st);
-    }
     if (rc == MSCKF_ERR_NOT_SPD && status[0] == 3) {       // the mirror of the status word in host memory was never written
         c->last_error = "K6-K7 did not report a status";
         rc = MSCKF_ERR_HIP;
     }
-    if (rc == MSCKF_ERR_NOT_SPD && status[0] == 2) {       // k_gain_stream gave up waiting for rows of T or for another workgroup
+    if (rc == MSCKF_ERR_NOT_SPD && (status[0] == 2 || (c->wide_active && status[1] == 2))) {       // k_gain_stream gave up waiting for rows of T or for another workgroup
         c->last_error = "k_gain_stream: timeout (the root sweep or a workgroup of the update did not make progress)";
         rc = MSCKF_ERR_HIP;
     }
@@ -2435,12 +2593,7 @@ int msckf_commit_covariance(msckf_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const int n_acc = c->acc_from_dev ? status[2] : (c->acc_override >= 0) ? c->acc_override : counters[0];
     if (n_acc == 0) return MSCKF_NOOP;
-    if (c->wide_active && !c->no_wide && (status[1] != 0 || status[0] == 1) && c->have_features) {      // (msckf_get_result's fallback, for callers that commit unseen)
-        if (int r2 = replan_no_wide(c)) return r2;
-        if (int r2 = run_pipeline(c, true, nullptr)) return r2;
-        return msckf_commit_covariance(c);
-    }
-    if (status[0] == 2) return MSCKF_ERR_HIP;                                  // k_gain_stream timed out
+    if (status[0] == 2 || (c->wide_active && status[1] == 2)) return MSCKF_ERR_HIP;   // k_gain_stream timed out
     if (status[0] != 0 || ((c->gain_blocked || c->wide_active) && status[1] != 0)) return MSCKF_ERR_NOT_SPD;
     HIPCHK(c, hipMemcpyAsync(c->dP.p, c->dPout.p, (size_t)c->d * c->d * 8, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2492,7 +2645,7 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
         HIPCHK(c, hipEventSynchronize(c->ev_gate));
         const int Fn = c->F;
         const int* rk = static_cast<const int*>(c->hGate);
-        const unsigned char* acc = static_cast<const unsigned char*>(c->hGate) + (size_t)Fn * 4;
+        const unsigned char* acc = static_cast<const unsigned char*>(c->hGate) + (size_t)c->Fs * 4;
         const int* perm = c->perm.data();
         const int* hv = c->h_view_sorted.data();
         int cnt[4] = {0, 0, 0, 0};
@@ -3444,46 +3597,66 @@ int msckf_debug_gate(msckf_ctx* c, double* gamma, int32_t* qdim) {
 }
 
 int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
-    if (!c || !c->ran || (c->root < 0 && !c->wide_active)) return MSCKF_ERR_STATE;
+    if (!c || !c->ran) return MSCKF_ERR_STATE;
+    // split long tracks: K6-K7 took two sources of rows -- the band root and the remainder blocks' rows (as they are, or the root
+    // of their own tree).  For this diagnostic ONE [T | r_n]: the Householder QR of both stacked, on the host.
+    const bool second = c->wide_active && (c->rem_direct || c->rroot >= 0);
+    if (c->root < 0 && !second) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
-    const int dc = c->dc;
-    std::vector<double> blk((size_t)dc * (dc + 1));
-    const double* src = c->root >= 0 ? root_block(c) : ptr<double>(c->dGramU);     // rows 0 .. dc - 1 of the factor: same layout
-    HIPCHK(c, hipMemcpy(blk.data(), src, blk.size() * 8, hipMemcpyDeviceToHost));
-    if (c->root >= 0 && c->wide_active) {
-        // band AND wide tracks: K6-K7 took two sources of rows.  For this diagnostic ONE [T | r_n] with the same Gram matrix:
-        // the Cholesky factor of [R1 r1]^T [R1 r1] + [U z]^T [U z] (shifted like the device's, k_gram.h), on the host
-        const int n = dc + 1;
-        std::vector<double> blk2((size_t)dc * n), G((size_t)n * n, 0.0);
-        HIPCHK(c, hipMemcpy(blk2.data(), c->dGramU.p, blk2.size() * 8, hipMemcpyDeviceToHost));
-        for (const std::vector<double>* B : {&blk, &blk2})
-            for (int k = 0; k < dc; ++k)
-                for (int i = k; i < n; ++i) {
-                    const double a = (*B)[(size_t)k * n + i];
-                    if (a == 0.0) continue;
-                    for (int j = i; j < n; ++j) G[(size_t)i * n + j] += a * (*B)[(size_t)k * n + j];
-                }
-        double tr = 0.0;
-        for (int i = 0; i < n; ++i) tr += G[(size_t)i * n + i];
-        for (int i = 0; i < n; ++i) G[(size_t)i * n + i] += 1e-14 * tr / n;
-        for (int i = 0; i < n; ++i) {                          // upper factor, row by row
-            for (int k = 0; k < i; ++k) {
-                const double u = G[(size_t)k * n + i];
-                if (u == 0.0) continue;
-                for (int j = i; j < n; ++j) G[(size_t)i * n + j] -= u * G[(size_t)k * n + j];
+    const int dc = c->dc, n = dc + 1;
+    std::vector<double> blk((size_t)dc * n, 0.0);
+    if (c->root >= 0) HIPCHK(c, hipMemcpy(blk.data(), root_block(c), blk.size() * 8, hipMemcpyDeviceToHost));
+    if (second) {
+        const int m2 = c->rem_direct ? ((c->rem_cap + 15) & ~15) : dc;
+        const double* src2 = c->rem_direct ? ptr<double>(c->dRem) : ptr<double>(c->dRbuf) + c->rroot_off;
+        std::vector<double> A((size_t)(dc + m2) * n, 0.0);
+        std::memcpy(A.data(), blk.data(), blk.size() * 8);
+        HIPCHK(c, hipMemcpy(A.data() + (size_t)dc * n, src2, (size_t)m2 * n * 8, hipMemcpyDeviceToHost));
+        for (int k = 0; k < dc; ++k) {                          // row k of the triangle and the rows behind it hold column k
+            double nrm2 = A[(size_t)k * n + k] * A[(size_t)k * n + k];
+            for (int i = dc; i < dc + m2; ++i) nrm2 += A[(size_t)i * n + k] * A[(size_t)i * n + k];
+            if (nrm2 == 0.0) continue;
+            const double xk = A[(size_t)k * n + k], nrm = std::sqrt(nrm2), alpha = xk > 0.0 ? -nrm : nrm;
+            const double vk = xk - alpha, beta = 1.0 / (nrm * (nrm + std::fabs(xk)));
+            for (int j = k + 1; j < n; ++j) {
+                double dot = vk * A[(size_t)k * n + j];
+                for (int i = dc; i < dc + m2; ++i) dot += A[(size_t)i * n + k] * A[(size_t)i * n + j];
+                const double w = beta * dot;
+                A[(size_t)k * n + j] -= w * vk;
+                for (int i = dc; i < dc + m2; ++i) A[(size_t)i * n + j] -= w * A[(size_t)i * n + k];
             }
-            const double piv = std::sqrt(std::max(G[(size_t)i * n + i], 1e-300));
-            for (int j = i; j < n; ++j) G[(size_t)i * n + j] /= piv;
+            A[(size_t)k * n + k] = alpha;
+            for (int i = dc; i < dc + m2; ++i) A[(size_t)i * n + k] = 0.0;
         }
-        for (int i = 0; i < dc; ++i)
-            for (int j = 0; j < n; ++j) blk[(size_t)i * n + j] = (j >= i) ? G[(size_t)i * n + j] : 0.0;
+        std::memcpy(blk.data(), A.data(), blk.size() * 8);
     }
     for (int i = 0; i < dc; ++i) {
         if (T) for (int j = 0; j < dc; ++j) T[(size_t)i * dc + j] = (j >= i) ? blk[(size_t)i * (dc + 1) + j] : 0.0;
         if (rn) rn[i] = blk[(size_t)i * (dc + 1) + dc];
     }
+    return MSCKF_OK;
+}
+
+int msckf_debug_split(msckf_ctx* c, int32_t out[8]) {
+    if (!c || !out) return MSCKF_ERR_ARG;
+    if (!c->have_features) return MSCKF_ERR_STATE;
+    out[0] = c->split_on ? c->Fw : 0;
+    out[1] = c->nNarrow;
+    out[2] = c->split_on ? c->rem_cap : 0;
+    out[3] = c->wide_active ? (c->rem_direct ? 1 : (c->rroot >= 0 ? 2 : 0)) : 0;
+    out[4] = (int)c->rlevels.size();
+    out[5] = c->Fs;
+    out[6] = c->band_plan ? 1 : 0;
+    out[7] = c->band_plan ? c->sweep_mode : -1;
+    return MSCKF_OK;
+}
+
+int msckf_debug_set_rem_direct_rows(msckf_ctx* c, int32_t rows) {
+    if (!c) return MSCKF_ERR_ARG;
+    c->rem_direct_max = rows < 0 ? 16 * GS_MAX_NB2 : std::min(rows, 16 * GS_MAX_NB2);
+    c->plan_valid = false;
     return MSCKF_OK;
 }
 
