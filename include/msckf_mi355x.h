@@ -64,10 +64,8 @@ extern "C" {
                                        whenever every track spans <= 15 clone slots,
                                        see msckf_band_rule)                                */
 
-#define MSCKF_FLAG_BAND_ONLY 2      /* K5: no information form (k_gram.h) for tracks of more than
-                                       10 clone slots: tracks of 11 - 15 slots take the 90-column
-                                       band tiles, wider ones the merge tree (as on contexts of more
-                                       than 31 clones, where the information form does not apply)  */
+#define MSCKF_FLAG_BAND_ONLY 2      /* K5: tracks of more than 10 clone slots are NOT split: tracks of
+                                       11 - 15 slots take the 90-column band tiles, wider ones the merge tree  */
 
 #define MSCKF_DTYPE_F64 0
 #define MSCKF_DTYPE_F32 1

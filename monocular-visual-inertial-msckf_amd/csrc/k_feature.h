@@ -106,11 +106,21 @@ __host__ __device__ inline int feature_lds_doubles(int M, bool chunked) {
 
 // ... of the split form (k_feature<64, true>): the chunked layout with a 61-column staging tile (a group has up to 10 views) +
 // V1, V2 rows, Z1, Z2, the view -> group map and the carry list
-__host__ __device__ inline int feature_split_lds_doubles(int M) {
+// nwv > 1: that many wavefronts per track, each with a staging tile of its own (the first also holds the sum of the partial gate
+// matrices and the elimination's tile)
+__host__ __device__ inline int feature_split_estride(int M) {
+    const int R2 = 2 * M;
+    const int cv = feature_chunk_views(M), ld = 6 * (cv > SPLIT_GSLOTS ? cv : SPLIT_GSLOTS) + 1;
+    const int stage = R2 * ld, elim = (R2 + 1) * (R2 + 3);
+    return (stage > elim ? stage : elim) + 8;
+}
+__host__ __device__ inline int feature_split_lds_doubles(int M, int nwv = 1) {
     const int R2 = 2 * M, C6 = 6 * M;
     const int head = (M + 2) / 2 + R2 * 6 + R2 * 3 + 3 * C6;
     const int cv = feature_chunk_views(M), ld = 6 * (cv > SPLIT_GSLOTS ? cv : SPLIT_GSLOTS) + 1;
-    return head + R2 * ld + (R2 + 2) + 8 + 6 * R2 + 6 * C6 + (M + 3 * SPLIT_MAXG + 4) / 2 + 2;
+    const int tail = (R2 + 2) + 8 + 6 * R2 + 6 * C6 + (M + 3 * SPLIT_MAXG + 4) / 2 + 2;
+    if (nwv > 1) return head + nwv * feature_split_estride(M) + tail;
+    return head + R2 * ld + tail;
 }
 
 // The workgroup IS one wavefront (64 threads): its LDS instructions execute in program order, so a phase boundary needs no
@@ -212,18 +222,25 @@ __device__ __forceinline__ void feature_static_for(Fn&& fn) {
     if constexpr (K < KEND) { fn(FTag<K>{}); feature_static_for<K + 1, KEND>(fn); }
 }
 // RMAX > 2 * max track length of the launch (rows of the gate matrix held per lane).
-template <int RMAX, bool SPLIT = false>
-__global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs p) {      // (<24>: <= 168 registers, the LDS footprint allows 12 wavefronts per CU; <32>: 219 registers, 8 per CU -- bounded to 168 it spills and is slower)
+// NWV > 1 (split form only): NWV wavefronts per track -- every wavefront runs K1 / K2 (cheap, all in registers), the view groups
+// (K4) and the gate's column chunks are dealt over the wavefronts, the partial gate matrices are summed through LDS and wavefront
+// 0 eliminates.  For FEW long tracks: one wavefront per track is one wavefront's latency (140 us at 30 views) in front of the
+// band pipeline's leaves.
+template <int RMAX, bool SPLIT = false, int NWV = 1>
+__global__ __launch_bounds__(64 * NWV, NWV > 1 ? 1 : (RMAX <= 24 ? 3 : 2)) void k_feature(FeatureArgs p) {      // (<24>: <= 168 registers, the LDS footprint allows 12 wavefronts per CU; <32>: 219 registers, 8 per CU -- bounded to 168 it spills and is slower)
     // CHUNKED: the gate works on column chunks (tracks of 16+ views, k_feature<64>).  Tracks of up to 15 views keep all 6M
     // columns of E in LDS: 27 KB at 15 views -- five wavefronts per CU instead of the chunked form's nine, and still the
     // faster one since the all-columns form was rebuilt in round 3 (per block at 15 views: 61 us chunked).
     constexpr bool CHUNKED = RMAX > 32;
     static_assert(!SPLIT || CHUNKED, "the split form is an instance of the chunked kernel");
+    static_assert(NWV == 1 || SPLIT, "several wavefronts per track: the split form only");
     constexpr bool ONE_CHUNK = RMAX <= 24;        // k_feature<24>: tracks of up to 10 views, all 60 columns in one chunk
     constexpr int MAXVK = ONE_CHUNK ? 10 : (RMAX - 2) / 2;   // longest track of this instance
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int f = blockIdx.x + p.f0;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = NWV > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const bool wfirst = wv == 0;                   // the wavefront that writes what all of them computed alike
+    auto xsync = [&]() { if constexpr (NWV > 1) __syncthreads(); else wave_sync(); };
     const int v0 = p.view_ptr[f];
     const int M = p.view_ptr[f + 1] - v0;
     const int R2 = 2 * M, C6 = 6 * M;
@@ -232,7 +249,7 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
     double* sV = sA + R2 * 6;              // [R2][3]   Householder vectors
     double* sZ = sV + R2 * 3;              // [3][C6]
 
-    if (f == 0 && lane < 8) {                  // the stack's zero words (saves the host a memset launch in front of this kernel)
+    if (f == 0 && lane < 8 && wfirst) {        // the stack's zero words (saves the host a memset launch in front of this kernel)
         if (p.stack_f32) static_cast<float*>(p.stack)[p.zero_idx + lane] = 0.0f;
         else static_cast<double*>(p.stack)[p.zero_idx + lane] = 0.0;
     }
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         }
     };
     if (p.select && !(p.select[f] & 1)) {      // not in valid_features (MSCKF.py:453-455): no rows, not a rejection
-        if (lane == 0) {
+        if (lane == 0 && wfirst) {
             p.rank[f] = 0; p.gamma[f] = 0.0; p.accepted[f] = 3;
             if (p.acc_h) { p.rank_h[f] = 0; p.acc_h[f] = 3; }
             if constexpr (SPLIT) {
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
     if (lane < R2) {
         const int o = v0 + view;
         const int s = p.obs_slot[o];
-        if ((lane & 1) == 0) sSlot[view] = s;
+        if ((lane & 1) == 0 && wfirst) sSlot[view] = s;
         const double* R = p.cam_R + 9 * s;
         const double* t = p.cam_t + 3 * s;
         const double* R0 = p.cam_R0 + 9 * s;
@@ -397,20 +414,20 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             w0 += dpp_move<0xB1>(w0);
             w1 += dpp_move<0xB1>(w1);
             w2 += dpp_move<0xB1>(w2);
-            if (lane < R2 && (lane & 1) == 0) {
+            if (lane < R2 && (lane & 1) == 0 && wfirst) {
                 const int c = 6 * view + a;
                 sZ[c] = T00 * w0;
                 sZ[C6 + c] = T01 * w0 + T11 * w1;
                 sZ[2 * C6 + c] = T02 * w0 + T12 * w1 + T22 * w2;
             }
         }
-        if (lane < R2) {
+        if (lane < R2 && wfirst) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) sA[lane * 6 + a] = av[a];
             sV[lane * 3 + 0] = vv0; sV[lane * 3 + 1] = vv1; sV[lane * 3 + 2] = vv2;
         }
     }
-    wave_sync();
+    xsync();
 
     if (p.stamps) tq[2] = wall_clock64();
     const int q = R2 - rank;
@@ -648,8 +665,11 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
     } else {
     const int CV = feature_chunk_views(M);   // views per column chunk
     const int ldE = 6 * ((SPLIT && CV < SPLIT_GSLOTS) ? SPLIT_GSLOTS : CV) + 1;
-    double* sE = sZ + 3 * C6;              // [R2][ldE] one column chunk of H_o (K4 staging) / of E = H_o P_sub (gate)
-    double* sRo = sE + R2 * ldE;           // [R2]      r_o
+    // [R2][ldE] one column chunk of H_o (K4 staging) / of E = H_o P_sub (gate): one per wavefront
+    double* sE0 = sZ + 3 * C6;
+    const int estride = NWV > 1 ? feature_split_estride(M) : 0;
+    double* sE = sE0 + wv * estride;
+    double* sRo = NWV > 1 ? sE0 + NWV * estride : sE0 + R2 * ldE;           // [R2]      r_o
     if constexpr (SPLIT) {
         // ---------------- K2 + K4 of a long track: two-level basis, G narrow blocks + one remainder block ----------------
         double* sU = sRo + (R2 + 2);           // [R2][3] level-1 reflectors (V1 rows)
@@ -665,11 +685,11 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             if (view >= sr.gv[g] && view < sr.gv[g + 1]) { grp = g; g0v = sr.gv[g]; }
         const bool inr = lane < R2;
         const int lr = lane - 2 * g0v;         // row within the group
-        if (inr && (lane & 1) == 0) sGrp[view] = grp;
+        if (inr && (lane & 1) == 0 && wfirst) sGrp[view] = grp;
         int ncarry = 0;
         for (int g = 0; g < ng; ++g) {
             const int rows = min(3, 2 * (sr.gv[g + 1] - sr.gv[g]));
-            for (int i = 0; i < rows; ++i) { if (lane == 0) sCarry[ncarry] = 2 * sr.gv[g] + i; ++ncarry; }
+            for (int i = 0; i < rows; ++i) { if (lane == 0 && wfirst) sCarry[ncarry] = 2 * sr.gv[g] + i; ++ncarry; }
         }
         // sums over the rows of ONE group, every lane receiving its own group's (ng <= 6 whole-wave sums)
         auto gsum = [&](double x) -> double {
@@ -723,7 +743,7 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
                 w0 += dpp_move<0xB1>(w0);
                 w1 += dpp_move<0xB1>(w1);
                 w2 += dpp_move<0xB1>(w2);
-                if (inr && (lane & 1) == 0) {
+                if (inr && (lane & 1) == 0 && wfirst) {
                     const int c = 6 * view + a;
                     sZ1[c] = A00 * w0;
                     sZ1[C6 + c] = A01 * w0 + A11 * w1;
@@ -769,13 +789,13 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
         const double B12 = -wb[2] * B11 * e12;
         const double s0 = wave_sum(ww[0] * r1), s1 = wave_sum(ww[1] * r1), s2 = wave_sum(ww[2] * r1);
         const double r2 = r1 - (ww[0] * (B00 * s0) + ww[1] * (B01 * s0 + B11 * s1) + ww[2] * (B02 * s0 + B12 * s1 + B22 * s2));
-        if (inr) {
+        if (inr && wfirst) {
             sU[lane * 3 + 0] = uu[0]; sU[lane * 3 + 1] = uu[1]; sU[lane * 3 + 2] = uu[2];
             sW[lane * 3 + 0] = ww[0]; sW[lane * 3 + 1] = ww[1]; sW[lane * 3 + 2] = ww[2];
         }
-        wave_sync();
+        xsync();
         // Z2 = T2^T (V2^T H1), lanes over the columns: column c of view v meets the (up to three) carry rows of v's group only
-        for (int c = lane; c < C6; c += 64) {
+        for (int c = lane + 64 * wv; c < C6; c += 64 * NWV) {
             const int v = c / 6, a = c - 6 * v, g = sGrp[v];
             const int L0 = 2 * sr.gv[g], rows = min(3, 2 * (sr.gv[g + 1] - sr.gv[g]));
             const double z0 = sZ1[c], z1 = sZ1[C6 + c], z2 = sZ1[2 * C6 + c];
@@ -790,14 +810,14 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             sZ2[C6 + c] = B01 * t0 + B11 * t1;
             sZ2[2 * C6 + c] = B02 * t0 + B12 * t1 + B22 * t2;
         }
-        wave_sync();
+        xsync();
         // K4: one group of columns at a time through the staging tile (lanes over rows), then out as contiguous row segments:
         // group g's narrow block (its rows 3.., its columns + r1) and the remainder block's columns of the group (the carry
         // rows behind the `rank` pivot rows, + r2 with the last group)
         n_wide_rows = ncarry - rank;
         const int ldw = C6 + 1;
         const long long wide_off = p.blk_off[sr.wide];
-        for (int g = 0; g < ng; ++g) {
+        for (int g = wv; g < ng; g += NWV) {            // (the groups dealt over the wavefronts; each has its own tile)
             const int gv0 = sr.gv[g], nvg = sr.gv[g + 1] - gv0;
             const int c0g = 6 * gv0, cw = 6 * nvg;
             const bool lastg = g == ng - 1;
@@ -853,11 +873,11 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
     //     then every lane (= row L of S) adds the chunk's part of S[L][:] = E[L,:] H_o^T to its REGISTER row:
     //     S never exists in LDS and sE holds one chunk only (17 KB per wavefront at 15 views instead of 36).
     const int ldb = C6 + 1;
-    if (lane < R2) sRo[lane] = ro;
+    if (lane < R2 && wfirst) sRo[lane] = ro;
 #pragma unroll
     for (int j = 0; j < RMAX; ++j) srow[j] = 0.0;
     double ez0 = 0.0, ez1 = 0.0, ez2 = 0.0;            // E[L,:] Z^T, over all chunks
-    for (int vc0 = 0; vc0 < M; vc0 += CV) {
+    for (int vc0 = CV * wv; vc0 < M; vc0 += CV * NWV) { // (NWV > 1: the chunks dealt over the wavefronts, partial sums below)
         const int nv = min(CV, M - vc0);                // views of this chunk
         const int c0 = 6 * vc0, cw = 6 * nv;
         const bool last = vc0 + nv >= M;
@@ -956,6 +976,35 @@ __global__ __launch_bounds__(64, RMAX <= 24 ? 3 : 2) void k_feature(FeatureArgs 
             }
         }
         wave_sync();                                 // the next chunk restages sE
+    }
+    if constexpr (NWV > 1) {
+        // the wavefronts' partial sums of srow / E Z^T, added up in wavefront 0's tile (free now) in turn; then wavefront 0 alone
+        double* sAcc = sE0;
+        const int lda = R2 + 3;
+        __syncthreads();
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) {
+            if (wv == w && lane < R2 && CV * w < M) {        // (a wavefront without a chunk has nothing to add)
+                double* arow = sAcc + lane * lda;
+                const bool firstw = w == 1;
+#pragma unroll
+                for (int j = 0; j < RMAX; ++j)
+                    if (j < R2) arow[j] = (firstw ? 0.0 : arow[j]) + srow[j];
+                arow[R2] = (firstw ? 0.0 : arow[R2]) + ez0;
+                arow[R2 + 1] = (firstw ? 0.0 : arow[R2 + 1]) + ez1;
+                arow[R2 + 2] = (firstw ? 0.0 : arow[R2 + 2]) + ez2;
+            }
+            __syncthreads();
+        }
+        if (wv != 0) return;
+        if (lane < R2 && CV < M) {
+            const double* arow = sAcc + lane * lda;
+#pragma unroll
+            for (int j = 0; j < RMAX; ++j)
+                if (j < R2) srow[j] += arow[j];
+            ez0 += arow[R2]; ez1 += arow[R2 + 1]; ez2 += arow[R2 + 2];
+        }
+        wave_sync();
     }
     if (p.stamps) tq[3] = tq[4] = tq[5] = wall_clock64();
     // S row of this lane: the -V Z part, sigma^2 on the diagonal, the rhs column r_o; lane R2 holds the extra row r_o^T

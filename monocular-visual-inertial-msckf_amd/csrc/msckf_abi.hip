@@ -316,6 +316,7 @@ struct msckf_ctx {
     size_t gather_off = 0;                // region for gathered shard blocks
     int gather_cap = 0;
     int n_leaves = 0;
+    int n_leaves0 = 0;                    // band plan: the leaves [0, n_leaves0) fold short tracks only (none of a split track's blocks)
     int acc_override = -1;                // total accepted over all shards (merge_gain path)
     float us_host_prep = 0, us_h2d = 0, us_d2h = 0;
     float us_stage[3] = {0, 0, 0};
@@ -567,9 +568,9 @@ struct Run { int b, e; };                 // entries [b, e) of the sorted arrays
 void build_tree(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid, const std::vector<Run>& runs,
                 size_t off0, std::vector<FoldNode>& nodes, std::vector<std::pair<int, int>>& levels, int& root, size_t& root_off,
-                size_t& off_end, int& n_leaves) {
+                size_t& off_end, int& n_leaves, int leaf_rows_default = 160) {
     const int N = c->N;
-    const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : 160;
+    const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : leaf_rows_default;
     const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 6;
     const int rem0 = c->split_on ? c->F + c->nNarrow : (1 << 30);        // remainder blocks: entries [rem0, Fs)
     nodes.clear();
@@ -915,6 +916,14 @@ bool build_plan_band(msckf_ctx* c, const std::vector<int>& fmin, const std::vect
         if (xchg) c->h_xflags[s] = 1.0;
         group_tri.push_back(cur[0]);
     }
+    // the leaves of the first run (the short tracks) in front of the others (the narrow blocks of split long tracks, written by a
+    // kernel on the second stream): they can start while that kernel runs.  (The merges name their sources by offset, not by node.)
+    c->n_leaves0 = (int)c->nodes.size();
+    if (runs.size() > 1) {
+        const int b1 = runs[1].b;
+        auto mid = std::stable_partition(c->nodes.begin(), c->nodes.end(), [b1](const FoldNode& n) { return n.src_begin < b1; });
+        c->n_leaves0 = (int)(mid - c->nodes.begin());
+    }
     c->n_leaves = (int)c->nodes.size();
     if (c->n_leaves > 0) c->levels.push_back({0, c->n_leaves});
     c->sweep_levels.clear();
@@ -1047,8 +1056,9 @@ void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
             // behind the band plan's workspace
             if (c->rem_direct) return;
             size_t off_end = 0; int nl = 0;
+            // (dense 6N-column rows: a merge level costs ~170 us whatever it folds, a leaf ~90 us per 256 rows -- few, tall leaves)
             build_tree(c, fmin, fmax, view_sorted, valid, {{F + c->nNarrow, Fs}}, c->rbuf_doubles, c->rnodes, c->rlevels, c->rroot,
-                       c->rroot_off, off_end, nl);
+                       c->rroot_off, off_end, nl, 512);
             c->rbuf_doubles = off_end;
             return;
         }
@@ -1119,18 +1129,19 @@ int launch_fold_levels(msckf_ctx* c, const std::vector<std::pair<int, int>>& lev
 }
 
 // band plan, level 0: the leaves fold their features' K4 blocks (k_lsweep)
-int launch_leaves_band(msckf_ctx* c) {
-    if (c->n_leaves == 0) return MSCKF_OK;
+int launch_leaves_band(msckf_ctx* c, int node_base = 0, int count = -1) {
+    if (count < 0) count = c->n_leaves - node_base;
+    if (count <= 0) return MSCKF_OK;
     LSweepArgs a{};
     a.nodes = ptr<FoldNode>(c->dNodes);
-    a.node_base = 0;
+    a.node_base = node_base;
     a.info = ptr<FeatInfo>(c->dFeatInfo);
     a.stack = c->dStack.p; a.stack_f32 = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
     a.rank = ptr<int>(c->dRank);
     a.accepted = ptr<unsigned char>(c->dAcc);
     a.rbuf = ptr<double>(c->dRbuf);
     a.zero_idx = c->stack_elems;
-    const dim3 grid(c->n_leaves), block(64 * SWEEP_NW);
+    const dim3 grid(count), block(64 * SWEEP_NW);
     if (c->leaf_narrow) {
         a.wide = 0;
         if (c->leaf_nf == 12) {          // large batches: twelve row blocks in flight (three wavefronts per SIMD), aligned rounds
@@ -1305,9 +1316,14 @@ int launch_feature(msckf_ctx* c) {
     auto go_split = [&](int f0, int nf, int mmax) {
         if (nf <= 0) return;
         a.f0 = f0; a.F = nf; a.split = ptr<SplitRec>(c->dSplit);
+        // few long tracks: four wavefronts per track (view groups and gate chunks in parallel: ~75 instead of 140 us at 30 views,
+        // all of it in front of the band pipeline's leaves); many: one wavefront per track fills the chip better (three per CU)
+        static const int mw_max = [] { const char* e = std::getenv("MSCKF_SPLIT_MW_MAX"); return e ? std::atoi(e) : 512; }();
+        const int nwv = nf <= mw_max ? 4 : 1;
         int lds_d = 0;
-        for (int m = 2; m <= mmax; ++m) lds_d = std::max(lds_d, feature_split_lds_doubles(m));
-        hipLaunchKernelGGL((k_feature<64, true>), dim3(nf), dim3(64), (size_t)lds_d * 8, st, a);
+        for (int m = 2; m <= mmax; ++m) lds_d = std::max(lds_d, feature_split_lds_doubles(m, nwv));
+        if (nwv == 4) hipLaunchKernelGGL((k_feature<64, true, 4>), dim3(nf), dim3(256), (size_t)lds_d * 8, st, a);
+        else hipLaunchKernelGGL((k_feature<64, true>), dim3(nf), dim3(64), (size_t)lds_d * 8, st, a);
         if (c->rem_direct) {             // few remainder rows: one dense matrix for K6-K7, no QR of their own
             RemScatterArgs r{};
             r.split = ptr<SplitRec>(c->dSplit); r.n_tracks = nf; r.rows_cap = c->rem_cap; r.rows_pad = (c->rem_cap + 15) & ~15;
@@ -1618,7 +1634,8 @@ int launch_root_and_gain(msckf_ctx* c, SweepArgs sa, int wtot, int nsteps, const
 
 // ... and for the ring-buffered root sweeps (k_wsweep form, sweep modes 1 and 2): k_root_gain_w
 bool root_gain_w_ok(const msckf_ctx* c, int band) {
-    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 3 * (SWEEP_NW - 1);
+    return gstream_ok(c, band) && c->gs_overlap && (c->dc + 15) / 16 + 1 <= 3 * (SWEEP_NW - 1) &&
+           2 * (2 + (c->dc + 15) / 16) <= c->n_cu;                                             // (as root_gain_ok: the sweep and the strips wait for each other)
 }
 template <int CS>
 int launch_root_and_gain_w(msckf_ctx* c, int node, int nsteps, int rc_log2, const double* zero, const double* Tblk, int band) {
@@ -1690,8 +1707,10 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         if ((rc = launch_fold_levels(c, c->rlevels, c->rnodes, rs, ptr<FoldNode>(c->dRNodes))) != MSCKF_OK) return rc;
         if (c->wide_on_stream2) HIPCHK(c, hipEventRecord(c->ev_rem, c->stream2));
     }
+    const bool early = c->F > 0 && c->wide_on_stream2 && c->band_plan && c->n_leaves0 > 0 && c->n_leaves0 < c->n_leaves;
+    if (early && (rc = launch_leaves_band(c, 0, c->n_leaves0)) != MSCKF_OK) return rc;          // (the short tracks' leaves need not wait)
     if (c->F > 0 && c->wide_on_stream2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wfeat, 0));
-    if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c)) != MSCKF_OK) return rc;
+    if (c->F > 0 && c->band_plan && (rc = launch_leaves_band(c, early ? c->n_leaves0 : 0)) != MSCKF_OK) return rc;
     if (c->F > 0 && !c->band_plan && (rc = launch_fold_levels(c, c->levels, c->nodes)) != MSCKF_OK) return rc;
     // (a rank that exports its group triangles stops in front of the root sweep: rank 0 runs it over all shards)
     // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront and the update's strips in ONE launch
@@ -1859,6 +1878,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 4, 3>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 6, 2>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_root_gain_w<SWEEP_NW, 6, 3>), LDS_MAX_BYTES - 1024, "k_root_gain_w LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_feature<64, true, 4>), LDS_MAX_BYTES - 1024, "k_feature<64, true, 4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<1>), LDS_MAX_BYTES - 1024, "k_gain_stream<1> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<2>), LDS_MAX_BYTES - 1024, "k_gain_stream<2> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
@@ -2180,7 +2200,9 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     }
     // A batch MOST of whose tracks span 11 - 15 slots and none more (BASELINE configs[4]: every track 15 views) keeps the
     // 90-column band pipeline for all of them: split, each would leave 3 remainder rows to the dense tree
-    if (Mmax_cls[2] > 0 && n_long == 0 && 2 * n_mid > F) {
+    // ... and so does one whose remainder rows (6 per such track) would be too many for K6-K7 to take as they are: the 90-column
+    // pipeline (539 us at 2000 tracks ~ U[2, 15]) beats band pipeline + remainder tree (866 us) there
+    if (Mmax_cls[2] > 0 && n_long == 0 && (2 * n_mid > F || 6 * n_mid > c->rem_direct_max)) {
         for (int f = 0; f < F; ++f) key_in[f] = (int)((size_t)key_in[f] % NN);
         Mmax_cls[0] = Mmax; Mmax_cls[2] = 0;
     }
@@ -2453,6 +2475,7 @@ int msckf_sync(msckf_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream_up));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));        // (the long tracks' kernels; the main stream is behind them by events already)
     c->feat_busy = c->pose_busy = c->main_busy = c->run_pending = false;
     return MSCKF_OK;
 }

@@ -9,7 +9,13 @@ from msckf_amd.api import UpdateEngine
 N, F, M = [int(x) for x in sys.argv[1:4]]
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dtype = sys.argv[5] if len(sys.argv) > 5 else "f64"
-prob = synth.make_problem(N, F, M, seed=0)
+kind = sys.argv[6] if len(sys.argv) > 6 else "uniform"      # few: F - 10 ten-view + 10 M-view tracks; ragged: tracks ~ U[2, M]
+if kind == "few":
+    prob = synth.few_long_tracks_problem(N, F, 10, 10, seed=0)
+elif kind == "ragged":
+    prob = synth.make_problem(N, F, M, seed=0, variable_tracks=True, min_track=2)
+else:
+    prob = synth.make_problem(N, F, M, seed=0)
 with UpdateEngine(max_clones=N, max_features=F, max_track=M, dtype=dtype) as eng:
     eng.load(prob)
     for _ in range(2):
