@@ -323,7 +323,8 @@ def main():
                  ("configs[4] in fp64", 50, 20000, 15, "f64", 20, None),
                  ("configs[4] fp32 storage + f32 MFMA P-update", 50, 20000, 15, "f32", 20, None),
                  # tracks of 2..30 consecutive clones (the reference's default window is 30 clones, MSCKF.py:45): tracks of more
-                 # than 10 slots take the information form (k_gram.h) beside the band pipeline of the others
+                 # than 10 slots are split (two-level nullspace basis): their <= 10-slot blocks join the band pipeline
+                 # of the others, their remainder rows go to K6-K7 as they are or through a merge tree of their own
                  ("long spans: N=30, 2000 features, track ~ U[2, 30]", 30, 2000, 30, "f64", 20,
                   lambda sd: synth.make_problem(30, 2000, 30, seed=sd, variable_tracks=True, min_track=2)),
                  ("spans <= 15: N=30, 2000 features, track ~ U[2, 15]", 30, 2000, 15, "f64", 50,

@@ -568,7 +568,7 @@ struct Run { int b, e; };                 // entries [b, e) of the sorted arrays
 void build_tree(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid, const std::vector<Run>& runs,
                 size_t off0, std::vector<FoldNode>& nodes, std::vector<std::pair<int, int>>& levels, int& root, size_t& root_off,
-                size_t& off_end, int& n_leaves, int leaf_rows_default = 160) {
+                size_t& off_end, int& n_leaves, int leaf_rows_default = 160, bool tall_merges = false) {
     const int N = c->N;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : leaf_rows_default;
     const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 6;
@@ -630,7 +630,10 @@ void build_tree(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
                 const int lo2 = std::min(lo, nodes[e].win_lo);
                 const int hi2 = std::max(hi, nodes[e].win_lo + nodes[e].w / 6 - 1);
                 const int cap = fold_bmax(6 * (hi2 - lo2 + 1));
-                if ((e - i) >= 2 && fold_rows + nodes[e].w > cap) break;   // keep one register batch per node
+                // keep one register batch per node -- unless the tree is a chain of dense levels anyway (the remainder blocks'
+                // tree: a level costs ~270 us whatever it folds, a further batch of sorted rows only the columns right of its
+                // first row's leading one)
+                if (!tall_merges && (e - i) >= 2 && fold_rows + nodes[e].w > cap) break;
                 fold_rows += nodes[e].w;
                 lo = lo2; hi = hi2;
                 ++e;
@@ -1056,9 +1059,10 @@ void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
             // behind the band plan's workspace
             if (c->rem_direct) return;
             size_t off_end = 0; int nl = 0;
-            // (dense 6N-column rows: a merge level costs ~170 us whatever it folds, a leaf ~90 us per 256 rows -- few, tall leaves)
+            // (measured at 2000 tracks ~ U[2, 30], 9750 rows: leaves of 160 / 512 rows with binary merges 2160 / 2165 us per update,
+            //  leaves of 1024 rows with merges of up to six triangles 2415 -- k_fold takes ~290 us per 256-row batch at w = 180)
             build_tree(c, fmin, fmax, view_sorted, valid, {{F + c->nNarrow, Fs}}, c->rbuf_doubles, c->rnodes, c->rlevels, c->rroot,
-                       c->rroot_off, off_end, nl, 512);
+                       c->rroot_off, off_end, nl, 512, false);
             c->rbuf_doubles = off_end;
             return;
         }

@@ -407,7 +407,7 @@ def _drop_views(prob, rng, keep_first=True, p_drop=0.35, only_first_slots=None):
     (30, 500, 15, 38, {"variable_tracks": True}, 90),   # ragged tracks up to 15 slots
     (24, 300, 13, 39, {"outlier_fraction": 0.1, "outlier_px": 500.0}, 90),
     (52, 300, 10, 40, {}, 60),                          # 60-column tiles, 312 rows of R: ring of 256 rows (k_wsweep<4>)
-    (31, 64, 31, 24, {}, None),                         # tracks wider than any sweep tile: the information form (k_gram.h)
+    (31, 64, 31, 24, {}, None),                         # tracks wider than any sweep tile: split
 ])
 def test_wide_sweep_and_ring(N, F, M, seed, kw, band):
     """Batches the plain sweep kernel cannot take -- tracks spanning 11-15 clone slots, band R larger than
@@ -418,7 +418,7 @@ def test_wide_sweep_and_ring(N, F, M, seed, kw, band):
     from oracle import msckf_oracle as oracle
     prob = synth.make_problem(N, F, M, seed=seed, **kw)
     ref = oracle.update(prob, dense_noise=False)
-    # (on windows of up to 31 clones tracks of 11+ slots take the information form by default: plan="band" keeps them on the
+    # (tracks of 11+ slots are split by default, DESIGN.md 3.6: plan="band" keeps them whole, on the
     #  90-column tiles this test is about; the default plan of the same batches is test_mixed_track_spans' subject)
     with UpdateEngine(max_clones=N, max_features=F, max_track=max(M, 2), plan="band" if band is not None else "auto") as e:
         res = e.update_problem(prob)
@@ -458,7 +458,7 @@ def _concat_problems(a, b):
 def test_mixed_track_spans(N, F, M, seed, kw):
     """The reference's window is 30 clones (MSCKF.py:45), a track grows one view per frame until it is lost (:404-412) and
     both pruning callers hand `update` every feature of the removed clones (:669-678, :726-735): a batch mixes spans.  Tracks
-    of up to 15 slots take the band pipeline, wider ones the information form (k_gram.h), K6-K7 takes both sources of rows.
+    of up to 10 slots take the band pipeline as they are, longer ones as the blocks of their split, K6-K7 takes both sources of rows.
     Against the oracle at the parity tolerance; bit-reproducible."""
     from msckf_amd import synth
     from msckf_amd.api import UpdateEngine
@@ -912,10 +912,10 @@ def test_batch_sizes_around_the_plan_boundaries(eng, F):
 @pytest.mark.parametrize("case", ["few_rows_wide_tracks_283", "few_rows_wide_tracks_373"])
 def test_wide_tracks_with_few_rows_fall_back_to_householder(case):
     """Two synthetic batches found by tools/soak_holes.py (tests/regress/*.npz hold their inputs): short tracks with holes that span
-    more than 10 clone slots -- the information form's class -- but contribute far fewer rows than the window has
-    columns.  Their Gram matrix has rank << 6N + 1, the factorisation of G + eps I met a non-positive pivot and the call returned
-    MSCKF_ERR_NOT_SPD where the reference's update exists.  The engine now re-plans such a batch with every track on the
-    Householder kernels and runs it again; `plan="band"` must give the same result without the detour."""
+    more than 10 clone slots but contribute far fewer rows than the window has columns.  Round 4's information form met a
+    non-positive pivot on them (rank of the Gram matrix << 6N + 1) and had to re-plan; since round 5 such tracks are split
+     and every row is a Householder row.  Kept: the one-shot call, the resident sequence committing unseen, the
+    exported block (one plan for every block) and `plan="band"` (no split) must agree with the oracle and with each other."""
     import os
     from msckf_amd import synth
     from msckf_amd.api import UpdateEngine
