@@ -368,6 +368,8 @@ struct msckf_ctx {
     Buf dSplit, dRem;
     int rem_cap = 0;                      // rows the remainder blocks may hold in all (3 per view group)
     int rem_direct_max = 16 * GS_MAX_NB2; // (msckf_debug_set_rem_direct_rows)
+    bool retry_plain = false;             // a K6-K7 launch timed out once: the context runs without in-launch waits since (msckf_get_result)
+    bool fake_timeout_done = false;       // MSCKF_DEBUG_FAKE_TIMEOUT
     bool rem_direct = false;              // ... few enough (16 GS_MAX_NB2): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
     // ... the remainder blocks' own QR: a merge tree beside the band pipeline (second stream), its root the second source of
     // rows for K6-K7 -- applied by a k_gain_stream launch of its own behind the first one, ordered by an event
@@ -2445,13 +2447,13 @@ int msckf_run(msckf_ctx* c) {
 
 // Every track of the current batch through ONE Householder plan (the wide ones included: the merge tree, as before the
 // information form existed): for blocks that leave this context, and when the wide tracks' Gram matrix does not factor.
-static int replan_no_wide(msckf_ctx* c) {
+static int replan_current(msckf_ctx* c, bool one_plan) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
-    c->no_wide = true;
+    if (one_plan) c->no_wide = true;
     c->plan_valid = false;
     plan_batch(c, c->h_fmin, c->h_fmax, c->h_view_sorted, nullptr);
-    c->plan_no_wide = true;
+    c->plan_no_wide = true;                // (not a plan the cache may hand to the next batch)
     c->gather_off = c->rbuf_doubles;
     const size_t need = (c->rbuf_doubles + 16) * 8;
     if (c->dRbuf.bytes < need) {
@@ -2469,7 +2471,7 @@ int msckf_run_compress(msckf_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->have_features && c->wide_active) {
         // the compressed block leaves this context (msckf_export_block): one plan for every track, the wide ones included
-        if (int rcp = replan_no_wide(c)) return rcp;
+        if (int rcp = replan_current(c, true)) return rcp;
     }
     return run_pipeline(c, false, nullptr);
 }
@@ -2566,7 +2568,25 @@ int msckf_get_result(msckf_ctx* c, double* dx, double* P_out, uint8_t* accepted,
         c->last_error = "K6-K7 did not report a status";
         rc = MSCKF_ERR_HIP;
     }
+    {   // MSCKF_DEBUG_FAKE_TIMEOUT=1 (tests): the first update of a context reads as timed out
+        static const bool fake = [] { const char* e = std::getenv("MSCKF_DEBUG_FAKE_TIMEOUT"); return e && std::atoi(e) == 1; }();
+        if (fake && !c->fake_timeout_done && rc == MSCKF_OK && c->ran_gain && c->gs_fused_last) { c->fake_timeout_done = true; status[0] = 2; rc = MSCKF_ERR_NOT_SPD; }
+    }
     if (rc == MSCKF_ERR_NOT_SPD && (status[0] == 2 || (c->wide_active && status[1] == 2))) {       // k_gain_stream gave up waiting for rows of T or for another workgroup
+        // The workgroups of k_root_gain / k_gain_stream wait for each other inside their launch; that they are all resident is
+        // argued from their LDS footprint and the device's CU count, not promised by HIP: a partitioned or busy
+        // device can keep one out until the 0.5 s bound.  ONE retry on kernels that never wait inside a launch (separate merge
+        // levels and root, round 3's K6-K7 launches), and the context stays on them.  Not with split long tracks in the batch
+        // (their second source of rows needs the sequential block update).
+        if (c->have_features && !c->split_on && !c->retry_plain && c->gs_enabled) {
+            c->retry_plain = true;
+            c->gs_enabled = false; c->stream_enabled = false;
+            if (int r2 = replan_current(c, false)) return r2;
+            if (int r2 = run_pipeline(c, true, nullptr)) return r2;
+            const int r3 = msckf_get_result(c, dx, P_out, accepted, st);
+            c->last_error = "k_gain_stream timed out once: this context now runs its sweeps and K6-K7 as separate launches";
+            return r3;
+        }
         c->last_error = "k_gain_stream: timeout (the root sweep or a workgroup of the update did not make progress)";
         rc = MSCKF_ERR_HIP;
     }

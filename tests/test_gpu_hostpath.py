@@ -242,3 +242,37 @@ def test_upload_paths_at_their_boundaries(monkeypatch, N, F, M):
     assert one.status == ref["status"] and np.array_equal(one.accepted, ref["accepted"])
     assert rel_err(one.dx, ref["dx"]) < TOL and rel_err(one.P_new, ref["P_new"]) < TOL
     assert np.array_equal(one.dx, res.dx) and np.array_equal(one.P_new, res.P_new) and np.array_equal(one.accepted, res.accepted)
+
+
+def test_a_timed_out_fused_launch_is_retried_on_plain_launches():
+    """The workgroups of k_root_gain wait for each other inside the launch; if one of them were kept off the device until the
+    0.5 s bound (a partitioned or busy GPU) the update is run again on kernels that never wait inside a launch, and the context
+    stays on those.  MSCKF_DEBUG_FAKE_TIMEOUT=1 makes the first update of a context read as timed out."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import msckf_amd
+from msckf_amd import synth
+from msckf_amd.api import UpdateEngine
+from oracle import msckf_oracle as oracle
+ok = True
+with UpdateEngine(max_clones=30, max_features=600, max_track=10) as e:
+    for seed in (1, 2, 3):
+        p = synth.make_problem(30, 500, 10, seed=seed, outlier_fraction=0.05, outlier_px=300.0)
+        ref = oracle.update(p, dense_noise=False)
+        r = e.update_problem(p)
+        e_dx = np.linalg.norm(r.dx - ref["dx"]) / np.linalg.norm(ref["dx"])
+        e_P = np.linalg.norm(r.P_new - ref["P_new"]) / np.linalg.norm(ref["P_new"])
+        ok = ok and r.status == 0 and np.array_equal(r.accepted, ref["accepted"]) and e_dx < 1e-8 and e_P < 1e-8
+        print(seed, r.status, e_dx, e_P, r.stats.get("k5_launches"), flush=True)
+print("RETRY_OK" if ok else "RETRY_FAIL")
+""" % root
+    env = dict(os.environ, MSCKF_DEBUG_FAKE_TIMEOUT="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert "RETRY_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    # the first call ran the fused launch (2 K5 launches), was retried, and every later call has the levels as launches of their own
+    lines = [l.split() for l in out.stdout.splitlines() if l and l[0] in "123"]
+    assert int(lines[0][4]) >= 3 and int(lines[1][4]) >= 3, lines
