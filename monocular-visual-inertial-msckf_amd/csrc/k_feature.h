@@ -1203,49 +1203,63 @@ __global__ __launch_bounds__(64 * NWV, NWV > 1 ? 1 : (RMAX <= 24 ? 3 : 2)) void 
 }
 
 // The remainder blocks of a batch with few enough long tracks (up to 16 GS_MAX_NB2 rows: a merge tree over them would take longer) as ONE dense
-// row-major matrix [rows][6N + 1] = [H | r], zero where a track has no view, zero rows for rejected tracks and up to the next
-// multiple of 16: the sequential block update (k_gstream.h) takes them 16 at a time as its second source of rows, in front
+// row-major matrix [rows][6N + 1] = [H | r], zero where a track has no view, the rows of the accepted tracks only, zero rows up to the
+// next multiple of 16: the sequential block update (k_gstream.h) takes them 16 at a time as its second source of rows, in front
 // of the band root's -- inside the root sweep's launch, while the sweep is on its first columns.
 //   reference MSCKF.py:581-588 (rows of the stack), :604-614 (the update they enter)
 struct RemScatterArgs {
     const SplitRec* split;       // [n_tracks]
-    int n_tracks;                // long tracks; workgroup n_tracks zeroes the padding rows
-    int rows_cap, rows_pad;      // sum of 3 ng | rounded up to 16
+    int n_tracks;                // long tracks; workgroup n_tracks zeroes the padding rows and publishes the row count
+    int rows_cap;                // sum of 3 ng: what `out` holds at most
     int dc, N;
     const int* view_ptr; const int* obs_slot;
     const long long* blk_off; const void* stack; int stack_f32;
     const int* rank; const unsigned char* accepted;
-    double* out;                 // [rows_pad][dc + 1]
+    double* out;                 // [<= rows_cap rounded up to 16][dc + 1]
+    int* nrows;                  // [0] row blocks of 16 (K6-K7 reads it at the head of its launch), [1] rows
 };
+// Only the rows that exist are laid down, in track order: a track's first row is the number of rows of the accepted tracks in front
+// of it (every workgroup sums them for itself: a few hundred records from L2 -- no scan kernel of its own).
 __global__ __launch_bounds__(256) void k_rem_scatter(RemScatterArgs p) {
     __shared__ int s_view[256];                       // clone slot -> view of the track (-1: none)
-    const int t = threadIdx.x, ld = p.dc + 1;
-    if ((int)blockIdx.x == p.n_tracks) {
-        for (int e = t; e < (p.rows_pad - p.rows_cap) * ld; e += 256) p.out[(size_t)p.rows_cap * ld + e] = 0.0;
+    __shared__ int s_red[256];
+    const int t = threadIdx.x, ld = p.dc + 1, me = (int)blockIdx.x;
+    int part = 0;
+    for (int i = t; i < min(me, p.n_tracks); i += 256) {
+        const int f = p.split[i].wide;
+        if (p.accepted[f] == 1) part += 2 * (p.view_ptr[f + 1] - p.view_ptr[f]) - p.rank[f];
+    }
+    s_red[t] = part;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) { if (t < k) s_red[t] += s_red[t + k]; __syncthreads(); }
+    const int row0 = s_red[0];
+    if (me == p.n_tracks) {                           // row0 = all rows: zero up to the next multiple of 16, publish
+        const int pad = ((row0 + 15) & ~15) - row0;
+        for (int e = t; e < pad * ld; e += 256) p.out[(size_t)row0 * ld + e] = 0.0;
+        if (t == 0) { p.nrows[0] = (row0 + 15) >> 4; p.nrows[1] = row0; }
         return;
     }
-    const SplitRec sr = p.split[blockIdx.x];
-    const int f = sr.wide, v0 = p.view_ptr[f], M = p.view_ptr[f + 1] - v0, cap = 3 * sr.ng;
+    const SplitRec sr = p.split[me];
+    const int f = sr.wide, v0 = p.view_ptr[f], M = p.view_ptr[f + 1] - v0;
     const int q = (p.accepted[f] == 1) ? 2 * M - p.rank[f] : 0;
+    if (q == 0) return;
     for (int i = t; i < p.N; i += 256) s_view[i] = -1;
     __syncthreads();
     if (t < M) s_view[p.obs_slot[v0 + t]] = t;
     __syncthreads();
     const long long boff = p.blk_off[f];
     const int ldb = 6 * M + 1;
-    for (int e = t; e < cap * ld; e += 256) {
+    for (int e = t; e < q * ld; e += 256) {
         const int row = e / ld, col = e - row * ld;
         double x = 0.0;
-        if (row < q) {
-            int src = -1;
-            if (col == p.dc) src = 6 * M;
-            else { const int sl = col / 6, v = s_view[sl]; if (v >= 0) src = 6 * v + (col - 6 * sl); }
-            if (src >= 0) {
-                const long long at = boff + (long long)row * ldb + src;
-                x = p.stack_f32 ? (double)static_cast<const float*>(p.stack)[at] : static_cast<const double*>(p.stack)[at];
-            }
+        int src = -1;
+        if (col == p.dc) src = 6 * M;
+        else { const int sl = col / 6, v = s_view[sl]; if (v >= 0) src = 6 * v + (col - 6 * sl); }
+        if (src >= 0) {
+            const long long at = boff + (long long)row * ldb + src;
+            x = p.stack_f32 ? (double)static_cast<const float*>(p.stack)[at] : static_cast<const double*>(p.stack)[at];
         }
-        p.out[(size_t)(sr.row0 + row) * ld + col] = x;
+        p.out[(size_t)(row0 + row) * ld + col] = x;
     }
 }
 

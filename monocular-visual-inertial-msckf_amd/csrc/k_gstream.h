@@ -80,6 +80,7 @@ struct GStreamArgs {
     // remainder blocks of split long tracks as a dense row-major matrix [16 nb2][ldt2] (k_rem_scatter; complete when the
     // launch starts -- its producer is ordered in front of the launch by the stream or an event).  nb2 = 0: none.
     const double* T2; int ldt2; int nb2;
+    const int* nb2_dev;                      // null, or where the producer of T2 left the number of its row blocks (<= nb2, the capacity)
     int nb1;                                 // row blocks of T to take (nb, or 0 when there is no band root at all)
     int f32_update;                          // msckf_config.dtype = f32: the rank-16 products X_I[s] X_I[r]^T of the P-update on the
                                              // f32 matrix cores (fp32 operands and sums of 16 terms; P itself stays fp64)
@@ -292,7 +293,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
 
     const long long t_start = wall_clock64();
     bool failed = false;
-    const int nb2 = p.nb2;
+    const int nb2 = p.nb2_dev ? min(p.nb2, *p.nb2_dev) : p.nb2;      // (written by a kernel in front of this launch: uniform)
     const int nb1 = p.nb1;
     for (int J = 0; J < nb2 + nb1; ++J) {
         const bool src2 = J < nb2;

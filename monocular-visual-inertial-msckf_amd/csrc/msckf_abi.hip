@@ -1332,10 +1332,11 @@ int launch_feature(msckf_ctx* c) {
         else hipLaunchKernelGGL((k_feature<64, true>), dim3(nf), dim3(64), (size_t)lds_d * 8, st, a);
         if (c->rem_direct) {             // few remainder rows: one dense matrix for K6-K7, no QR of their own
             RemScatterArgs r{};
-            r.split = ptr<SplitRec>(c->dSplit); r.n_tracks = nf; r.rows_cap = c->rem_cap; r.rows_pad = (c->rem_cap + 15) & ~15;
+            r.split = ptr<SplitRec>(c->dSplit); r.n_tracks = nf; r.rows_cap = c->rem_cap;
             r.dc = c->dc; r.N = c->N;
             r.view_ptr = a.view_ptr; r.obs_slot = a.obs_slot; r.blk_off = a.blk_off; r.stack = a.stack; r.stack_f32 = a.stack_f32;
             r.rank = a.rank; r.accepted = a.accepted; r.out = ptr<double>(c->dRem);
+            r.nrows = reinterpret_cast<int*>(ptr<double>(c->dRem) + (size_t)16 * GS_MAX_NB2 * (6 * c->maxN + 1));   // behind the matrix
             hipLaunchKernelGGL(k_rem_scatter, dim3(nf + 1), dim3(256), 0, st, r);
         }
     };
@@ -1559,7 +1560,10 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.nb1 = Tblk ? nb : 0;
     a.f32_update = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
-    if (c->wide_active && c->rem_direct) { a.T2 = ptr<double>(c->dRem); a.ldt2 = dc + 1; a.nb2 = (c->rem_cap + 15) / 16; }
+    if (c->wide_active && c->rem_direct) {
+        a.T2 = ptr<double>(c->dRem); a.ldt2 = dc + 1; a.nb2 = (c->rem_cap + 15) / 16;
+        a.nb2_dev = reinterpret_cast<const int*>(ptr<double>(c->dRem) + (size_t)16 * GS_MAX_NB2 * (6 * c->maxN + 1));
+    }
     a.stamps = nullptr;
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
 }
@@ -1585,7 +1589,7 @@ int launch_gain_chain(msckf_ctx* c, const double* Tblk) {
     GStreamArgs a;
     fill_gstream_args(c, a, Tblk, c->dc, false);
     a.P = ptr<double>(c->dPout); a.ldp = c->d; a.dx0 = ptr<double>(c->dDx);
-    a.T2 = nullptr; a.nb2 = 0;
+    a.T2 = nullptr; a.nb2 = 0; a.nb2_dev = nullptr;
     a.status = ptr<int>(c->dStatus) + 1;
     a.status_h = nullptr; a.dx_h = nullptr; a.Pout_h = nullptr; a.tstamp = nullptr;
     const size_t lds = gstream_lds_doubles(a.ns, a.ncb) * 8;
@@ -1937,7 +1941,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     {   // k_gain_stream: exchange tiles and (epoch-tagged, hence zeroed once) flags, the root sweep's progress word
         const size_t nbm = (size_t)(dc + 15) / 16, nsm = nbm + 1;
         E(c->dGsEx, (nbm + GS_MAX_NB2) * nsm * 256 * 8);      // (two sources of row blocks: the band root and the remainder rows of split long tracks)
-        E(c->dRem, 16 * (size_t)GS_MAX_NB2 * (dc + 1) * 8);   // the dense remainder rows (k_rem_scatter)
+        E(c->dRem, 16 * (size_t)GS_MAX_NB2 * (dc + 1) * 8 + 64);   // the dense remainder rows (k_rem_scatter) + their count
         E(c->dGsFlag, ((nbm + GS_MAX_NB2) * nsm + 8) * 8, true);
         E(c->dMProg, 512, true);                       // (progress words of the merge workgroups inside k_root_gain's launch)
         E(c->dGsProg, 512, true);                      // (progress word at 0, k_root_gain's time stamps on a line of their own at byte 256)
@@ -3656,7 +3660,12 @@ int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
     std::vector<double> blk((size_t)dc * n, 0.0);
     if (c->root >= 0) HIPCHK(c, hipMemcpy(blk.data(), root_block(c), blk.size() * 8, hipMemcpyDeviceToHost));
     if (second) {
-        const int m2 = c->rem_direct ? ((c->rem_cap + 15) & ~15) : dc;
+        int m2 = dc;
+        if (c->rem_direct) {                                   // (the rows k_rem_scatter laid down, rounded up to whole blocks)
+            int nr[2] = {0, 0};
+            HIPCHK(c, hipMemcpy(nr, ptr<double>(c->dRem) + (size_t)16 * GS_MAX_NB2 * (6 * c->maxN + 1), 8, hipMemcpyDeviceToHost));
+            m2 = 16 * nr[0];
+        }
         const double* src2 = c->rem_direct ? ptr<double>(c->dRem) : ptr<double>(c->dRbuf) + c->rroot_off;
         std::vector<double> A((size_t)(dc + m2) * n, 0.0);
         std::memcpy(A.data(), blk.data(), blk.size() * 8);
