@@ -331,6 +331,14 @@ def main():
                   lambda sd: synth.make_problem(30, 2000, 15, seed=sd, variable_tracks=True, min_track=2)),
                  ("a few long tracks: N=30, 1990 ten-view + 10 thirty-view tracks", 30, 2000, 30, "f64", 50,
                   lambda sd: synth.few_long_tracks_problem(30, 2000, 10, 10, seed=sd)),
+                 # a 50-clone window (MSCKFParameters.max_number_of_camera_states is a free parameter, MSCKF.py:45): long tracks are
+                 # split there too (round 4's information form stopped at 31 clones); beside it the batch it is measured against
+                 ("N=50, 2000 features, track=15 (90-column pipeline)", 50, 2000, 15, "f64", 30, None),
+                 ("long spans at N=50: 2000 features, track ~ U[2, 31]", 50, 2000, 31, "f64", 20,
+                  lambda sd: synth.make_problem(50, 2000, 31, seed=sd, variable_tracks=True, min_track=2)),
+                 # (the reference's front end keeps at most 300 features per frame, main.py:199)
+                 ("a frame of the reference's size: N=30, 300 features, track ~ U[2, 30], 10 % outliers", 30, 300, 30, "f64", 50,
+                  lambda sd: synth.make_problem(30, 300, 30, seed=sd, variable_tracks=True, min_track=2, outlier_fraction=0.10, outlier_px=400.0)),
                  ("10 % gross outliers: N=30, 2000 features, track=10", 30, 2000, 10, "f64", 50,
                   lambda sd: synth.make_problem(30, 2000, 10, seed=sd, outlier_fraction=0.10, outlier_px=400.0))]
         for name, n, f, m, dt, st, mk in extra:

@@ -73,10 +73,9 @@ class UpdateEngine:
 
     def __init__(self, max_clones: int = 30, max_features: int = 4096, max_track: int = 30,
                  device: int = 0, leaf_rows: int = 0, merge_arity: int = 0, plan: str = "auto", dtype: str = "f64"):
-        """plan: "auto" = band pipeline (k_sweep) for tracks of up to 10 clone slots and, on windows of up to 31 clones,
-        the information form (k_gram) for wider ones; "band" = no information form: 90-column band tiles for tracks of
-        11 - 15 slots, the merge tree beyond (what windows of more than 31 clones get anyway); "tree" = always the merge
-        tree (A/B, tests).
+        """plan: "auto" = band pipeline (k_sweep) for tracks of up to 10 clone slots; longer ones are split into <= 10-slot
+        blocks for that pipeline + a few remainder rows; "band" = no split: 90-column band tiles for tracks of
+        11 - 15 slots, the merge tree beyond; "tree" = always the merge tree (A/B, tests).
         dtype: "f64" = the reference's arithmetic (parity 1e-8); "f32" = fp32 storage of the stacked system and
         the Joseph covariance update on the f32 matrix cores (BASELINE.json configs[4]; tolerance in DESIGN.md)."""
         self._lib = _ffi.load()

@@ -1,7 +1,7 @@
 // K6-K7 as separate launches behind K5 (rounds 1-3): Kalman gain and Joseph-form covariance update.  Since round 4 the
-// update runs as k_gstream.h's sequential block update beside the root sweep; what is still used of this file: k_chol16
-// (the wide tracks' Gram matrix, k_gram.h), the in-wave elimination it lent k_gstream.h, and the whole chain for windows
-// of more than 82 clones / MSCKF_GAIN_STREAM=0.
+// update runs as k_gstream.h's sequential block update beside the root sweep; what is still used of this file: the in-wave
+// elimination k_chol16 lent k_gstream.h, and the whole chain for windows of more than 82 clones, MSCKF_GAIN_STREAM=0 and the
+// retry of a timed-out fused launch (msckf_get_result).
 //   reference MSCKF.py:604-607 : S = T P T^T + R_n ; K = P T^T S^-1 ; dx = K r_n
 //   reference MSCKF.py:612-614 : P+ = (I-KT) P (I-KT)^T + K R_n K^T ; P+ <- (P+ + P+^T)/2
 // with R_n = sigma^2 I (Q^T (sigma^2 I) Q, MSCKF.py:598) and T = [0 | R] acting
@@ -269,7 +269,7 @@ struct CholArgs {
     double* work;                 // n*(n+1)/2 doubles when !use_lds
     int* status;                  // [0] set to 1 when a pivot is not positive
     long long* stamps;            // debug builds (CHOL16_STAMPS) only: s_memtime stamps per step and wavefront
-    double diag_rel;              // k_chol16: factor S + diag_rel * trace(S) / n * I (0: S itself); k_gram.h says why
+    double diag_rel;              // k_chol16: factor S + diag_rel * trace(S) / n * I (0: S itself; nothing sets it since round 5)
     unsigned long long* done_flag;   // k_chol16, optional: done_val | rows of U (16 per step) that are final and visible device-wide:
     unsigned long long done_val;     //   a kernel of another stream (k_root_gain) follows the factor row block by row block
 };

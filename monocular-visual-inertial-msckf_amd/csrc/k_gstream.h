@@ -57,7 +57,7 @@ __device__ __forceinline__ void gs_std(double* p, double v) { gs_st(p, (unsigned
 constexpr int GS_WAVES = 16;                 // wavefronts per workgroup: tile wavefronts 0 .., wavefront 15 also eliminates
 constexpr int GS_PUB_WAVE = 14;              // publishes the strip's Y tile
 constexpr int GS_MAX_NS = 32;                // strips (two tiles per wavefront)
-constexpr int GS_MAX_NB2 = 128;              // row blocks of the second source (dense remainder rows of split long tracks)
+constexpr int GS_MAX_NB2 = 1024;             // row blocks of the second source (dense remainder rows of split long tracks)
 constexpr int GS_XS = 17;                    // X tiles in LDS: [column][row] with columns 17 doubles apart (a stride of 16 put a
 constexpr int GS_XT = 16 * GS_XS;            //  wavefront's store on four bank pairs: 1.2 us per row block for thirteen tiles)
 constexpr long long GS_TIMEOUT_TICKS = 50000000LL;   // 0.5 s of the 100 MHz wall clock

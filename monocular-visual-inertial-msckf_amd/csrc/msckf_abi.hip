@@ -367,10 +367,10 @@ struct msckf_ctx {
     std::vector<int> h_parent;            // [Fs - F] sorted index of the long track a block belongs to
     Buf dSplit, dRem;
     int rem_cap = 0;                      // rows the remainder blocks may hold in all (3 per view group)
-    int rem_direct_max = 16 * GS_MAX_NB2; // (msckf_debug_set_rem_direct_rows)
+    int rem_direct_max = 2048, rem_direct_max_wide = 16 * GS_MAX_NB2;   // (msckf_debug_set_rem_direct_rows)
     bool retry_plain = false;             // a K6-K7 launch timed out once: the context runs without in-launch waits since (msckf_get_result)
     bool fake_timeout_done = false;       // MSCKF_DEBUG_FAKE_TIMEOUT
-    bool rem_direct = false;              // ... few enough (16 GS_MAX_NB2): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
+    bool rem_direct = false;              // ... few enough (2048; 8192 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
     // ... the remainder blocks' own QR: a merge tree beside the band pipeline (second stream), its root the second source of
     // rows for K6-K7 -- applied by a k_gain_stream launch of its own behind the first one, ordered by an event
     std::vector<FoldNode> rnodes;
@@ -381,7 +381,7 @@ struct msckf_ctx {
     bool wide_active = false;             // the current plan keeps the wide tracks out of the band pipeline / tree
     bool no_wide = false;                 // the batch was re-planned with every track in one plan (msckf_run_compress: the
                                           // exported block must hold the wide tracks' rows too)
-    hipStream_t stream2 = nullptr;        // the wide tracks' chain (k_feature, k_gram, k_gram_reduce, k_chol16) runs beside the band pipeline
+    hipStream_t stream2 = nullptr;        // the long tracks' kernels (k_feature<64, true>, k_rem_scatter, the remainder blocks' tree) run beside the band pipeline
     hipEvent_t ev_fork = nullptr, ev_wfeat = nullptr;   // uploads done -> stream2 may start; the wide tracks' K4 blocks are written
     bool wide_on_stream2 = false;         // this batch's wide k_feature went to stream2 (ev_wfeat pending)
     // The one-shot call's K5 plan (a memset of the workspace + four to six tables of a few KB, each a ~5 us blit kernel) goes up on
@@ -1303,7 +1303,7 @@ int launch_feature(msckf_ctx* c) {
     a.select = c->use_select ? ptr<unsigned char>(c->dSelFlags) : nullptr;
     a.stamps = c->dStamps.p ? ptr<long long>(c->dStamps) + 8 * 8192 : nullptr;   // behind the fold stamps
     a.zero_idx = c->stack_elems;
-    c->gate_direct = c->want_direct && c->Fw == 0 && !c->use_select;
+    c->gate_direct = c->want_direct && !c->use_select;      // (long tracks: k_feature<64, true> mirrors its track's results as well)
     if (c->gate_direct) { a.rank_h = static_cast<int*>(c->hGate); a.acc_h = static_cast<unsigned char*>(c->hGate) + (size_t)c->Fs * 4; }
     // one launch per class of tracks: the short tracks [0, Fb) and the long ones [Fb, F), which are split (k_feature<64, true>
     // writes their narrow and remainder blocks)
@@ -1740,7 +1740,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
         HIPCHK(c, hipGetLastError());
     }
     c->gs_fused_last = beside;
-    c->res_direct = c->want_direct && c->gate_direct && gs && !c->wide_active;
+    c->res_direct = c->want_direct && c->gate_direct && gs && !chain;       // (a second update behind the first writes the HBM copies only)
     if (beside && c->sweep_mode > 0) {
         const SweepNode& rn = c->snodes.back();
         const double* zero = ptr<double>(c->dRbuf) + c->zero_off;
@@ -2212,7 +2212,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     // 90-column band pipeline for all of them: split, each would leave 3 remainder rows to the dense tree
     // ... and so does one whose remainder rows (6 per such track) would be too many for K6-K7 to take as they are: the 90-column
     // pipeline (539 us at 2000 tracks ~ U[2, 15]) beats band pipeline + remainder tree (866 us) there
-    if (Mmax_cls[2] > 0 && n_long == 0 && (2 * n_mid > F || 6 * n_mid > c->rem_direct_max)) {
+    if (Mmax_cls[2] > 0 && n_long == 0 && (2 * n_mid > F || 6 * n_mid > (c->dc > FOLD_RLDS_MAX_W ? c->rem_direct_max_wide : c->rem_direct_max))) {
         for (int f = 0; f < F; ++f) key_in[f] = (int)((size_t)key_in[f] % NN);
         Mmax_cls[0] = Mmax; Mmax_cls[2] = 0;
     }
@@ -2291,7 +2291,9 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->rem_cap = rem_cap;
         // (K6-K7 takes 16 dense rows in ~5 us; a merge tree over them is a leaf of ~100 us and ~170 us per level: the tree pays
         //  beyond some 2000 rows)
-        c->rem_direct = c->split_on && rem_cap <= c->rem_direct_max;
+        // ... and the tree's kernels are at their slowest on windows wider than their LDS holds (N > 31: ~1 ms per level), where the
+        // rows are taken as they are up to four times as many
+        c->rem_direct = c->split_on && rem_cap <= (c->dc > FOLD_RLDS_MAX_W ? c->rem_direct_max_wide : c->rem_direct_max);
         Fs = F + (int)narrow.size() + (int)wide.size();
         h_view.resize(Fs + 1); h_fmin.resize(Fs); h_fmax.resize(Fs);
         c->h_parent.resize(Fs - F);
@@ -2449,8 +2451,9 @@ int msckf_run(msckf_ctx* c) {
     return rc;
 }
 
-// Every track of the current batch through ONE Householder plan (the wide ones included: the merge tree, as before the
-// information form existed): for blocks that leave this context, and when the wide tracks' Gram matrix does not factor.
+// The current batch planned afresh.  one_plan: every block of the split long tracks with the short tracks in ONE merge tree
+// (blocks that leave this context: msckf_run_compress); else the same kind of plan under changed switches (the retry of a
+// timed-out launch).
 static int replan_current(msckf_ctx* c, bool one_plan) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream2));
@@ -2694,6 +2697,7 @@ int msckf_update(msckf_ctx* c, int32_t N, const double* P, const double* cam_R, 
         // K1-K4's results are in hGate once ev_gate has passed: sum them and fill the caller's mask while K5-K7 run
         const double tg0 = now_us();
         HIPCHK(c, hipEventSynchronize(c->ev_gate));
+        if (c->wide_on_stream2) HIPCHK(c, hipEventSynchronize(c->ev_wfeat));      // (the long tracks' results come from the second stream)
         const int Fn = c->F;
         const int* rk = static_cast<const int*>(c->hGate);
         const unsigned char* acc = static_cast<const unsigned char*>(c->hGate) + (size_t)c->Fs * 4;
@@ -3711,7 +3715,8 @@ int msckf_debug_split(msckf_ctx* c, int32_t out[8]) {
 
 int msckf_debug_set_rem_direct_rows(msckf_ctx* c, int32_t rows) {
     if (!c) return MSCKF_ERR_ARG;
-    c->rem_direct_max = rows < 0 ? 16 * GS_MAX_NB2 : std::min(rows, 16 * GS_MAX_NB2);
+    c->rem_direct_max = rows < 0 ? 2048 : std::min(rows, 16 * GS_MAX_NB2);
+    c->rem_direct_max_wide = rows < 0 ? 16 * GS_MAX_NB2 : c->rem_direct_max;
     c->plan_valid = false;
     return MSCKF_OK;
 }
