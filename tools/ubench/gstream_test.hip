@@ -125,7 +125,7 @@ int main(int argc, char** argv) {
 #endif
     GStreamArgs a{};
     a.P = dP; a.ldp = d; a.T = dT; a.ldt = ldt; a.ex = dEx; a.exflag = dFlag; a.dx = dDx; a.Pout = dPout; a.ldo = d;
-    a.status = dStatus; a.sigma2 = sigma2; a.d = d; a.dc = dc; a.nb = nb; a.ns = ns; a.ncb = ncb;
+    a.status = dStatus; a.sigma2 = sigma2; a.d = d; a.dc = dc; a.nb = nb; a.ns = ns; a.ncb = ncb; a.nb1 = nb;
     long long* dStamps = nullptr;
     CK(hipMalloc(&dStamps, 80 * 8 * 8)); CK(hipMemset(dStamps, 0, 80 * 8 * 8));
     a.stamps = dStamps;
