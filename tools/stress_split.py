@@ -30,6 +30,8 @@ with UpdateEngine(max_clones=53, max_features=2048, max_track=31) as eng:
         eng.set_rem_direct_rows(int(os.environ["SPLIT_DIRECT_ROWS"]))
     calls = 0
     for rd in range(rounds):
+        if rd and rd % 500 == 0:
+            print(f"... {calls} calls, {bad} bad, {time.time() - t0:.0f} s", flush=True)
         order = np.random.default_rng(rd).permutation(nb)
         for i in order:
             res = eng.update_problem(probs[i])
