@@ -2126,10 +2126,11 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     const size_t r_uv = 0, r_base = r_uv + (size_t)sumM * 16, r_m = r_base + (size_t)F * 24, r_rho = r_m + (size_t)F * 24;
     const size_t r_slot = r_rho + (size_t)F * 8;
     const size_t raw_bytes = (r_slot + (size_t)sumM * 4 + 15) & ~(size_t)15;
-    // the sort's records behind the arrays: one per entry of the sorted arrays (the tracks and, for long tracks that are split,
-    // their blocks: at most 7 per track of 11+ views, i.e. fewer than sumM) and one SplitRec per long track
-    const size_t rec_cap = (size_t)F + (size_t)sumM * 7 / 11 + 8;
-    const size_t pin_bytes = raw_bytes + rec_cap * sizeof(GatherRec) + ((size_t)sumM / 11 + 1) * sizeof(SplitRec);
+    // the sort's records behind the arrays: one per entry of the sorted arrays -- the tracks and, for long tracks that are split,
+    // their blocks: a narrow block per view group of 2+ views and one remainder block, i.e. at most M / 2 + 1 per track (a
+    // ragged track may span 11+ slots with three views) -- and one SplitRec per long track
+    const size_t rec_cap = 2 * (size_t)F + (size_t)sumM / 2 + 8;
+    const size_t pin_bytes = raw_bytes + rec_cap * sizeof(GatherRec) + ((size_t)F + 1) * sizeof(SplitRec);
     if (c->hFeatCap < pin_bytes) {
         if (c->hFeat) HIPCHK(c, hipHostFree(c->hFeat));
         c->hFeat = nullptr; c->hFeatCap = 0;
@@ -2288,6 +2289,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
             narrow.swap(sorted);
         }
         c->nNarrow = (int)narrow.size();
+        if ((size_t)F + narrow.size() + wide.size() > rec_cap) { (void)hipStreamSynchronize(c->stream); c->last_error = "split: record capacity"; return MSCKF_ERR_STATE; }
         c->rem_cap = rem_cap;
         // (K6-K7 takes 16 dense rows in ~5 us; a merge tree over them is a leaf of ~100 us and ~170 us per level: the tree pays
         //  beyond some 2000 rows)
