@@ -42,7 +42,7 @@ struct __attribute__((aligned(8))) SplitRec {
     int wide;                            // block index of the remainder block
     unsigned char gv[SPLIT_MAXG + 1];    // group g = views [gv[g], gv[g + 1]) of the track (views in slot order)
     unsigned char ng;                    // groups (>= 2)
-    int row0;                            // first row of the track's 3 ng rows in the dense remainder matrix (k_rem_scatter)
+    int rows_cap;                        // 3 ng: the rows the remainder block may hold (its place in the dense matrix is found by k_rem_scatter)
 };
 
 struct FeatureArgs {

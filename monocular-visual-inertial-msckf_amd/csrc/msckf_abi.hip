@@ -2276,7 +2276,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
                     ++ng;
                 }
                 sr.gv[ng] = (unsigned char)M; sr.ng = (unsigned char)ng;
-                sr.row0 = rem_cap; rem_cap += 3 * ng;
+                sr.rows_cap = 3 * ng; rem_cap += 3 * ng;
                 c->h_split[pi] = sr;
                 wide.push_back({sidx, f, a, M, lo, hi, pi, -1});
             }
