@@ -368,6 +368,10 @@ struct msckf_ctx {
     Buf dSplit, dRem;
     int rem_cap = 0;                      // rows the remainder blocks may hold in all (3 per view group)
     int rem_direct_max = 2048, rem_direct_max_wide = 16 * GS_MAX_NB2;   // (msckf_debug_set_rem_direct_rows)
+    bool in_merge = false;                // a merge of gathered shard blocks is being launched: its K6-K7 has ONE source of rows, whatever the
+                                          //   rank's own last batch looked like
+    bool t2_early = false;                // this run: the dense remainder rows were applied by a launch of their own (launch_gain_t2_early); the update
+                                          //   on the band root starts from that launch's P_out / dx
     bool retry_plain = false;             // a K6-K7 launch timed out once: the context runs without in-launch waits since (msckf_get_result)
     bool fake_timeout_done = false;       // MSCKF_DEBUG_FAKE_TIMEOUT
     bool rem_direct = false;              // ... few enough (2048; 8192 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
@@ -1560,10 +1564,11 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.nb1 = Tblk ? nb : 0;
     a.f32_update = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
-    if (c->wide_active && c->rem_direct) {
+    if (c->wide_active && c->rem_direct && !c->t2_early && !c->in_merge) {
         a.T2 = ptr<double>(c->dRem); a.ldt2 = dc + 1; a.nb2 = (c->rem_cap + 15) / 16;
         a.nb2_dev = reinterpret_cast<const int*>(ptr<double>(c->dRem) + (size_t)16 * GS_MAX_NB2 * (6 * c->maxN + 1));
     }
+    if (c->t2_early && !c->in_merge) { a.P = ptr<double>(c->dPout); a.ldp = d; a.dx0 = ptr<double>(c->dDx); }
     a.stamps = nullptr;
     a.tstamp = c->gs_stamp ? ptr<long long>(c->dGsProg) + 32 : nullptr;
 }
@@ -1577,6 +1582,25 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
     else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
     HIPCHK(c, hipGetLastError());
     c->gain_blocked = false;
+    return MSCKF_OK;
+}
+// MANY dense remainder rows (more than the root sweep's ~110 us cover at ~9 us per block on the nine-wavefront strips of its
+// launch): the update on them runs as a launch of its own, sixteen wavefronts per strip (~7 us per block), on the stream that made
+// them -- beside the band pipeline's leaves, which do not touch P -- from the prior P into P_out / dx (status word 1); the update on
+// the band root, inside the root sweep's launch, then starts from those.
+int launch_gain_t2_early(msckf_ctx* c, hipStream_t st) {
+    ++c->gs_epoch;
+    GStreamArgs a;
+    const bool keep = c->t2_early;
+    c->t2_early = false;
+    fill_gstream_args(c, a, nullptr, c->dc, false);        // (T2 = the dense rows, no first source)
+    c->t2_early = keep;
+    a.status = ptr<int>(c->dStatus) + 1;
+    a.status_h = nullptr; a.dx_h = nullptr; a.Pout_h = nullptr; a.tstamp = nullptr;
+    const size_t lds = gstream_lds_doubles(a.ns, a.nb) * 8;
+    if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, st, a);
+    HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
 // K6-K7 on a SECOND source of rows -- the root of the remainder blocks' tree (split long tracks) -- behind the update on the
@@ -1726,6 +1750,15 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     // K6-K7 beside the root sweep: the band plan's k_sweep root with the flusher wavefront and the update's strips in ONE launch
     const bool direct = c->F > 0 && c->wide_active && c->rem_direct;      // (the dense remainder rows: K6-K7's second source, taken first)
     const bool have_rows = c->root >= 0 || chain || direct;
+    {
+        static const int early_min = [] { const char* e = std::getenv("MSCKF_T2_EARLY_MIN"); return e ? std::atoi(e) : 20; }();
+        c->t2_early = direct && with_gain && c->root >= 0 && gstream_ok(c, c->root_band) && (c->rem_cap + 15) / 16 >= early_min;
+        if (c->t2_early) {
+            hipStream_t rs = c->wide_on_stream2 ? c->stream2 : c->stream;
+            if ((rc = launch_gain_t2_early(c, rs)) != MSCKF_OK) return rc;
+            if (c->wide_on_stream2) HIPCHK(c, hipEventRecord(c->ev_rem, c->stream2));
+        }
+    }
     const bool gs = with_gain && c->F > 0 && have_rows && gstream_ok(c, c->root_band);
     if (chain && with_gain && !gs) { c->last_error = "split long tracks need the streamed K6-K7"; return MSCKF_ERR_STATE; }
     const bool beside = gs && c->band_plan && c->root >= 0 &&
@@ -1739,6 +1772,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
                            c->xmask_doubles > 0 ? reinterpret_cast<unsigned char*>(ptr<double>(c->dRbuf) + c->N + 1) : nullptr);
         HIPCHK(c, hipGetLastError());
     }
+    if (c->t2_early && c->wide_on_stream2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rem, 0));     // (its P_out / dx are what the update below starts from)
     c->gs_fused_last = beside;
     c->res_direct = c->want_direct && c->gate_direct && gs && !chain;       // (a second update behind the first writes the HBM copies only)
     if (beside && c->sweep_mode > 0) {
@@ -3059,9 +3093,12 @@ int msckf_export_block(msckf_ctx* c, void* dst, int device_ptr, int32_t* n_accep
     return MSCKF_OK;
 }
 
+struct MergeScope { msckf_ctx* c; explicit MergeScope(msckf_ctx* c_) : c(c_) { c->in_merge = true; } ~MergeScope() { c->in_merge = false; } };
+
 int msckf_run_merge_gain(msckf_ctx* c, const void* blocks, int32_t n_blocks, int device_ptr,
                          int32_t total_accepted) {
     if (!c || !blocks || n_blocks < 1) return MSCKF_ERR_ARG;
+    MergeScope merge_scope(c);
     if (!c->have_state) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->N, dc = c->dc;
@@ -3210,6 +3247,7 @@ int collect_masks(msckf_ctx* c, const double* recs, long long rec_stride, int n_
 
 int run_merge_groups(msckf_ctx* c, const void* records, int32_t n_rec, int device_ptr, int32_t total_accepted, const uint8_t* flags) {
     if (!c || !records || n_rec < 1) return MSCKF_ERR_ARG;
+    MergeScope merge_scope(c);
     if (!c->have_state) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     const int N = c->N, dc = c->dc;
