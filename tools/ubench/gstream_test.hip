@@ -2,7 +2,8 @@
 // the reference's formulas (MSCKF.py:604-614), alone and beside a producer kernel that hands out the rows of T the way
 // the root sweep's flusher does (write-through stores, progress word), at a given pace.
 //   hipcc -O3 --offload-arch=gfx950 -I monocular-visual-inertial-msckf_amd/csrc -o build/gstream_test tools/ubench/gstream_test.hip
-//   build/gstream_test [N=30] [band=60] [us_per_row=0.6] [reps=20]
+//   build/gstream_test [N=30] [band=60] [us_per_row=0.6] [reps=20] [nb2=0]
+// nb2 > 0: ONLY a dense second source of 16 nb2 rows (the remainder rows of split long tracks), standalone, against the same formulas.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -39,6 +40,7 @@ int main(int argc, char** argv) {
     const int band = argc > 2 ? atoi(argv[2]) : 60;
     const double us_row = argc > 3 ? atof(argv[3]) : 0.6;
     const int reps = argc > 4 ? atoi(argv[4]) : 20;
+    const int nb2 = argc > 5 ? atoi(argv[5]) : 0;
     const int dc = 6 * N, d = 15 + dc, ldt = dc + 1;
     const int nb = (dc + 15) / 16, ns = nb + 1;
     const int ncb = gstream_ncb(dc, band);
@@ -152,6 +154,95 @@ int main(int argc, char** argv) {
         std::printf("%s: status %d  rel err dx %.3e  P+ %.3e  max |P+ - P+^T| %.3e\n", what, st, std::sqrt(e1 / n1), std::sqrt(e2 / n2), asym);
         return (st == 0 && std::sqrt(e1 / n1) < 1e-9 && std::sqrt(e2 / n2) < 1e-9) ? 0 : 2;
     };
+
+    if (nb2 > 0) {
+        // dense rows R: m x (dc + 1); Y = P[:, 15:] R^T; S = R Y[15:] + s2 I = L L^T; X = Y L^-T; dx = X L^-1 r; P+ = P - X X^T
+        const int m = 16 * nb2;
+        std::vector<double> R((size_t)m * ldt), Y2((size_t)d * m), S2((size_t)m * m), L2((size_t)m * m, 0.0), X2((size_t)d * m), dx2(d), Pn2((size_t)d * d), w2(m);
+        for (auto& x : R) x = nd(rng);
+        for (int i = 0; i < d; ++i)
+            for (int c = 0; c < m; ++c) {
+                double s = 0.0;
+                for (int k = 0; k < dc; ++k) s += P[(size_t)i * d + 15 + k] * R[(size_t)c * ldt + k];
+                Y2[(size_t)i * m + c] = s;
+            }
+        for (int a2 = 0; a2 < m; ++a2)
+            for (int b = 0; b < m; ++b) {
+                double s = (a2 == b) ? sigma2 : 0.0;
+                for (int k = 0; k < dc; ++k) s += R[(size_t)a2 * ldt + k] * Y2[(size_t)(15 + k) * m + b];
+                S2[(size_t)a2 * m + b] = s;
+            }
+        for (int j = 0; j < m; ++j) {
+            double s = S2[(size_t)j * m + j];
+            for (int k = 0; k < j; ++k) s -= L2[(size_t)j * m + k] * L2[(size_t)j * m + k];
+            L2[(size_t)j * m + j] = std::sqrt(s);
+            for (int i = j + 1; i < m; ++i) {
+                double v = S2[(size_t)i * m + j];
+                for (int k = 0; k < j; ++k) v -= L2[(size_t)i * m + k] * L2[(size_t)j * m + k];
+                L2[(size_t)i * m + j] = v / L2[(size_t)j * m + j];
+            }
+        }
+        for (int j = 0; j < m; ++j) {
+            double v = R[(size_t)j * ldt + dc];
+            for (int k = 0; k < j; ++k) v -= L2[(size_t)j * m + k] * w2[k];
+            w2[j] = v / L2[(size_t)j * m + j];
+        }
+        for (int i = 0; i < d; ++i) {
+            for (int j = 0; j < m; ++j) {
+                double v = Y2[(size_t)i * m + j];
+                for (int k = 0; k < j; ++k) v -= X2[(size_t)i * m + k] * L2[(size_t)j * m + k];
+                X2[(size_t)i * m + j] = v / L2[(size_t)j * m + j];
+            }
+            double s = 0.0;
+            for (int j = 0; j < m; ++j) s += X2[(size_t)i * m + j] * w2[j];
+            dx2[i] = s;
+        }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double s = P[(size_t)i * d + j];
+                for (int k = 0; k < m; ++k) s -= X2[(size_t)i * m + k] * X2[(size_t)j * m + k];
+                Pn2[(size_t)i * d + j] = s;
+            }
+        dx = dx2; Pn = Pn2;
+        double* dR; double* dEx2; unsigned long long* dFlag2; long long* dSt2;
+        CK(hipMalloc(&dR, R.size() * 8)); CK(hipMemcpy(dR, R.data(), R.size() * 8, hipMemcpyHostToDevice));
+        CK(hipMalloc(&dEx2, (size_t)(nb2 + nb) * ns * 256 * 8)); CK(hipMalloc(&dFlag2, (size_t)(nb2 + nb) * ns * 8 + 64));
+        CK(hipMemset(dFlag2, 0, (size_t)(nb2 + nb) * ns * 8 + 64));
+        CK(hipMalloc(&dSt2, (size_t)(nb2 + 80) * 8 * 8)); CK(hipMemset(dSt2, 0, (size_t)(nb2 + 80) * 8 * 8));
+        a.ex = dEx2; a.exflag = dFlag2; a.T = nullptr; a.nb1 = 0; a.T2 = dR; a.ldt2 = ldt; a.nb2 = nb2; a.progress = nullptr; a.stamps = dSt2;
+        const size_t lds2 = gstream_lds_doubles(ns, nb) * 8;
+        auto launch2 = [&](hipStream_t st) {
+            if (ns <= 16) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds2, st, a);
+            else hipLaunchKernelGGL(k_gain_stream<2>, dim3(ns), dim3(64 * GS_WAVES), lds2, st, a);
+        };
+        int rc2 = 0;
+        a.epoch = ++epoch; launch2(sb); CK(hipStreamSynchronize(sb));
+        rc2 |= check("dense second source");
+        float best = 1e9f, sum = 0.f;
+        for (int it = 0; it < reps; ++it) {
+            a.epoch = ++epoch;
+            CK(hipEventRecord(e0, sb)); launch2(sb); CK(hipEventRecord(e1, sb)); CK(hipEventSynchronize(e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms); sum += ms;
+        }
+        std::printf("dense second source, %d row blocks: best %.1f us, mean %.1f us = %.2f us per block (N = %d, %d strips)\n", nb2, best * 1e3, sum / reps * 1e3,
+                    best * 1e3 / nb2, N, ns);
+        rc2 |= check("dense second source (last rep)");
+#ifdef GS_STAMPS
+        {
+            std::vector<long long> st((size_t)(nb2 + 80) * 8);
+            CK(hipMemcpy(st.data(), dSt2, st.size() * 8, hipMemcpyDeviceToHost));
+            std::printf("workgroup 0, 10 ns ticks per row block: top -> partials | -> published | -> tiles fetched | barrier | eliminated | wave 0 followed | LDS write + barrier | to next block's top\n");
+            for (int I = 0; I < nb2 && I < 60; ++I) {
+                if (I == 5) continue;
+                const long long* q = &st[I * 8];
+                std::printf("  block %2d: %5lld | %5lld | %5lld | %4lld | %5lld | %5lld | %5lld | %5lld\n", I, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4],
+                            q[7] - q[5], q[6] - q[7], I + 1 < nb2 ? st[(I + 1) * 8] - q[6] : 0LL);
+            }
+        }
+#endif
+        std::printf(rc2 == 0 ? "OK\n" : "FAILED\n");
+        return rc2;
+    }
     int rc = 0;
     // (1) alone: T complete, no progress word
     CK(hipMemcpy(dT, T.data(), T.size() * 8, hipMemcpyHostToDevice));
