@@ -363,6 +363,10 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             // one round trip less on paper).  Readers that re-poll a line back to back keep being served the copy of their
             // first miss (every launch but the first timed out; a sleep between polls or a buffer_inv sc1 cured it), and
             // with the sleep the 4 KB sweeps of 13 x 13 wavefronts were slower than this: 108 against 90 us at N = 30.
+            // Round 5 (tools/ubench/gstream_test.hip, 40 dense blocks at N = 30: 7.6 us per block): tagged granules behind an
+            // UNDRAINED flag as a hint (one sweep per reader, sleep + second sweep on a stale tag) -- correct, but the drain is
+            // only ~0.4 us of a block and the 4 KB reads cost more than that: 8.0 us; the T tiles of complete blocks loaded one
+            // block ahead: 8.05 us (the flag polls wait behind the prefetched loads, vmcnt counts in order).
             double* dst = p.ex + ((size_t)J * ns + r) * 256 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gs_std(dst + 64 * i, y[i]);

@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
     unsigned long long *dFlag, *dProg;
     int* dStatus;
     CK(hipMalloc(&dP, P.size() * 8)); CK(hipMalloc(&dT, T.size() * 8)); CK(hipMalloc(&dTsrc, T.size() * 8));
-    CK(hipMalloc(&dEx, (size_t)nb * ns * 256 * 8)); CK(hipMalloc(&dFlag, (size_t)nb * ns * 8 + 64)); CK(hipMalloc(&dProg, 64));
+    CK(hipMalloc(&dEx, (size_t)nb * ns * 256 * 16)); CK(hipMemset(dEx, 0, (size_t)nb * ns * 256 * 16)); CK(hipMalloc(&dFlag, (size_t)nb * ns * 8 + 64)); CK(hipMalloc(&dProg, 64));
     CK(hipMalloc(&dDx, d * 8)); CK(hipMalloc(&dPout, P.size() * 8)); CK(hipMalloc(&dStatus, 64));
     CK(hipMemcpy(dP, P.data(), P.size() * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dTsrc, T.data(), T.size() * 8, hipMemcpyHostToDevice));
@@ -206,7 +206,7 @@ int main(int argc, char** argv) {
         dx = dx2; Pn = Pn2;
         double* dR; double* dEx2; unsigned long long* dFlag2; long long* dSt2;
         CK(hipMalloc(&dR, R.size() * 8)); CK(hipMemcpy(dR, R.data(), R.size() * 8, hipMemcpyHostToDevice));
-        CK(hipMalloc(&dEx2, (size_t)(nb2 + nb) * ns * 256 * 8)); CK(hipMalloc(&dFlag2, (size_t)(nb2 + nb) * ns * 8 + 64));
+        CK(hipMalloc(&dEx2, (size_t)(nb2 + nb) * ns * 256 * 16)); CK(hipMemset(dEx2, 0, (size_t)(nb2 + nb) * ns * 256 * 16)); CK(hipMalloc(&dFlag2, (size_t)(nb2 + nb) * ns * 8 + 64));
         CK(hipMemset(dFlag2, 0, (size_t)(nb2 + nb) * ns * 8 + 64));
         CK(hipMalloc(&dSt2, (size_t)(nb2 + 80) * 8 * 8)); CK(hipMemset(dSt2, 0, (size_t)(nb2 + 80) * 8 * 8));
         a.ex = dEx2; a.exflag = dFlag2; a.T = nullptr; a.nb1 = 0; a.T2 = dR; a.ldt2 = ldt; a.nb2 = nb2; a.progress = nullptr; a.stamps = dSt2;
