@@ -238,6 +238,27 @@ __device__ __forceinline__ void gs_follow(double (&a0)[NT][4], unsigned w_in, co
         for (int i = 0; i < 4; ++i) a0[tq][i] *= ri;
 }
 
+// acc += the n partial tiles at src (256 doubles apart; this lane's four entries 64 apart), in order, four tiles' reads in flight
+// at a time (a loop of one tile per trip, each waiting for its own four reads, took 0.9 us for twelve tiles -- twice per row block,
+// on the block's dependent chain)
+__device__ __forceinline__ void gs_sum_tiles(double (&acc)[4], const double* src, int n) {
+    for (int s0 = 0; s0 < n; s0 += 4) {
+        double v[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double* q = src + (size_t)min(s0 + c, n - 1) * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[c][i] = q[64 * i];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (s0 + c < n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += v[c][i];
+            }
+    }
+}
+
 // WV wavefronts; wavefront wv < TW holds the tiles s = wv + TW q, q < TPW; wavefront WV - 1 eliminates (with TW < WV it has
 // no tile of its own to follow afterwards), wavefront WV - 2 also publishes.
 template <int WV, int TW, int TPW>
@@ -317,8 +338,12 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         }
         GS_STAMP(WV - 1, 0);                                      // rows of T seen
         if (p.tstamp && !src2 && r == 0 && wv == WV - 1 && lane == 0 && I < 15) p.tstamp[3 + I] = wall_clock64();
-        __syncthreads();
-        if (sCtl[1]) { failed = true; break; }
+        // (the barrier hands the wait's outcome to the other wavefronts; a block that waits for nothing needs none: what it writes
+        //  in LDS -- Y partials, then A partials, X -- was last read two barriers ago)
+        if (!src2 && p.progress) {
+            __syncthreads();
+            if (sCtl[1]) { failed = true; break; }
+        }
         const int s_lo = src2 ? 1 : 1 + (row0 >> 4), s_hi = min(s_lo + ncbs - 1, ns - 1);   // strips that hold T_I's columns
         // ---- B: partials of Y_I[r] = sum_s P(r, s) T_{I,s}^T ------------------------------------------------
         double Tt[TPW][4];
@@ -353,10 +378,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         // ---- C: publish Y_I[r] ---------------------------------------------------------------------------------
         if (wv == WV - 2) {
             double y[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int sl = 0; sl <= s_hi - s_lo; ++sl) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i] += sPartY[(size_t)sl * 256 + 64 * i + lane];
-            }
+            gs_sum_tiles(y, sPartY + lane, s_hi - s_lo + 1);
             y[3] += rhs;                                               // (row 15 of strip 0; zero elsewhere)
             // payload write-through, drained, then the flag (MI355X_MICROARCH.md, inter-workgroup visibility, first table row).
             // Tried and dropped: tagged 8-byte granules polled by their readers instead of a flag (no drain, no flag store:
@@ -365,8 +387,8 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
             // with the sleep the 4 KB sweeps of 13 x 13 wavefronts were slower than this: 108 against 90 us at N = 30.
             // Round 5 (tools/ubench/gstream_test.hip, 40 dense blocks at N = 30: 7.6 us per block): tagged granules behind an
             // UNDRAINED flag as a hint (one sweep per reader, sleep + second sweep on a stale tag) -- correct, but the drain is
-            // only ~0.4 us of a block and the 4 KB reads cost more than that: 8.0 us; the T tiles of complete blocks loaded one
-            // block ahead: 8.05 us (the flag polls wait behind the prefetched loads, vmcnt counts in order).
+            // only ~0.4 us of a block and the 4 KB reads cost more than that: 8.0 us; the T tiles of complete blocks requested one
+            // block ahead: 8.05 us, requested behind the previous block's last barrier: 7.6 against 7.1 us.
             double* dst = p.ex + ((size_t)J * ns + r) * 256 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gs_std(dst + 64 * i, y[i]);
@@ -414,10 +436,7 @@ __device__ __forceinline__ void gain_stream_body(const GStreamArgs& p, const int
         double* sri = sRi + half * 16;
         if (wv == WV - 1) {
             double a[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int sl = 0; sl <= s_hi - s_lo; ++sl) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] += sPartA[(size_t)sl * 256 + 64 * i + lane];
-            }
+            gs_sum_tiles(a, sPartA + lane, s_hi - s_lo + 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (g + 4 * i == cc) a[i] += p.sigma2;
             // the other half's words are reset for the next block (its followers have passed this block's first barrier)
