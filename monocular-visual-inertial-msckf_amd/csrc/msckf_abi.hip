@@ -367,14 +367,18 @@ struct msckf_ctx {
     std::vector<int> h_parent;            // [Fs - F] sorted index of the long track a block belongs to
     Buf dSplit, dRem;
     int rem_cap = 0;                      // rows the remainder blocks may hold in all (3 per view group)
-    int rem_direct_max = 2048, rem_direct_max_wide = 16 * GS_MAX_NB2;   // (msckf_debug_set_rem_direct_rows)
+    // remainder rows (capacity: 3 per view group) up to which K6-K7 takes them as they are (msckf_debug_set_rem_direct_rows).  Measured
+    // on tracks ~ U[2, 30] at N = 30, direct against their own merge tree: 450 tracks 887 / 1420 us, 600 1106 / 1505, 800 1420 / 1653,
+    // 1000 (4900 rows) 1724 / 1777, 1300 2213 / 1895
+    static constexpr int REM_DIRECT_DEFAULT = 5376;
+    int rem_direct_max = REM_DIRECT_DEFAULT, rem_direct_max_wide = 16 * GS_MAX_NB2;
     bool in_merge = false;                // a merge of gathered shard blocks is being launched: its K6-K7 has ONE source of rows, whatever the
                                           //   rank's own last batch looked like
     bool t2_early = false;                // this run: the dense remainder rows were applied by a launch of their own (launch_gain_t2_early); the update
                                           //   on the band root starts from that launch's P_out / dx
     bool retry_plain = false;             // a K6-K7 launch timed out once: the context runs without in-launch waits since (msckf_get_result)
     bool fake_timeout_done = false;       // MSCKF_DEBUG_FAKE_TIMEOUT
-    bool rem_direct = false;              // ... few enough (2048; 8192 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
+    bool rem_direct = false;              // ... few enough (5376; 16384 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
     // ... the remainder blocks' own QR: a merge tree beside the band pipeline (second stream), its root the second source of
     // rows for K6-K7 -- applied by a k_gain_stream launch of its own behind the first one, ordered by an event
     std::vector<FoldNode> rnodes;
@@ -1761,7 +1765,11 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     }
     const bool gs = with_gain && c->F > 0 && have_rows && gstream_ok(c, c->root_band);
     if (chain && with_gain && !gs) { c->last_error = "split long tracks need the streamed K6-K7"; return MSCKF_ERR_STATE; }
-    const bool beside = gs && c->band_plan && c->root >= 0 &&
+    // (behind an early update on the dense remainder rows the root sweep runs as a launch of its own, BESIDE that update, and the update
+    //  on its rows follows both: in one launch with it the sweep would wait for the remainder rows' update too -- a frame of 300 tracks
+    //  ~ U[2, 30]: 695 -> ~610 us)
+    static const bool t2_split = [] { const char* e = std::getenv("MSCKF_T2_SPLIT_ROOT"); return !e || std::atoi(e) != 0; }();
+    const bool beside = gs && c->band_plan && c->root >= 0 && !(c->t2_early && t2_split) &&
                         (c->sweep_mode == 0 ? (!c->h_root_flush.empty() && root_gain_ok(c, c->root_band)) : root_gain_w_ok(c, c->root_band));
     const bool streamed = beside && c->sweep_mode == 0 && c->root_streamed;     // the last merge level rides in the root's launch
     if (c->F > 0 && c->band_plan && (rc = launch_sweeps(c, (with_gain || !c->xchg_planned) && !beside, streamed ? c->stream_level : -1)) != MSCKF_OK) return rc;
@@ -2247,7 +2255,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
     // 90-column band pipeline for all of them: split, each would leave 3 remainder rows to the dense tree
     // ... and so does one whose remainder rows (6 per such track) would be too many for K6-K7 to take as they are: the 90-column
     // pipeline (539 us at 2000 tracks ~ U[2, 15]) beats band pipeline + remainder tree (866 us) there
-    if (Mmax_cls[2] > 0 && n_long == 0 && (2 * n_mid > F || 6 * n_mid > (c->dc > FOLD_RLDS_MAX_W ? c->rem_direct_max_wide : c->rem_direct_max))) {
+    if (Mmax_cls[2] > 0 && n_long == 0 && (2 * n_mid > F || 6 * n_mid > (c->dc > FOLD_RLDS_MAX_W ? c->rem_direct_max_wide : std::min(c->rem_direct_max, 2048)))) {
         for (int f = 0; f < F; ++f) key_in[f] = (int)((size_t)key_in[f] % NN);
         Mmax_cls[0] = Mmax; Mmax_cls[2] = 0;
     }
@@ -3755,7 +3763,7 @@ int msckf_debug_split(msckf_ctx* c, int32_t out[8]) {
 
 int msckf_debug_set_rem_direct_rows(msckf_ctx* c, int32_t rows) {
     if (!c) return MSCKF_ERR_ARG;
-    c->rem_direct_max = rows < 0 ? 2048 : std::min(rows, 16 * GS_MAX_NB2);
+    c->rem_direct_max = rows < 0 ? msckf_ctx::REM_DIRECT_DEFAULT : std::min(rows, 16 * GS_MAX_NB2);
     c->rem_direct_max_wide = rows < 0 ? 16 * GS_MAX_NB2 : c->rem_direct_max;
     c->plan_valid = false;
     return MSCKF_OK;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/ktimeline2.sh u15|u30|mixed -> kernel timeline of the last resident update of that batch
+# usage (on the GPU box): tools/ktimeline2.sh u15|u30|frame|mixed -> kernel timeline of the last resident update of that batch
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/tl2_$1
 rm -rf $out; mkdir -p $out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One named batch of tools/span_rows.py run a few times on the resident path (for rocprofv3 --kernel-trace: tools/ktimeline2.sh
-u15|u30|mixed)."""
+u15|u30|frame|mixed)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,8 @@ if which == "u15":
     prob = synth.make_problem(30, 2000, 15, seed=0, variable_tracks=True, min_track=2)
 elif which == "u30":
     prob = synth.make_problem(30, 2000, 30, seed=0, variable_tracks=True, min_track=2)
+elif which == "frame":      # a frame of the reference's size (main.py:199): 300 tracks ~ U[2, 30]
+    prob = synth.make_problem(30, 300, 30, seed=0, variable_tracks=True, min_track=2)
 else:
     a = synth.make_problem(30, 1990, 10, seed=0)
     b = synth.make_problem(30, 10, 30, seed=100, P=a.P, poses=(a.cam_R, a.cam_t))

@@ -17,6 +17,8 @@ elif kind == "ragged":
 else:
     prob = synth.make_problem(N, F, M, seed=0)
 with UpdateEngine(max_clones=N, max_features=F, max_track=M, dtype=dtype) as eng:
+    if "SPLIT_DIRECT_ROWS" in os.environ:          # remainder rows taken as they are up to this many (default 2048 / 16384)
+        eng.set_rem_direct_rows(int(os.environ["SPLIT_DIRECT_ROWS"]))
     eng.load(prob)
     for _ in range(2):
         eng.run()
