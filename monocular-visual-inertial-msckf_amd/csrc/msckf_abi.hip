@@ -371,6 +371,7 @@ struct msckf_ctx {
     // on tracks ~ U[2, 30] at N = 30, direct against their own merge tree: 450 tracks 887 / 1420 us, 600 1106 / 1505, 800 1420 / 1653,
     // 1000 (4900 rows) 1724 / 1777, 1300 2213 / 1895
     static constexpr int REM_DIRECT_DEFAULT = 5376;
+    int rem_leaf_rows = 0;                // rows of a leaf of the remainder rows' merge tree (MSCKF_REM_LEAF_ROWS; 0: one register batch of k_fold)
     int rem_direct_max = REM_DIRECT_DEFAULT, rem_direct_max_wide = 16 * GS_MAX_NB2;
     bool in_merge = false;                // a merge of gathered shard blocks is being launched: its K6-K7 has ONE source of rows, whatever the
                                           //   rank's own last batch looked like
@@ -608,8 +609,9 @@ void build_tree(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
             int rows = 0, e = f, last = f;
             while (e < F && (e - f) < FOLD_MAX_SRC) {
                 if (live(e)) {
-                    // (rows of the entry at most: 2 per view; a remainder block holds 3 per view group)
-                    const int r = e >= rem0 ? 3 * (int)c->h_split[c->h_parent[e - c->F] - c->Fb].ng : 2 * (view_sorted[e + 1] - view_sorted[e]);
+                    // (rows of the entry: at most 2 per view; a remainder block holds 3 (groups - 1) of them unless the track's geometry
+                    //  is degenerate -- an estimate is all a leaf's size needs, k_fold takes what it finds in register batches of 256)
+                    const int r = e >= rem0 ? 3 * ((int)c->h_split[c->h_parent[e - c->F] - c->Fb].ng - 1) : 2 * (view_sorted[e + 1] - view_sorted[e]);
                     if (e > f && rows + r > leaf_rows) break;
                     rows += r;
                     lo = std::min(lo, fmin[e]);
@@ -1069,10 +1071,12 @@ void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
             // behind the band plan's workspace
             if (c->rem_direct) return;
             size_t off_end = 0; int nl = 0;
-            // (measured at 2000 tracks ~ U[2, 30], 9750 rows: leaves of 160 / 512 rows with binary merges 2160 / 2165 us per update,
-            //  leaves of 1024 rows with merges of up to six triangles 2415 -- k_fold takes ~290 us per 256-row batch at w = 180)
+            // (a leaf is ONE register batch of k_fold -- 192 rows at w = 180, ~290 us whatever it holds.  Measured at 2000 tracks
+            //  ~ U[2, 30], 5850 rows, leaves of 96 / 128 / 160 / 176 / 192 / 208 / 256 rows: 2149 / 2151 / 2113 / 2097 / 1940 / 2164 /
+            //  2175 us per update; by the 3-per-group bound, i.e. two batches per leaf, 2160; leaves of 1024 rows with merges of up
+            //  to six triangles 2415)
             build_tree(c, fmin, fmax, view_sorted, valid, {{F + c->nNarrow, Fs}}, c->rbuf_doubles, c->rnodes, c->rlevels, c->rroot,
-                       c->rroot_off, off_end, nl, 512, false);
+                       c->rroot_off, off_end, nl, c->rem_leaf_rows > 0 ? c->rem_leaf_rows : fold_bmax(c->dc), false);
             c->rbuf_doubles = off_end;
             return;
         }
@@ -1883,6 +1887,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         c->gs_enabled = !(e1 && std::atoi(e1) == 0);
         { const char* e3 = std::getenv("MSCKF_WIDE_STREAM"); c->wide_concurrent = !(e3 && std::atoi(e3) == 0); }
         c->gs_overlap = !(e2 && std::atoi(e2) == 0);
+        { const char* e4 = std::getenv("MSCKF_REM_LEAF_ROWS"); if (e4 && std::atoi(e4) >= 16) c->rem_leaf_rows = std::atoi(e4); }
     }
     // every failure here is reported at create time (a dropped attribute would only surface later as an
     // opaque launch error of the first kernel that needs the LDS)
