@@ -58,6 +58,34 @@ struct FoldArgs {
     long long* stamps;          // optional diagnostics: per-node cycle stamps (8 per node), may be null
 };
 
+// The triangles a CUT merge tree ends with (split long tracks' remainder rows, msckf_abi.hip plan_batch: the last levels of a
+// dense tree halve a few hundred rows per ~250 us launch, K6-K7 takes 16 rows in ~7 us) laid down as ONE dense row-major matrix
+// [rows_pad][dc + 1] -- window columns at their place, rhs last, zeros elsewhere and in the padding rows -- for K6-K7 to take as
+// they are (k_gstream.h, second source).  reference MSCKF.py:594-598 (any orthogonal row compression of the stack serves :604-614)
+constexpr int TRI_GATHER_MAX = 64;
+struct TriGatherArgs {
+    const double* rbuf; double* dst;
+    int dc, n, rows, rows_pad;               // n triangles, sum of their widths, ... rounded up to whole blocks of 16
+    long long off[TRI_GATHER_MAX];           // FoldNode::out_off
+    int w[TRI_GATHER_MAX], col0[TRI_GATHER_MAX], row0[TRI_GATHER_MAX + 1];
+};
+__global__ __launch_bounds__(256) void k_tri_gather(TriGatherArgs p) {
+    const int ld = p.dc + 1;
+    const long long total = (long long)p.rows_pad * ld;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / ld), col = (int)(idx - (long long)row * ld);
+        double v = 0.0;
+        if (row < p.rows) {
+            int k = 0;
+            while (k + 1 < p.n && row >= p.row0[k + 1]) ++k;
+            const int i = row - p.row0[k], w = p.w[k];
+            const int j = (col == p.dc) ? w : col - p.col0[k];
+            if (j >= 0 && (j < w || col == p.dc)) v = p.rbuf[p.off[k] + (long long)i * (w + 1) + j];
+        }
+        p.dst[idx] = v;
+    }
+}
+
 constexpr int FOLD_MAX_SRC = 1024;   // sources per node the LDS bookkeeping can hold
 constexpr int STAGE_U = 4;           // loads in flight per lane while a leaf stages one K4 block
 

@@ -368,9 +368,9 @@ struct msckf_ctx {
     Buf dSplit, dRem;
     int rem_cap = 0;                      // rows the remainder blocks may hold in all (3 per view group)
     // remainder rows (capacity: 3 per view group) up to which K6-K7 takes them as they are (msckf_debug_set_rem_direct_rows).  Measured
-    // on tracks ~ U[2, 30] at N = 30, direct against their own merge tree: 450 tracks 887 / 1420 us, 600 1106 / 1505, 800 1420 / 1653,
-    // 1000 (4900 rows) 1724 / 1777, 1300 2213 / 1895
-    static constexpr int REM_DIRECT_DEFAULT = 5376;
+    // on tracks ~ U[2, 30] at N = 30, as they are against their own (cut) merge tree: 300 tracks 619 / 794 us, 450 886 / 1019,
+    // 600 (3100 rows) 1107 / 1116, 800 1423 / 1273, 1000 1718 / 1340
+    static constexpr int REM_DIRECT_DEFAULT = 3072;
     int rem_leaf_rows = 0;                // rows of a leaf of the remainder rows' merge tree (MSCKF_REM_LEAF_ROWS; 0: one register batch of k_fold)
     int rem_direct_max = REM_DIRECT_DEFAULT, rem_direct_max_wide = 16 * GS_MAX_NB2;
     bool in_merge = false;                // a merge of gathered shard blocks is being launched: its K6-K7 has ONE source of rows, whatever the
@@ -379,12 +379,17 @@ struct msckf_ctx {
                                           //   on the band root starts from that launch's P_out / dx
     bool retry_plain = false;             // a K6-K7 launch timed out once: the context runs without in-launch waits since (msckf_get_result)
     bool fake_timeout_done = false;       // MSCKF_DEBUG_FAKE_TIMEOUT
-    bool rem_direct = false;              // ... few enough (5376; 16384 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
+    bool rem_direct = false;              // ... few enough (3072; 16384 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
     // ... the remainder blocks' own QR: a merge tree beside the band pipeline (second stream), its root the second source of
     // rows for K6-K7 -- applied by a k_gain_stream launch of its own behind the first one, ordered by an event
     std::vector<FoldNode> rnodes;
     std::vector<std::pair<int, int>> rlevels;
     int rroot = -1; size_t rroot_off = 0;
+    // ... or, the tree cut where a further level would remove fewer rows than K6-K7 takes in the launch's time: the triangles it
+    // ends with (k_tri_gather lays them down in dRem as dense rows for a k_gain_stream launch behind the first update)
+    std::vector<int> rtops;
+    int rtop_rows = 0;
+    int rem_cut_rows = -1;                // MSCKF_REM_CUT_ROWS: rows a level must remove to be worth its launch (-1: 600 with R in LDS, else never; 0: never)
     Buf dRNodes;
     hipEvent_t ev_rem = nullptr;
     bool wide_active = false;             // the current plan keeps the wide tracks out of the band pipeline / tree
@@ -579,7 +584,8 @@ struct Run { int b, e; };                 // entries [b, e) of the sorted arrays
 void build_tree(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<int>& fmax,
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid, const std::vector<Run>& runs,
                 size_t off0, std::vector<FoldNode>& nodes, std::vector<std::pair<int, int>>& levels, int& root, size_t& root_off,
-                size_t& off_end, int& n_leaves, int leaf_rows_default = 160, bool tall_merges = false) {
+                size_t& off_end, int& n_leaves, int leaf_rows_default = 160, bool tall_merges = false, int cut_rows = 0,
+                std::vector<int>* tops = nullptr) {
     const int N = c->N;
     const int leaf_rows = c->cfg.leaf_rows > 0 ? c->cfg.leaf_rows : leaf_rows_default;
     const int arity = c->cfg.merge_arity > 0 ? c->cfg.merge_arity : 6;
@@ -654,6 +660,17 @@ void build_tree(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
             i = e;
         }
         if (grps.size() == 1) { grps[0].lo = 0; grps[0].hi = N - 1; }   // the root spans every clone
+        if (cut_rows > 0 && tops && lvl_cnt <= TRI_GATHER_MAX) {
+            // a level that removes fewer than cut_rows rows is not worth its launch: the tree ends with this level's triangles
+            int rows_in = 0, rows_out = 0;
+            for (int k = lvl_base; k < end; ++k) rows_in += nodes[k].w;
+            for (const Grp& g : grps) rows_out += 6 * (g.hi - g.lo + 1);
+            if (rows_in - rows_out < cut_rows) {
+                for (int k = lvl_base; k < end; ++k) tops->push_back(k);
+                root = -1; root_off = 0; off_end = off;
+                return;
+            }
+        }
         for (const Grp& g : grps) push(1, g.b, g.e, g.lo, g.hi);
         lvl_base = nb;
         lvl_cnt = (int)nodes.size() - nb;
@@ -1042,7 +1059,7 @@ void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
                 const std::vector<int>& view_sorted, const std::vector<unsigned char>* valid_in = nullptr) {
     c->xchg_planned = false;
     c->wide_active = false;
-    c->rnodes.clear(); c->rlevels.clear(); c->rroot = -1; c->rroot_off = 0;
+    c->rnodes.clear(); c->rlevels.clear(); c->rroot = -1; c->rroot_off = 0; c->rtops.clear(); c->rtop_rows = 0;
     const int F = c->F, Fs = c->Fs;
     // a block is as valid as the track it was split off
     std::vector<unsigned char> vfull;
@@ -1076,7 +1093,9 @@ void plan_batch(msckf_ctx* c, const std::vector<int>& fmin, const std::vector<in
             //  2175 us per update; by the 3-per-group bound, i.e. two batches per leaf, 2160; leaves of 1024 rows with merges of up
             //  to six triangles 2415)
             build_tree(c, fmin, fmax, view_sorted, valid, {{F + c->nNarrow, Fs}}, c->rbuf_doubles, c->rnodes, c->rlevels, c->rroot,
-                       c->rroot_off, off_end, nl, c->rem_leaf_rows > 0 ? c->rem_leaf_rows : fold_bmax(c->dc), false);
+                       c->rroot_off, off_end, nl, c->rem_leaf_rows > 0 ? c->rem_leaf_rows : (c->dc > FOLD_RLDS_MAX_W ? 512 : fold_bmax(c->dc)), false,
+                       c->rem_cut_rows >= 0 ? c->rem_cut_rows : (c->dc > FOLD_RLDS_MAX_W ? 0 : 600), &c->rtops);
+            for (int k : c->rtops) c->rtop_rows += c->rnodes[k].w;
             c->rbuf_doubles = off_end;
             return;
         }
@@ -1630,6 +1649,38 @@ int launch_gain_chain(msckf_ctx* c, const double* Tblk) {
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
+// ... on the triangles a cut remainder tree ended with (k_tri_gather laid them down in dRem): a dense second source, nothing else
+int launch_tri_gather(msckf_ctx* c, hipStream_t st) {
+    TriGatherArgs g{};
+    g.rbuf = ptr<double>(c->dRbuf); g.dst = ptr<double>(c->dRem);
+    g.dc = c->dc; g.n = (int)c->rtops.size(); g.rows = c->rtop_rows; g.rows_pad = (c->rtop_rows + 15) / 16 * 16;
+    if (g.n < 1 || g.n > TRI_GATHER_MAX || g.rows_pad > 16 * GS_MAX_NB2) { c->last_error = "remainder tree: too many triangles for K6-K7"; return MSCKF_ERR_STATE; }
+    int r0 = 0;
+    for (int k = 0; k < g.n; ++k) {
+        const FoldNode& nd = c->rnodes[c->rtops[k]];
+        g.off[k] = nd.out_off; g.w[k] = nd.w; g.col0[k] = 6 * nd.win_lo; g.row0[k] = r0;
+        r0 += nd.w;
+    }
+    g.row0[g.n] = r0;
+    const long long total = (long long)g.rows_pad * (c->dc + 1);
+    hipLaunchKernelGGL(k_tri_gather, dim3((unsigned)std::min<long long>((total + 255) / 256, 1024)), dim3(256), 0, st, g);
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
+int launch_gain_chain_dense(msckf_ctx* c) {
+    ++c->gs_epoch;
+    GStreamArgs a;
+    fill_gstream_args(c, a, nullptr, c->dc, false);
+    a.P = ptr<double>(c->dPout); a.ldp = c->d; a.dx0 = ptr<double>(c->dDx);
+    a.T2 = ptr<double>(c->dRem); a.ldt2 = c->dc + 1; a.nb2 = (c->rtop_rows + 15) / 16; a.nb2_dev = nullptr;
+    a.status = ptr<int>(c->dStatus) + 1;
+    a.status_h = nullptr; a.dx_h = nullptr; a.Pout_h = nullptr; a.tstamp = nullptr;
+    const size_t lds = gstream_lds_doubles(a.ns, a.nb) * 8;
+    if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
+    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return MSCKF_OK;
+}
 // The root sweep (k_sweep form) and K6-K7 in ONE launch (k_root_gain): workgroup 0 sweeps and publishes the rows of the
 // root block as they become final, workgroups 1.. are the strips of the update.  `sa` carries the tables and the node index.
 bool root_gain_ok(const msckf_ctx* c, int band) {
@@ -1740,13 +1791,14 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[1], c->stream));
     // split long tracks: their remainder blocks' tree follows k_feature<64, true> on the second stream, beside the band
     // pipeline; the leaves below read the narrow blocks that kernel wrote
-    const bool chain = c->F > 0 && c->wide_active && c->rroot >= 0;
+    const bool chain = c->F > 0 && c->wide_active && (c->rroot >= 0 || !c->rtops.empty());
     if (chain) {
         hipStream_t rs = c->wide_on_stream2 ? c->stream2 : c->stream;
         // (the tree reads the plan's tables and writes the workspace: behind their upload / memset, which the main stream is
         //  behind by now -- ev_plan, set_features)
         if (c->wide_on_stream2) { HIPCHK(c, hipEventRecord(c->ev_fork, c->stream)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
         if ((rc = launch_fold_levels(c, c->rlevels, c->rnodes, rs, ptr<FoldNode>(c->dRNodes))) != MSCKF_OK) return rc;
+        if (!c->rtops.empty() && (rc = launch_tri_gather(c, rs)) != MSCKF_OK) return rc;
         if (c->wide_on_stream2) HIPCHK(c, hipEventRecord(c->ev_rem, c->stream2));
     }
     const bool early = c->F > 0 && c->wide_on_stream2 && c->band_plan && c->n_leaves0 > 0 && c->n_leaves0 < c->n_leaves;
@@ -1823,7 +1875,7 @@ int run_pipeline(msckf_ctx* c, bool with_gain, hipEvent_t* stage_ev) {
     }
     if (chain && with_gain) {              // the remainder blocks' rows: a second update behind the first
         if (c->wide_on_stream2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_rem, 0));
-        if ((rc = launch_gain_chain(c, ptr<double>(c->dRbuf) + c->rroot_off)) != MSCKF_OK) return rc;
+        if ((rc = c->rtops.empty() ? launch_gain_chain(c, ptr<double>(c->dRbuf) + c->rroot_off) : launch_gain_chain_dense(c)) != MSCKF_OK) return rc;
     }
     if (stage_ev) HIPCHK(c, hipEventRecord(stage_ev[3], c->stream));
     c->ran = true;
@@ -1888,6 +1940,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
         { const char* e3 = std::getenv("MSCKF_WIDE_STREAM"); c->wide_concurrent = !(e3 && std::atoi(e3) == 0); }
         c->gs_overlap = !(e2 && std::atoi(e2) == 0);
         { const char* e4 = std::getenv("MSCKF_REM_LEAF_ROWS"); if (e4 && std::atoi(e4) >= 16) c->rem_leaf_rows = std::atoi(e4); }
+        { const char* e5 = std::getenv("MSCKF_REM_CUT_ROWS"); if (e5 && std::atoi(e5) >= 0) c->rem_cut_rows = std::atoi(e5); }
     }
     // every failure here is reported at create time (a dropped attribute would only surface later as an
     // opaque launch error of the first kernel that needs the LDS)
@@ -2135,7 +2188,7 @@ int msckf_set_features(msckf_ctx* c, int32_t F, const int32_t* view_ptr, const d
         c->band_plan = false; c->root = -1; c->perm.clear();
         c->Fb = c->Fw = c->Fw1 = 0; c->wide_active = false;
         c->Fs = 0; c->nNarrow = 0; c->sumMs = 0; c->split_on = false; c->rem_cap = 0; c->rem_direct = false; c->h_split.clear(); c->h_parent.clear();
-        c->rnodes.clear(); c->rlevels.clear(); c->rroot = -1;
+        c->rnodes.clear(); c->rlevels.clear(); c->rroot = -1; c->rtops.clear(); c->rtop_rows = 0;
         c->plan_valid = false;
         c->xchg_planned = false;
         if (c->xchg) {
@@ -3708,7 +3761,8 @@ int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
     if (!c || !c->ran) return MSCKF_ERR_STATE;
     // split long tracks: K6-K7 took two sources of rows -- the band root and the remainder blocks' rows (as they are, or the root
     // of their own tree).  For this diagnostic ONE [T | r_n]: the Householder QR of both stacked, on the host.
-    const bool second = c->wide_active && (c->rem_direct || c->rroot >= 0);
+    const bool tops = c->wide_active && !c->rem_direct && !c->rtops.empty();
+    const bool second = c->wide_active && (c->rem_direct || c->rroot >= 0 || tops);
     if (c->root < 0 && !second) return MSCKF_ERR_STATE;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3723,7 +3777,8 @@ int msckf_debug_compressed(msckf_ctx* c, double* T, double* rn) {
             HIPCHK(c, hipMemcpy(nr, ptr<double>(c->dRem) + (size_t)16 * GS_MAX_NB2 * (6 * c->maxN + 1), 8, hipMemcpyDeviceToHost));
             m2 = 16 * nr[0];
         }
-        const double* src2 = c->rem_direct ? ptr<double>(c->dRem) : ptr<double>(c->dRbuf) + c->rroot_off;
+        if (tops) m2 = (c->rtop_rows + 15) / 16 * 16;            // (the triangles a cut tree ended with, as k_tri_gather laid them down)
+        const double* src2 = (c->rem_direct || tops) ? ptr<double>(c->dRem) : ptr<double>(c->dRbuf) + c->rroot_off;
         std::vector<double> A((size_t)(dc + m2) * n, 0.0);
         std::memcpy(A.data(), blk.data(), blk.size() * 8);
         HIPCHK(c, hipMemcpy(A.data() + (size_t)dc * n, src2, (size_t)m2 * n * 8, hipMemcpyDeviceToHost));
@@ -3758,7 +3813,7 @@ int msckf_debug_split(msckf_ctx* c, int32_t out[8]) {
     out[0] = c->split_on ? c->Fw : 0;
     out[1] = c->nNarrow;
     out[2] = c->split_on ? c->rem_cap : 0;
-    out[3] = c->wide_active ? (c->rem_direct ? 1 : (c->rroot >= 0 ? 2 : 0)) : 0;
+    out[3] = c->wide_active ? (c->rem_direct ? 1 : ((c->rroot >= 0 || !c->rtops.empty()) ? 2 : 0)) : 0;
     out[4] = (int)c->rlevels.size();
     out[5] = c->Fs;
     out[6] = c->band_plan ? 1 : 0;

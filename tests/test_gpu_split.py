@@ -48,7 +48,7 @@ def eng():
 
 
 def test_the_plans_the_split_chooses(eng):
-    """few long tracks: remainder rows taken as they are; many: the same (up to 5376 rows); forced small limit: their own tree;
+    """few long tracks: remainder rows taken as they are; many: the same (up to 3072 rows); forced small limit: their own tree;
     a batch most of whose tracks span 11 - 15 slots and none more (BASELINE configs[4]): no split, 90-column tiles."""
     p = synth.few_long_tracks_problem(30, 400, 10, 10, seed=1)
     _check(eng, p)
@@ -106,6 +106,30 @@ def test_long_tracks_against_oracle(eng, N, F, M, seed, kw, direct_rows):
         assert rel_err(r2.dx, ref["dx"]) < TOL and rel_err(r2.P_new, ref["P_new"]) < TOL
     finally:
         eng.set_rem_direct_rows(-1)
+
+
+@pytest.mark.parametrize("cut_rows,levels", [(None, None), ("0", 4), ("200", 3), ("1000", 1)])
+def test_the_remainder_tree_cut_and_whole(monkeypatch, cut_rows, levels):
+    """Many remainder rows: their merge tree ends where a further level would remove fewer rows than K6-K7 takes in the launch's time,
+    and K6-K7 takes the triangles it ends with as dense rows (default: a level must remove 600 rows); MSCKF_REM_CUT_ROWS=0: the
+    whole tree (8 leaves, three merge levels) and its root block; 200: all but the last level; 1000: the leaves' triangles.  All against
+    the oracle (reference MSCKF.py:594-614)."""
+    from msckf_amd.api import UpdateEngine
+    if cut_rows is None:
+        monkeypatch.delenv("MSCKF_REM_CUT_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("MSCKF_REM_CUT_ROWS", cut_rows)
+    prob = synth.make_problem(30, 500, 30, seed=71, variable_tracks=True, min_track=2, outlier_fraction=0.05, outlier_px=300.0)
+    with UpdateEngine(max_clones=30, max_features=512, max_track=30) as e:
+        e.set_rem_direct_rows(0)
+        res, ref = _check(e, prob)
+        s = e.debug_split()
+        assert s["remainder_mode"] == 2 and (s["remainder_tree_levels"] == levels if levels else 1 <= s["remainder_tree_levels"] <= 3), s
+        T, rn = e.debug_compressed()                       # (one [T | r_n] of the band root and the second source's rows)
+        H, r = ref["H_X"][:, 15:], ref["r_o"]
+        assert rel_err(T.T @ T, H.T @ H) < 1e-10 and rel_err(T.T @ rn, H.T @ r) < 1e-10
+        res2 = e.update_problem(prob)
+        assert np.array_equal(res.dx, res2.dx) and np.array_equal(res.P_new, res2.P_new)
 
 
 @pytest.mark.parametrize("case", ["edge_long_tracks", "edge_mixed_spans", "edge_few_long_among_short", "edge_long_tracks_B",
