@@ -6,12 +6,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"gpurun_out/profiles_{tag}"
 dst = "profiles"
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
+newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]       # (gpurun merges every run's files into the same directory)
+stats = newest(f"{src}/stats/*/*_kernel_stats.csv")[0]
 rows = list(csv.DictReader(open(stats)))
 with open(f"{dst}/{tag}_kernel_stats.csv", "w") as f:
     f.write(open(stats).read())
 def pmc(kind):
-    fs = glob.glob(f"{src}/{kind}/*/*_counter_collection.csv")
+    fs = newest(f"{src}/{kind}/*/*_counter_collection.csv")
     if not fs: return {}
     acc = defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(fs[0])):
@@ -22,7 +23,7 @@ fetch, write = pmc("fetch"), pmc("write")
 
 def pmc_multi(kind):
     """kernel -> counter -> (mean per launch, launches) for a pass that collected several counters."""
-    fs = glob.glob(f"{src}/{kind}/*/*_counter_collection.csv")
+    fs = newest(f"{src}/{kind}/*/*_counter_collection.csv")
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     if fs:
         for r in csv.DictReader(open(fs[0])):
