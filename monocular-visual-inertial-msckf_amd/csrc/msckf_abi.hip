@@ -1590,7 +1590,10 @@ void fill_gstream_args(msckf_ctx* c, GStreamArgs& a, const double* Tblk, int ban
     a.sigma2 = c->sigma * c->sigma;
     a.d = d; a.dc = dc; a.nb = nb; a.ns = nb + 1; a.ncb = gstream_ncb(dc, band);
     a.nb1 = Tblk ? nb : 0;
-    a.f32_update = c->cfg.dtype == MSCKF_DTYPE_F32 ? 1 : 0;
+    // (dtype = f32: the rank-16 products of the P-update on the f32 matrix cores -- but not for a batch with split long tracks: its
+    //  dense remainder rows add tens of row blocks, every one an fp32-rounded product against a covariance that keeps shrinking;
+    //  tools/soak_holes.py 150 8 f32, (48, 370, <= 22 views): dx off by 2.5e-4 with them, against the mode's 1e-4)
+    a.f32_update = (c->cfg.dtype == MSCKF_DTYPE_F32 && !(c->wide_active && !c->in_merge)) ? 1 : 0;
     if (c->wide_active && c->rem_direct && !c->t2_early && !c->in_merge) {
         a.T2 = ptr<double>(c->dRem); a.ldt2 = dc + 1; a.nb2 = (c->rem_cap + 15) / 16;
         a.nb2_dev = reinterpret_cast<const int*>(ptr<double>(c->dRem) + (size_t)16 * GS_MAX_NB2 * (6 * c->maxN + 1));
