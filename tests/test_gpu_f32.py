@@ -82,3 +82,25 @@ def test_bad_dtype_is_refused():
     from msckf_amd.api import UpdateEngine
     with pytest.raises(ValueError):
         UpdateEngine(dtype="bf16")
+
+
+def test_ragged_long_tracks_keep_the_tolerance(eng32):
+    """A ragged batch with split long tracks -- tens of dense remainder row blocks through K6-K7 -- on a 48-clone
+    window: the batch `tools/soak_holes.py 150 8 f32` found 2.5e-4 off on dx while the P-update's rank-16 products of those blocks
+    ran on the f32 matrix cores; with split long tracks in the batch they stay fp64 (6e-6).  reference MSCKF.py:604-614."""
+    import importlib.util, os
+    from oracle import msckf_oracle as oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("soak_holes", os.path.join(root, "tools", "soak_holes.py"))
+    sh = importlib.util.module_from_spec(spec); spec.loader.exec_module(sh)
+    rng = np.random.default_rng(8)
+    for _ in range(124):                                   # (the soak's own sequence: case 123)
+        N = int(rng.integers(2, 54)); F = int(rng.integers(1, 400))
+        hi = int(rng.integers(2, min(N, 31) + 1))
+        prob = sh.ragged(rng, N, F, 2, hi, float(rng.choice([0.0, 0.1, 0.4])))
+    assert (prob.N, prob.F) == (48, 370)
+    ref = oracle.update(prob, dense_noise=False)
+    res = eng32.update_problem(prob)
+    assert res.status == ref["status"] == 0 and np.array_equal(res.accepted, ref["accepted"])
+    assert eng32.debug_split()["long_tracks"] > 0
+    assert rel_err(res.dx, ref["dx"]) < TOL_DX and rel_err(res.P_new, ref["P_new"]) < TOL_P
