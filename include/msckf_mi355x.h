@@ -369,7 +369,7 @@ int msckf_debug_time_select(msckf_ctx* ctx, int32_t iters, float* us_per_launch)
  * block), 1 takes them as they are (dense second source), 2 takes the root of their own merge tree in a second launch;
  * out[4] levels of that tree, out[5] entries of the sorted arrays (tracks + blocks), out[6] 1: band plan, out[7] sweep mode. */
 int msckf_debug_split(msckf_ctx* ctx, int32_t out[8]);
-/* Tests: remainder rows up to which K6-K7 takes them as they are (default 3072; < 0 restores it).  Applies to the
+/* Tests: remainder rows up to which K6-K7 takes them as they are (default 3840; < 0 restores it).  Applies to the
  * batches loaded afterwards. */
 int msckf_debug_set_rem_direct_rows(msckf_ctx* ctx, int32_t rows);
 /* Raw device pointers (as integers) for zero-copy interop: which = 0 dx (dx[d] | P_out[d*d] are contiguous for the

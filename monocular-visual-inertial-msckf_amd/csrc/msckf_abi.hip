@@ -26,6 +26,7 @@
 #include "k_fold.h"
 #include "k_gain.h"
 #include "k_gstream.h"
+#include "k_gdense.h"
 #include "k_select.h"
 #include "k_sweep.h"
 #include "k_wsweep.h"
@@ -368,9 +369,9 @@ struct msckf_ctx {
     Buf dSplit, dRem;
     int rem_cap = 0;                      // rows the remainder blocks may hold in all (3 per view group)
     // remainder rows (capacity: 3 per view group) up to which K6-K7 takes them as they are (msckf_debug_set_rem_direct_rows).  Measured
-    // on tracks ~ U[2, 30] at N = 30, as they are against their own (cut) merge tree: 300 tracks 619 / 794 us, 450 886 / 1019,
-    // 600 (3100 rows) 1107 / 1116, 800 1423 / 1273, 1000 1718 / 1340
-    static constexpr int REM_DIRECT_DEFAULT = 3072;
+    // on tracks ~ U[2, 30] at N = 30, as they are against their own (cut) merge tree: 450 tracks 777 / 971 us, 600 (3100 rows)
+    // 961 / 1056, 800 (4250 rows) 1221 / 1185, 1000 1486 / 1286
+    static constexpr int REM_DIRECT_DEFAULT = 3840;
     int rem_leaf_rows = 0;                // rows of a leaf of the remainder rows' merge tree (MSCKF_REM_LEAF_ROWS; 0: one register batch of k_fold)
     int rem_direct_max = REM_DIRECT_DEFAULT, rem_direct_max_wide = 16 * GS_MAX_NB2;
     bool in_merge = false;                // a merge of gathered shard blocks is being launched: its K6-K7 has ONE source of rows, whatever the
@@ -379,7 +380,7 @@ struct msckf_ctx {
                                           //   on the band root starts from that launch's P_out / dx
     bool retry_plain = false;             // a K6-K7 launch timed out once: the context runs without in-launch waits since (msckf_get_result)
     bool fake_timeout_done = false;       // MSCKF_DEBUG_FAKE_TIMEOUT
-    bool rem_direct = false;              // ... few enough (3072; 16384 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
+    bool rem_direct = false;              // ... few enough (3840; 16384 on windows of more than 31 clones): K6-K7 takes them as they are (k_rem_scatter), no QR of their own
     // ... the remainder blocks' own QR: a merge tree beside the band pipeline (second stream), its root the second source of
     // rows for K6-K7 -- applied by a k_gain_stream launch of its own behind the first one, ordered by an event
     std::vector<FoldNode> rnodes;
@@ -1614,6 +1615,19 @@ int launch_gain_stream(msckf_ctx* c, const double* Tblk, int band) {
     c->gain_blocked = false;
     return MSCKF_OK;
 }
+// K6-K7 on a dense source of rows alone: two row blocks per exchange where the window allows it (k_gdense.h: 7.1 -> 6.1 us per
+// block at N = 30; MSCKF_GAIN_DENSE=0: the one-block kernel)
+void launch_gain_dense_rows(msckf_ctx* c, const GStreamArgs& a, hipStream_t st) {
+    static const bool pairs = [] { const char* e = std::getenv("MSCKF_GAIN_DENSE"); return !e || std::atoi(e) != 0; }();
+    const size_t ldsp = gdense_lds_doubles(a.ns, a.nb) * 8;
+    if (pairs && a.nb1 == 0 && a.nb2 > 0 && a.ns <= 14 && ldsp <= (size_t)(LDS_MAX_BYTES - 1024)) {
+        hipLaunchKernelGGL(k_gain_dense, dim3(a.ns), dim3(64 * GS_WAVES), ldsp, st, a);
+        return;
+    }
+    const size_t lds = gstream_lds_doubles(a.ns, a.nb) * 8;
+    if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, st, a);
+    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, st, a);
+}
 // MANY dense remainder rows (more than the root sweep's ~110 us cover at ~9 us per block on the nine-wavefront strips of its
 // launch): the update on them runs as a launch of its own, sixteen wavefronts per strip (~7 us per block), on the stream that made
 // them -- beside the band pipeline's leaves, which do not touch P -- from the prior P into P_out / dx (status word 1); the update on
@@ -1627,9 +1641,7 @@ int launch_gain_t2_early(msckf_ctx* c, hipStream_t st) {
     c->t2_early = keep;
     a.status = ptr<int>(c->dStatus) + 1;
     a.status_h = nullptr; a.dx_h = nullptr; a.Pout_h = nullptr; a.tstamp = nullptr;
-    const size_t lds = gstream_lds_doubles(a.ns, a.nb) * 8;
-    if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, st, a);
-    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, st, a);
+    launch_gain_dense_rows(c, a, st);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -1678,9 +1690,7 @@ int launch_gain_chain_dense(msckf_ctx* c) {
     a.T2 = ptr<double>(c->dRem); a.ldt2 = c->dc + 1; a.nb2 = (c->rtop_rows + 15) / 16; a.nb2_dev = nullptr;
     a.status = ptr<int>(c->dStatus) + 1;
     a.status_h = nullptr; a.dx_h = nullptr; a.Pout_h = nullptr; a.tstamp = nullptr;
-    const size_t lds = gstream_lds_doubles(a.ns, a.nb) * 8;
-    if (a.ns <= GS_WAVES) hipLaunchKernelGGL(k_gain_stream<1>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
-    else hipLaunchKernelGGL(k_gain_stream<2>, dim3(a.ns), dim3(64 * GS_WAVES), lds, c->stream, a);
+    launch_gain_dense_rows(c, a, c->stream);
     HIPCHK(c, hipGetLastError());
     return MSCKF_OK;
 }
@@ -1994,6 +2004,7 @@ int msckf_create(msckf_ctx** out, const msckf_config* cfg) {
     lds_attr(reinterpret_cast<const void*>(&k_feature<64, true, 4>), LDS_MAX_BYTES - 1024, "k_feature<64, true, 4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<1>), LDS_MAX_BYTES - 1024, "k_gain_stream<1> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_gain_stream<2>), LDS_MAX_BYTES - 1024, "k_gain_stream<2> LDS attribute");
+    lds_attr(reinterpret_cast<const void*>(&k_gain_dense), LDS_MAX_BYTES - 1024, "k_gain_dense LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<8, 4, LS_RS4, true>), FOLD_LDS_BYTES, "k_lsweep<8,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<12, 4, LS_RS4, false>), FOLD_LDS_BYTES, "k_lsweep<12,4> LDS attribute");
     lds_attr(reinterpret_cast<const void*>(&k_lsweep<SWEEP_NW, 6, LS_RS6>), FOLD_LDS_BYTES, "k_lsweep<6> LDS attribute");

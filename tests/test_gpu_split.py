@@ -48,7 +48,7 @@ def eng():
 
 
 def test_the_plans_the_split_chooses(eng):
-    """few long tracks: remainder rows taken as they are; many: the same (up to 3072 rows); forced small limit: their own tree;
+    """few long tracks: remainder rows taken as they are; many: the same (up to 3840 rows); forced small limit: their own tree;
     a batch most of whose tracks span 11 - 15 slots and none more (BASELINE configs[4]): no split, 90-column tiles."""
     p = synth.few_long_tracks_problem(30, 400, 10, 10, seed=1)
     _check(eng, p)

@@ -11,6 +11,7 @@
 #include <random>
 #include <vector>
 #include "k_gstream.h"
+#include "k_gdense.h"
 
 using namespace msckf;
 
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
     const double us_row = argc > 3 ? atof(argv[3]) : 0.6;
     const int reps = argc > 4 ? atoi(argv[4]) : 20;
     const int nb2 = argc > 5 ? atoi(argv[5]) : 0;
+    const int pairs = argc > 6 ? atoi(argv[6]) : 0;         // 1: k_gain_dense (two row blocks per exchange) on the dense source
     const int dc = 6 * N, d = 15 + dc, ldt = dc + 1;
     const int nb = (dc + 15) / 16, ns = nb + 1;
     const int ncb = gstream_ncb(dc, band);
@@ -210,9 +212,12 @@ int main(int argc, char** argv) {
         CK(hipMemset(dFlag2, 0, (size_t)(nb2 + nb) * ns * 8 + 64));
         CK(hipMalloc(&dSt2, (size_t)(nb2 + 80) * 8 * 8)); CK(hipMemset(dSt2, 0, (size_t)(nb2 + 80) * 8 * 8));
         a.ex = dEx2; a.exflag = dFlag2; a.T = nullptr; a.nb1 = 0; a.T2 = dR; a.ldt2 = ldt; a.nb2 = nb2; a.progress = nullptr; a.stamps = dSt2;
-        const size_t lds2 = gstream_lds_doubles(ns, nb) * 8;
+        const size_t lds2 = pairs ? gdense_lds_doubles(ns, nb) * 8 : gstream_lds_doubles(ns, nb) * 8;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gain_dense), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        if (pairs && (ns > 14 || lds2 > 160 * 1024 - 1024)) { std::printf("k_gain_dense: window too large\n"); return 1; }
         auto launch2 = [&](hipStream_t st) {
-            if (ns <= 16) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds2, st, a);
+            if (pairs) hipLaunchKernelGGL(k_gain_dense, dim3(ns), dim3(64 * GS_WAVES), lds2, st, a);
+            else if (ns <= 16) hipLaunchKernelGGL(k_gain_stream<1>, dim3(ns), dim3(64 * GS_WAVES), lds2, st, a);
             else hipLaunchKernelGGL(k_gain_stream<2>, dim3(ns), dim3(64 * GS_WAVES), lds2, st, a);
         };
         int rc2 = 0;
