@@ -3,10 +3,12 @@
 //   reference MSCKF.py:604-607, :612-614 (k_gstream.h restates them as the sequential block update this kernel runs)
 // A row block of k_gstream.h costs ~7 us, half of it the ONE all-to-all exchange of its Y tiles.  Here blocks a = 2 p and
 // b = 2 p + 1 share an exchange: both Y_a = P^(a) T_a^T and Y^_b = P^(a) T_b^T go out together (Y^_b is short of block a's update),
-// and with W = T_b X_a (16 x 16: V = T_b Y_a follows block a's pivots in the eliminating wavefront's registers)
+// and with W = T_b X_a (16 x 16: V = T_b Y_a follows block a's pivots like any tile, in the publishing wavefront, which is idle then)
 //     Y_b = Y^_b - X_a W^T,     A_b = T_b Y^_b - W W^T + sigma^2 I
-// are what the sequential update would have formed after block a.  Per pair: one exchange, four workgroup barriers (two blocks of
-// k_gstream.h: two and six), 32 matrix-core instructions per tile wavefront instead of 24.
+// are what the sequential update would have formed after block a; block a's rank-16 update of P runs while block b is eliminated.
+// Per pair: one exchange, four workgroup barriers (two blocks of k_gstream.h: two and six), 32 matrix-core instructions per tile
+// wavefront instead of 24.  Measured (tools/ubench/gstream_test.hip N band us_per_row reps nb2 1): 7.1 -> 6.1 us per block at N = 30,
+// 7.7 -> 6.9 at N = 33; results to 1e-14 of the dense evaluation of MSCKF.py:604-614, odd block counts included.
 // One tile per wavefront, the publishing and the eliminating wavefront without one (ns <= 14 strips): windows of up to 33 clones.
 #pragma once
 #include "k_gstream.h"
